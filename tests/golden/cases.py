@@ -1,0 +1,180 @@
+"""Deterministic synthetic inputs for the golden vectors (shared by make_golden.py and the tests).
+
+Inputs are regenerated from a seed (torch CPU generator -- identical on the build container and the
+GPU box, same image); each fixture stores a checksum of X so a generator mismatch is detected rather
+than silently compared.  Distributions follow SURVEY.md 8(d).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+D = 512
+LOGIT_SCALE = 4.0309  # trained value of the shipped checkpoint
+
+
+def gen(seed: int):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def make_bag(N: int, seed: int, kind: str = "iid", dtype=torch.float32, d: int = D) -> torch.Tensor:
+    """kind: 'iid' N(0,1); 'clustered' 64 Gaussian clusters sigma=0.1; 'adversarial' (see below)."""
+    g = gen(seed)
+    if kind == "iid":
+        X = torch.randn(N, d, generator=g)
+    elif kind == "clustered":
+        centers = torch.randn(64, d, generator=g)
+        idx = torch.randint(0, 64, (N,), generator=g)
+        X = centers[idx] + 0.1 * torch.randn(N, d, generator=g)
+    elif kind == "adversarial":
+        # all-zero row (1e-12 clamp), duplicated rows (ties at the max), |x| >> 1 and |x| << 1 rows
+        X = torch.randn(N, d, generator=g)
+        X[0] = 0.0
+        if N > 4:
+            X[3] = X[2]
+            X[4] = 1e4 * X[4]
+        if N > 6:
+            X[5] = 1e-4 * X[5]
+            X[6] = -X[2]
+    else:
+        raise ValueError(kind)
+    if dtype == torch.bfloat16:
+        X = X.to(torch.bfloat16).to(torch.float32)  # oracle = fp32 math on the bf16-rounded values
+    return X
+
+
+def make_params(P: int, K: int, seed: int, gated: bool = False, d: int = D, aligned_to=None):
+    """Q[P(+1),d] ~ 0.5*N + N, T[K,d] ~ N, W,b ~ U(+-1/sqrt(d)).
+
+    ``aligned_to`` (a bag) adds a multiple of a few patch rows to the queries so that some scores are
+    close to +-100 (adversarial case)."""
+    g = gen(seed)
+    nq = P + 1 if gated else P
+    prompt = torch.randn(nq, d, generator=g)
+    resid = torch.randn(nq, d, generator=g)
+    T = torch.randn(K, d, generator=g)
+    bound = 1.0 / math.sqrt(d)
+    W = (torch.rand(d, d, generator=g) * 2 - 1) * bound
+    b = (torch.rand(d, generator=g) * 2 - 1) * bound
+    if aligned_to is not None:
+        n = aligned_to.shape[0]
+        prompt[0] = prompt[0] + 40.0 * aligned_to[min(2, n - 1)] / aligned_to[min(2, n - 1)].norm().clamp_min(1e-6) * math.sqrt(d)
+        prompt[1 % nq] = prompt[1 % nq] - 40.0 * aligned_to[min(1, n - 1)] / aligned_to[min(1, n - 1)].norm().clamp_min(1e-6) * math.sqrt(d)
+    return dict(prompt=prompt, resid=resid, T=T, W=W, b=b)
+
+
+def _uniform(g, shape, bound):
+    return (torch.rand(*shape, generator=g) * 2 - 1) * bound
+
+
+def make_pool_params(kind: str, seed: int, d: int = D, hid: int = 256):
+    """Seeded parameters of Attention_Pooling / Gated_Attention_Pooling / VLFAN 'weight' pooling
+    (nn.Linear-style uniform(+-1/sqrt(fan_in)) init), so fixtures need not store them."""
+    g = gen(seed)
+    bd, bh = 1.0 / math.sqrt(d), 1.0 / math.sqrt(hid)
+    if kind == "attention":
+        return dict(w1=_uniform(g, (hid, d), bd), b1=_uniform(g, (hid,), bd),
+                    w2=_uniform(g, (1, hid), bh), b2=_uniform(g, (1,), bh))
+    if kind == "gated_attention":
+        return dict(wa=_uniform(g, (hid, d), bd), ba=_uniform(g, (hid,), bd),
+                    wg=_uniform(g, (hid, d), bd), bg=_uniform(g, (hid,), bd),
+                    w2=_uniform(g, (1, hid), bh), b2=_uniform(g, (1,), bh))
+    if kind == "weight":
+        return dict(weight=torch.randn(1, hid, generator=g))  # caller slices [:, :P]
+    return {}
+
+
+def make_adapter_params(seed: int, d: int = D, reduction: int = 4):
+    g = gen(seed)
+    h = d // reduction
+    return dict(down=_uniform(g, (h, d), 1.0 / math.sqrt(d)), up=_uniform(g, (d, h), 1.0 / math.sqrt(h)))
+
+
+BIG = 8192
+SAMPLE_ROWS = (0, 1, -2, -1)
+
+
+def pack_big(out: dict, key: str, t: torch.Tensor):
+    """Store a tensor in a fixture dict; large 2-D tensors as 4 sampled rows + Frobenius norm + sum."""
+    t = t.detach()
+    if t.numel() <= BIG or t.dim() != 2:
+        out[key] = t.numpy()
+    else:
+        out[key + "@rows"] = t[list(SAMPLE_ROWS)].numpy()
+        out[key + "@fro"] = t.double().norm().numpy()
+        out[key + "@sum"] = t.double().sum().numpy()
+
+
+def check_big(fx, key: str, t: torch.Tensor, atol: float, rtol: float = 0.0):
+    """Assert a tensor matches what pack_big stored.  Returns the max abs error seen."""
+    import numpy as np
+    t = t.detach().cpu()
+    if key in fx:
+        ref = torch.from_numpy(np.asarray(fx[key])).reshape(t.shape)
+        err = (t.double() - ref.double()).abs().max().item() if t.numel() else 0.0
+        tol = atol + rtol * ref.double().abs().max().item() if t.numel() else atol
+        assert err <= tol, f"{key}: max abs err {err:.3e} > {tol:.3e}"
+        return err
+    rows = torch.from_numpy(np.asarray(fx[key + "@rows"]))
+    got = t[list(SAMPLE_ROWS)]
+    err = (got.double() - rows.double()).abs().max().item()
+    tol = atol + rtol * rows.double().abs().max().item()
+    assert err <= tol, f"{key}@rows: max abs err {err:.3e} > {tol:.3e}"
+    fro = float(fx[key + "@fro"])
+    assert abs(t.double().norm().item() - fro) <= 1e-3 * fro + atol * math.sqrt(t.numel()), f"{key}@fro"
+    return err
+
+
+def checksum(X: torch.Tensor):
+    x = X.double()
+    return [float(x.sum()), float((x * x).sum()), float(x[-1, -1])]
+
+
+# ---- case tables ------------------------------------------------------------------------------
+# VLFAN through the real VLSA.forward (cached-text branch)
+VLFAN_CASES = [
+    # name,            N,    P,  K, pooling,           head,       gated, kind,         seed, grads
+    ("n1_p4",          1,    4,  4, "mean",            "default",  False, "iid",        101, True),
+    ("n2_p7",          2,    7,  8, "mean",            "default",  False, "iid",        102, True),
+    ("n17_p8_max",     17,   8, 12, "max",             "default",  False, "iid",        103, True),
+    ("n257_p12_wt",    257, 12, 12, "weight",          "default",  False, "iid",        104, True),
+    ("n2798_shipped",  2798, 12, 12, "mean",           "default",  False, "iid",        105, True),
+    ("n4096_p13_id",   4096, 13,  4, "mean",           "Identity", False, "iid",        106, True),
+    ("n257_attn",      257, 12,  8, "attention",       "default",  False, "iid",        107, True),
+    ("n257_gattn",     257, 12,  8, "gated_attention", "default",  False, "iid",        108, True),
+    ("n300_gatedq",    300,  8,  8, "mean",            "default",  True,  "iid",        109, True),
+    ("n64_adv",        64,  12, 12, "mean",            "default",  False, "adversarial", 110, True),
+    ("n1000_clust",    1000, 12, 4, "mean",            "default",  False, "clustered",  111, True),
+    ("n1000_bf16",     1000, 12, 4, "mean",            "default",  False, "iid_bf16",   112, False),
+    ("n16_p16",        16,  16, 16, "mean",            "default",  False, "iid",        113, True),
+    ("n33_p1",         33,   1,  1, "mean",            "default",  False, "iid",        114, True),
+]
+
+ZEROSHOT_CASES = [
+    # name, N, K, pooling, seed
+    ("zs_mean", 500, 4, "logit_mean", 201),
+    ("zs_max", 500, 4, "logit_max", 202),
+    ("zs_top10", 500, 4, "logit_top10", 203),
+    ("zs_top10_n5", 5, 4, "logit_top10", 204),
+    ("zs_top3_k12", 1000, 12, "logit_top3", 205),
+    ("fm_mean", 100, 4, "mean", 206),
+    ("fm_max", 100, 4, "max", 207),
+]
+
+DEEPMIL_CASES = [
+    # name, N, K, pooling, seed
+    ("dm_attn", 300, 12, "attention", 301),
+    ("dm_gattn", 300, 12, "gated_attention", 302),
+    ("dm_mean", 50, 4, "mean", 303),
+    ("dm_max", 50, 4, "max", 304),
+    ("dm_attn_n1", 1, 4, "attention", 305),
+]
+
+
+def bag_for_case(N, kind, seed):
+    if kind == "iid_bf16":
+        return make_bag(N, seed, "iid", torch.bfloat16)
+    return make_bag(N, seed, kind)
