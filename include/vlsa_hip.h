@@ -1,0 +1,129 @@
+/*
+ * vlsa_hip.h -- C ABI of the MI355X-native VLSA patch-aggregation hot path (libvlsa_hip.so).
+ *
+ * The upstream reference (liupei101/VLSA) has no FFI / operator registry: its replaceable seam is the
+ * duck-typed Python module interface.  These entry points are what a ctypes binding on
+ * the reference side would call in place of the torch op sequences cited next to each function
+ * (paths relative to the reference root).  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless said otherwise; all buffers are caller-allocated;
+ *   - no allocation, no synchronisation, no global state inside: each call only enqueues kernels (and
+ *     hipMemsetAsync nodes) on `stream` (a hipStream_t passed as void*), so calls are re-entrant across
+ *     streams and capturable in a hipGraph;
+ *   - return value: 0 on success, a negative VLSA_E* code otherwise (nothing was enqueued then);
+ *   - matrices are row-major; `ldx` is the row stride of X in ELEMENTS;
+ *   - P = number of effective queries (<= VLSA_MAX_P); with the gated query the caller passes nq = P+1
+ *     raw queries to vlsa_prepare_queries and the subtraction is folded into the effective queries;
+ *   - "log2 domain": scores t = s * log2(e) with s = coattn_scale * cos(q, x); m2 = max t.
+ */
+#ifndef VLSA_HIP_H
+#define VLSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLSA_ABI_VERSION 1
+#define VLSA_MAX_P 16      /* queries per bag (reference: 7..12 prototypes (+1 gate), runner/global_cfg.py:1-22) */
+#define VLSA_MAX_K 64      /* ordinal rank prompts / classes */
+#define VLSA_MAX_D 1024    /* feature dim; the tuned MFMA kernels need D == 512 (CONCH) */
+
+#define VLSA_DT_F32 0
+#define VLSA_DT_BF16 1
+
+#define VLSA_OK 0
+#define VLSA_EINVAL (-1)      /* bad argument (null pointer, size out of range, misaligned) */
+#define VLSA_EUNSUPPORTED (-2)/* valid request the library has no kernel for */
+#define VLSA_ELAUNCH (-3)     /* hipLaunch / hipMemsetAsync reported an error */
+
+/* kernel selection for vlsa_vlfan_partial */
+#define VLSA_KERNEL_AUTO 0
+#define VLSA_KERNEL_GENERIC 1 /* fp32 VALU kernel, any D <= VLSA_MAX_D with D % 8 == 0 */
+#define VLSA_KERNEL_MFMA 2    /* split-bf16 MFMA kernel, D == 512 */
+
+/* query pooling over the P aggregated rows (model/deepmil.py:133-150) */
+#define VLSA_POOL_MEAN 0
+#define VLSA_POOL_MAX 1
+#define VLSA_POOL_WEIGHT 2    /* softmax(pool_w[P]) @ out */
+#define VLSA_POOL_GIVEN 3     /* `out` already holds ONE pooled row (P == 1): attention poolings done by the caller */
+
+int vlsa_abi_version(void);
+const char* vlsa_error_string(int code);
+
+/* Number of per-workgroup partials vlsa_vlfan_partial writes for a shard of N rows (deterministic). */
+int vlsa_num_partials(int64_t N);
+
+/* Bytes of the opaque prepared-query block for feature dim D. */
+size_t vlsa_qprep_bytes(int D);
+
+/*
+ * Replaces: Q = F.normalize(Q.unsqueeze(0), dim=-1) and, with gated_query, the later
+ * A_[:, :-1] - A_[:, -1:] (model/deepmil.py:187,192-195) -- folded into effective queries
+ * e_p = q^_p - q^_gate, which is exact because the score is linear in the query.
+ *   Q      [nq, D] fp32 raw queries (nq = P, or P+1 when gated)
+ *   qprep  opaque block of vlsa_qprep_bytes(D): fp32 effective queries, their 3-term bf16 split,
+ *          fp32 unit queries q^ [nq, D] and raw norms [nq] (the last two are what backward needs).
+ */
+int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, void* qprep, void* stream);
+/* Accessors into the opaque block (device pointers; for backward and for tests). */
+const float* vlsa_qprep_qeff(const void* qprep, int D);   /* [16, D] effective queries, rows >= P zero */
+const float* vlsa_qprep_qhat(const void* qprep, int D);   /* [17, D] unit queries */
+const float* vlsa_qprep_qnorm(const void* qprep, int D);  /* [17] max(||q||, 1e-12) */
+
+/*
+ * Replaces: norm_X = F.normalize(X); A_ = Q @ norm_X^T; A_ *= 100; softmax over N; out = A @ X
+ * (model/deepmil.py:189-200), as ONE streaming pass over the shard's rows producing per-workgroup
+ * online-softmax partials:
+ *   pm   [G, 16]   log2-domain running max per query        (G = vlsa_num_partials(N))
+ *   pl   [G, 16]   sum_n exp2(t_pn - pm)
+ *   pacc [G, P, D] sum_n exp2(t_pn - pm) x_n
+ *   scores (nullable) [P, N] log2-domain scores t_pn, needed only when attention weights are wanted.
+ * X: [N, D] rows, dtype VLSA_DT_F32 or VLSA_DT_BF16, row stride ldx elements, 16-byte aligned rows.
+ * coattn_scale: the reference's exp(coattn_logit_scale) = 100 (model/deepmil.py:120-126,197).
+ */
+int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int P,
+                       float coattn_scale, int kernel, float* pm, float* pl, float* pacc, float* scores,
+                       void* stream);
+
+/*
+ * Log-sum-exp merge of G partials (from this GPU's workgroups, or all-gathered from the other ranks):
+ *   m2 [16], l [16], out [P, D];  normalise != 0 -> out_p = acc_p / l_p (the reference's A @ X row),
+ *   normalise == 0 -> out holds the un-normalised merged acc (a compact partial for the RCCL exchange).
+ */
+int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int normalise,
+                     float* m2, float* l, float* out, void* stream);
+
+/* A[p, n] = exp2(scores[p, n] - m2[p]) / l[p]   (softmax of model/deepmil.py:198). */
+int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, const float* l, float* A,
+                        void* stream);
+
+/* out[r, :] = in[r, :] / max(||in[r, :]||, 1e-12); norms[r] (nullable) = that denominator. (F.normalize) */
+int vlsa_normalize_rows(const float* in, int rows, int D, float* out, float* norms, void* stream);
+
+/* Bytes of scratch vlsa_head_forward needs (ticket counter + slabs). */
+size_t vlsa_head_workspace_bytes(int D);
+
+/*
+ * Replaces: forward_query_pooling (mean | max | weight) -> visual_adapter (nn.Linear or Identity) ->
+ * F.normalize -> exp(logit_scale) * v^ @ T^^T (model/deepmil.py:203-204, model/vlsa.py:188-192), and
+ * optionally the softmax output converter (utils/func.py:43-44).
+ *   rows [P, D]; pool_w [P] raw 'weight' pooling parameter (nullable); W [D, D], b [D] (nullable => Identity)
+ *   That [K, D] UNIT-norm text features; logit_scale: device pointer to the scalar parameter (pre-exp)
+ *   outputs: pooled [D], v [D], vhat [D], vnorm [1], logits [K], incidence [K] (nullable)
+ */
+int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                      const float* b, const float* That, int K, const float* logit_scale, void* workspace,
+                      float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                      void* stream);
+
+/* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
+int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLSA_HIP_H */

@@ -1,0 +1,46 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and the product path refuses CPU tensors loudly (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vlsa_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vlsa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from vlsa_amd import build, _native
+    build.build_native()
+    lib = _native.load()
+    declared = _header_symbols()
+    assert declared, "no declarations parsed from include/vlsa_hip.h"
+    for name in declared:
+        assert hasattr(lib, name), f"libvlsa_hip.so does not export {name}"
+    assert set(_native.exported_symbols()) == set(declared), "binding and header disagree"
+    assert lib.vlsa_abi_version() == _native.ABI_VERSION
+
+
+def test_host_side_queries_need_no_gpu():
+    from vlsa_amd import _native
+    lib = _native.load()
+    assert lib.vlsa_num_partials(0) == 1
+    assert lib.vlsa_num_partials(1) == 1
+    assert lib.vlsa_num_partials(33) == 2
+    assert lib.vlsa_num_partials(50_000) == 256
+    assert lib.vlsa_qprep_bytes(512) == 16 * 512 * 4 + 3 * 16 * 512 * 2 + 17 * 512 * 4 + 128
+    assert lib.vlsa_error_string(-1) == b"invalid argument"
+
+
+def test_cpu_tensor_is_refused_loudly():
+    from vlsa_amd import VlsaNativeError, functional as F
+    X = torch.randn(8, 512)
+    Q = torch.randn(4, 512)
+    with pytest.raises(VlsaNativeError):
+        F.vlfan_aggregate(X, Q)

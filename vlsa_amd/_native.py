@@ -1,0 +1,92 @@
+"""ctypes binding of libvlsa_hip.so -- the ONLY compute backend of this package.
+
+There is no CPU / eager-PyTorch fallback: if the shared library is missing or a call fails, the
+caller gets a ``VlsaNativeError`` immediately (the product path must fail loudly, never silently
+route around the HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libvlsa_hip.so")
+ABI_VERSION = 1
+
+# mirrors include/vlsa_hip.h
+DT_F32, DT_BF16 = 0, 1
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+POOL_MEAN, POOL_MAX, POOL_WEIGHT, POOL_GIVEN = 0, 1, 2, 3
+MAX_P, MAX_K, MAX_D = 16, 64, 1024
+P_STRIDE = 16
+
+
+class VlsaNativeError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "vlsa_abi_version": (c_int, []),
+    "vlsa_error_string": (c_char_p, [c_int]),
+    "vlsa_num_partials": (c_int, [c_int64]),
+    "vlsa_qprep_bytes": (c_size_t, [c_int]),
+    "vlsa_qprep_qeff": (c_void_p, [c_void_p, c_int]),
+    "vlsa_qprep_qhat": (c_void_p, [c_void_p, c_int]),
+    "vlsa_qprep_qnorm": (c_void_p, [c_void_p, c_int]),
+    "vlsa_prepare_queries": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "vlsa_vlfan_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_float, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_vlfan_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "vlsa_attn_normalise": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_head_workspace_bytes": (c_size_t, [c_int]),
+    "vlsa_head_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "vlsa_debug_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked against include/vlsa_hip.h in the tests)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """dlopen the library (once) and type every entry point.  Raises VlsaNativeError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise VlsaNativeError(
+            f"{_LIB_PATH} is missing: build it with `python -m vlsa_amd.build` (hipcc, gfx950). "
+            "vlsa_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(_LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise VlsaNativeError(f"cannot load {_LIB_PATH}: {exc}") from exc
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise VlsaNativeError(f"{_LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.vlsa_abi_version()
+    if ver != ABI_VERSION:
+        raise VlsaNativeError(f"ABI mismatch: library {ver}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().vlsa_error_string(code).decode()
+        raise VlsaNativeError(f"{what} failed: {msg} ({code})")

@@ -1,0 +1,326 @@
+// Tail of the per-bag forward: partial merge, attention-weight normalisation, row normalisation and the
+// bag-level incidence head (query pooling -> visual adapter -> cosine logits against the rank prompts).
+// All of it is P x D / D x D sized work; the design goal is few launches and no single-workgroup serial
+// stretch longer than a few microseconds (MI355X_MICROARCH.md: kernel boundary ~1.5-1.9 us).
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+// ---------------------------------------------------------------------------------------------------
+// Merge G partials.  grid = (ceil(D/64), P): workgroup (cc, p) owns 64 columns of query p and reads G
+// segments of 256 B.  thread -> (float4 column c4 = tid & 15, partial subset gs = tid >> 4).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vlfan_merge(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                      const float* __restrict__ pacc, int G, int P, int D,
+                                                      int normalise, float* __restrict__ m2, float* __restrict__ l,
+                                                      float* __restrict__ out) {
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
+    __shared__ float sl[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = blockIdx.y, c0 = blockIdx.x * 64;
+    const int c4 = tid & 15, gs = tid >> 4;
+
+    float mx = -INFINITY;
+    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * kPStride + p]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = 0.f;
+    const int col = c0 + c4 * 4;
+    for (int gI = gs; gI < G; gI += 16) {
+        const float mg = pm[(size_t)gI * kPStride + p];
+        const float f = (mg == -INFINITY) ? 0.f : fast_exp2(mg - mx);
+        lt += pl[(size_t)gI * kPStride + p] * f;
+        if (col < D) {
+            const float4 v = *reinterpret_cast<const float4*>(pacc + ((size_t)gI * P + p) * D + col);
+            a.x += v.x * f; a.y += v.y * f; a.z += v.z * f; a.w += v.w * f;
+        }
+    }
+    sacc[gs][c4] = a;
+    if (c4 == 0) sl[gs] = lt;
+    __syncthreads();
+    if (tid < 16) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ls = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = sacc[k][tid];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            ls += sl[k];
+        }
+        if (normalise) {
+            const float inv = 1.f / ls;
+            s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+        }
+        const int cc = c0 + tid * 4;
+        if (cc < D) *reinterpret_cast<float4*>(out + (size_t)p * D + cc) = s;
+        if (tid == 0 && blockIdx.x == 0) {
+            m2[p] = mx;
+            l[p] = ls;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_attn_normalise(const float* __restrict__ scores, int P, int64_t N,
+                                                         const float* __restrict__ m2, const float* __restrict__ l,
+                                                         float* __restrict__ A) {
+    const int p = blockIdx.y;
+    const float mp = m2[p], inv = 1.f / l[p];
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256)
+        A[(size_t)p * N + n] = fast_exp2(scores[(size_t)p * N + n] - mp) * inv;
+}
+
+__global__ __launch_bounds__(256) void k_normalize_rows(const float* __restrict__ in, int D, float* __restrict__ out,
+                                                         float* __restrict__ norms) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* x = in + (size_t)r * D;
+    float ss = 0.f;
+    for (int d = tid; d < D; d += 256) ss += x[d] * x[d];
+    ss = block_sum_256(ss, red);
+    const float nrm = fmaxf(sqrtf(ss), kNormEps);
+    for (int d = tid; d < D; d += 256) out[(size_t)r * D + d] = x[d] / nrm;
+    if (norms != nullptr && tid == 0) norms[r] = nrm;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Incidence head.  grid = NB workgroups; workgroup j computes rows [8j, 8j+8) of v = W pooled + b
+// (pooled is recomputed per workgroup from the P x D rows: 24 KB of L2 reads), publishes them, takes a
+// ticket; the last arriver normalises v and scores it against the K unit rank-prompt embeddings.
+// Hand-off follows the release/acquire recipe of cdna_hip_programming.md Guideline 16.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kHeadRowsPerBlock = 8;
+
+__device__ __forceinline__ float pooled_col(const float* __restrict__ rows, int P, int D, int c, int pool_mode,
+                                            const float* pw) {
+    if (pool_mode == VLSA_POOL_MEAN) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += rows[(size_t)p * D + c];
+        return s / (float)P;
+    }
+    if (pool_mode == VLSA_POOL_MAX) {
+        float s = -INFINITY;
+        for (int p = 0; p < P; ++p) s = fmaxf(s, rows[(size_t)p * D + c]);
+        return s;
+    }
+    if (pool_mode == VLSA_POOL_WEIGHT) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += pw[p] * rows[(size_t)p * D + c];
+        return s;
+    }
+    return rows[c];  // VLSA_POOL_GIVEN
+}
+
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, int P, int D, int pool_mode,
+                                               const float* __restrict__ pool_w, const float* __restrict__ W,
+                                               const float* __restrict__ bias, const float* __restrict__ That, int K,
+                                               const float* __restrict__ logit_scale, unsigned int* counter,
+                                               float* __restrict__ pooled, float* v, float* __restrict__ vhat,
+                                               float* __restrict__ vnorm, float* __restrict__ logits,
+                                               float* __restrict__ incidence, int NB) {
+    __shared__ float sp[VLSA_MAX_D];
+    __shared__ float spw[VLSA_MAX_P];
+    __shared__ float slog[VLSA_MAX_K];
+    __shared__ float red[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (pool_mode == VLSA_POOL_WEIGHT) {  // softmax over the raw 'weight' parameter (model/deepmil.py:148)
+        if (tid == 0) {
+            float mx = -INFINITY, s = 0.f;
+            for (int p = 0; p < P; ++p) mx = fmaxf(mx, pool_w[p]);
+            for (int p = 0; p < P; ++p) { spw[p] = expf(pool_w[p] - mx); s += spw[p]; }
+            for (int p = 0; p < P; ++p) spw[p] /= s;
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < D; c += 256) {
+        const float pc = pooled_col(rows, P, D, c, pool_mode, spw);
+        sp[c] = pc;
+        if (blockIdx.x == 0) pooled[c] = pc;
+    }
+    __syncthreads();
+
+    if (W != nullptr) {
+        // each wave: 2 output rows; lanes stride the D columns in float4
+        for (int rr = 0; rr < 2; ++rr) {
+            const int j = blockIdx.x * kHeadRowsPerBlock + wv * 2 + rr;
+            if (j < D) {
+                const float* wr = W + (size_t)j * D;
+                float s = 0.f;
+                for (int c = lane * 4; c < D; c += 256) {
+                    const float4 wq = *reinterpret_cast<const float4*>(wr + c);
+                    s += wq.x * sp[c] + wq.y * sp[c + 1] + wq.z * sp[c + 2] + wq.w * sp[c + 3];
+                }
+                s = wave_sum(s);
+                if (lane == 0) v[j] = s + (bias != nullptr ? bias[j] : 0.f);
+            }
+        }
+    } else {
+        for (int c = tid; c < D; c += 256) v[c] = sp[c];
+    }
+
+    // publish + ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(NB - 1));
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- last arriver: v^ = v / max(|v|, eps); logits = exp(ls) * v^ . T^_k; incidence = softmax ----
+    float ss = 0.f;
+    for (int c = tid; c < D; c += 256) {
+        const float x = __hip_atomic_load(v + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sp[c] = x;
+        ss += x * x;
+    }
+    ss = block_sum_256(ss, red);
+    const float nrm = fmaxf(sqrtf(ss), kNormEps);
+    for (int c = tid; c < D; c += 256) {
+        const float u = sp[c] / nrm;
+        sp[c] = u;
+        vhat[c] = u;
+    }
+    if (tid == 0) vnorm[0] = nrm;
+    __syncthreads();
+    const float ls = expf(logit_scale[0]);
+    for (int k = wv; k < K; k += 4) {
+        const float* tk = That + (size_t)k * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += sp[c] * tk[c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float lg = ls * s;
+            logits[k] = lg;
+            slog[k] = lg;
+        }
+    }
+    __syncthreads();
+    if (incidence != nullptr && tid == 0) {
+        float mx = -INFINITY, s = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, slog[k]);
+        for (int k = 0; k < K; ++k) s += expf(slog[k] - mx);
+        for (int k = 0; k < K; ++k) incidence[k] = expf(slog[k] - mx) / s;
+    }
+    if (tid == 0) *counter = 0u;  // leave the ticket clean for callers that skip the memset
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hardware-layout probes (used by tests/test_gpu_probe.py)
+//   which = 0: MFMA 16x16x32 bf16 fragment map.  A[i][k] = i + 1 (k == probe_k) ... see test.
+//   which = 1: ds_read_b64_tr_b16 lane map.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_probe_mfma(float* out) {
+    // A[i][k] = (i + 1) if k == 5 * (i % 6) else 0 ; B[k][j] = 100 * k + j  -> C[i][j] = (i+1) * (100*k_i + j)
+    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        a[e] = (__bf16)((k == 5 * (i % 6)) ? (float)(i + 1) : 0.f);
+        b[e] = (__bf16)(float)(4 * k + i);  // B[k][j = i]; values < 256 exactly representable in bf16
+    }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = c[r];
+}
+
+__global__ void k_probe_tr(float* out) {
+    // LDS holds a [4 x 16 rows][16 cols] bf16 matrix, row stride 64 B (2 x the payload, to prove the row
+    // stride is free), value(row, col) = row * 16 + col (< 1024, but keep < 256: rows 0..15 only used).
+    __shared__ __attribute__((aligned(16))) unsigned short lds[16 * 32];
+    const int lane = threadIdx.x, g = lane >> 4, i = lane & 15;
+    for (int idx = lane; idx < 16 * 32; idx += 64) {
+        const int row = idx >> 5, col = idx & 31;
+        const __bf16 val = (__bf16)(float)((col < 16) ? (row * 16 + col) : 0);
+        lds[idx] = __builtin_bit_cast(unsigned short, val);
+    }
+    __syncthreads();
+    // group g reads the 4 x 16 block of rows 4g..4g+3: lane supplies row 4g + (i >> 2), cols 4*(i&3)..+3
+    const unsigned short* src = lds + (4 * g + (i >> 2)) * 32 + (i & 3) * 4;
+    const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(src));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = (float)t[r];
+}
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+extern "C" int vlsa_abi_version(void) { return VLSA_ABI_VERSION; }
+
+extern "C" const char* vlsa_error_string(int code) {
+    switch (code) {
+        case VLSA_OK: return "ok";
+        case VLSA_EINVAL: return "invalid argument";
+        case VLSA_EUNSUPPORTED: return "unsupported configuration";
+        case VLSA_ELAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH; }
+
+extern "C" int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D,
+                                int normalise, float* m2, float* l, float* out, void* stream) {
+    if (!pm || !pl || !pacc || !m2 || !l || !out) return VLSA_EINVAL;
+    if (G < 1 || P < 1 || P > VLSA_MAX_P || D <= 0 || D > VLSA_MAX_D || (D % 8) != 0) return VLSA_EINVAL;
+    hipLaunchKernelGGL(k_vlfan_merge, dim3((D + 63) / 64, P), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D,
+                       normalise, m2, l, out);
+    return launch_status();
+}
+
+extern "C" int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, const float* l, float* A,
+                                   void* stream) {
+    if (!scores || !m2 || !l || !A || P < 1 || P > VLSA_MAX_P || N < 0) return VLSA_EINVAL;
+    if (N == 0) return VLSA_OK;
+    int64_t nb = (N + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_attn_normalise, dim3((unsigned)nb, P), dim3(256), 0, (hipStream_t)stream, scores, P, N, m2, l, A);
+    return launch_status();
+}
+
+extern "C" int vlsa_normalize_rows(const float* in, int rows, int D, float* out, float* norms, void* stream) {
+    if (!in || !out || rows < 0 || D <= 0) return VLSA_EINVAL;
+    if (rows == 0) return VLSA_OK;
+    hipLaunchKernelGGL(k_normalize_rows, dim3(rows), dim3(256), 0, (hipStream_t)stream, in, D, out, norms);
+    return launch_status();
+}
+
+extern "C" size_t vlsa_head_workspace_bytes(int D) { (void)D; return 256; }
+
+extern "C" int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                 const float* b, const float* That, int K, const float* logit_scale, void* workspace,
+                                 float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                                 void* stream) {
+    if (!rows || !That || !logit_scale || !workspace || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
+    if (P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D <= 0 || D > VLSA_MAX_D || (D % 4) != 0) return VLSA_EINVAL;
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_GIVEN) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) return VLSA_ELAUNCH;
+    const int NB = W ? (D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock : 1;
+    hipLaunchKernelGGL(k_head, dim3(NB), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
+                       static_cast<unsigned int*>(workspace), pooled, v, vhat, vnorm, logits, incidence, NB);
+    return launch_status();
+}
+
+extern "C" int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream) {
+    if (!out || out_bytes < 64 * 4 * sizeof(float)) return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 0) hipLaunchKernelGGL(k_probe_mfma, dim3(1), dim3(64), 0, s, static_cast<float*>(out));
+    else if (which == 1) hipLaunchKernelGGL(k_probe_tr, dim3(1), dim3(64), 0, s, static_cast<float*>(out));
+    else return VLSA_EINVAL;
+    return launch_status();
+}

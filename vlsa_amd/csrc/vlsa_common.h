@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 kernels of libvlsa_hip.so.  CDNA4 only: 64-lane wavefronts,
+// MFMA 16x16x32 bf16, LDS transpose reads.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vlsa_hip.h"
+
+namespace vlsa {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNormEps = 1e-12f;  // F.normalize eps (model/deepmil.py:187,189)
+constexpr int kPStride = 16;        // stride of the per-query m/l arrays
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// Sum / max over the 4 lanes {i, i+16, i+32, i+48} (the four 16-lane rows of a wavefront).
+__device__ __forceinline__ float quad_rows_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float quad_rows_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float load_as_float(const float* p) { return *p; }
+__device__ __forceinline__ float load_as_float(const __bf16* p) { return (float)*p; }
+
+// Block-wide sum for 256-thread blocks; `red` is >= 4 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// Opaque prepared-query block layout (see vlsa_prepare_queries).
+struct QPrepLayout {
+    size_t qeff, qsplit, qhat, qnorm, total;
+    __host__ __device__ explicit QPrepLayout(int D) {
+        qeff = 0;
+        qsplit = qeff + (size_t)16 * D * 4;
+        qhat = qsplit + (size_t)3 * 16 * D * 2;
+        qnorm = qhat + (size_t)17 * D * 4;
+        total = qnorm + 32 * 4;
+    }
+};
+
+}  // namespace vlsa

@@ -1,0 +1,213 @@
+"""Functional API over the C ABI: allocation, stream plumbing and autograd glue.  All arithmetic on the
+N-sized data runs in libvlsa_hip.so; torch is used for device memory, streams and autograd bookkeeping.
+
+Reference ops replaced (paths relative to the upstream repo): model/deepmil.py:187-200 (cross attention),
+133-150 + 204 (query pooling, visual adapter), model/vlsa.py:185-192 (cosine logits).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import VlsaNativeError
+
+COATTN_SCALE = 100.0  # exp(coattn_logit_scale), model/deepmil.py:120-126
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VlsaNativeError(
+                "vlsa_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback; the CPU oracle under "
+                "oracle/ is test infrastructure)")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _bag2d(X: torch.Tensor) -> torch.Tensor:
+    """[1,N,D] or [N,D] -> [N,D] view with unit inner stride and 16-byte aligned rows (copy only if needed)."""
+    if X.dim() == 3:
+        if X.shape[0] != 1:
+            raise AssertionError("X.shape[0] must be 1 (one bag per call; model/deepmil.py:175)")
+        X = X[0]
+    if X.dim() != 2:
+        raise ValueError(f"expected a [N, D] or [1, N, D] bag, got {tuple(X.shape)}")
+    if X.dtype not in (torch.float32, torch.bfloat16):
+        X = X.float()
+    esz = X.element_size()
+    if X.shape[0] > 0 and (X.stride(1) != 1 or (X.stride(0) * esz) % 16 != 0 or X.data_ptr() % 16 != 0
+                           or X.stride(0) < X.shape[1]):
+        X = X.contiguous()
+    return X
+
+
+@dataclass
+class PreparedQueries:
+    """Device block produced by vlsa_prepare_queries (unit queries, effective queries, bf16 split)."""
+    buf: torch.Tensor
+    nq: int
+    P: int
+    D: int
+    gated: bool
+
+    def _view(self, off: int, rows: int) -> torch.Tensor:
+        return self.buf[off:off + rows * self.D * 4].view(torch.float32).view(rows, self.D)
+
+    @property
+    def qeff(self) -> torch.Tensor:   # [P, D] effective queries (q^_p - q^_gate)
+        return self._view(0, 16)[: self.P]
+
+    @property
+    def qhat(self) -> torch.Tensor:   # [nq, D] unit queries
+        off = 16 * self.D * 4 + 3 * 16 * self.D * 2
+        return self._view(off, 17)[: self.nq]
+
+    @property
+    def qnorm(self) -> torch.Tensor:  # [nq] max(||q||, 1e-12)
+        off = 16 * self.D * 4 + 3 * 16 * self.D * 2 + 17 * self.D * 4
+        return self.buf[off:off + 128].view(torch.float32)[: self.nq]
+
+
+def prepare_queries(Q: torch.Tensor, gated: bool = False) -> PreparedQueries:
+    _need_gpu(Q)
+    lib = nat.load()
+    Q = _f32c(Q)
+    nq, D = Q.shape
+    P = nq - 1 if gated else nq
+    if not (1 <= P <= nat.MAX_P):
+        raise ValueError(f"number of queries P={P} outside [1, {nat.MAX_P}]")
+    buf = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=Q.device)
+    nat.check(lib.vlsa_prepare_queries(_p(Q), nq, D, int(gated), _p(buf), _stream()), "vlsa_prepare_queries")
+    return PreparedQueries(buf, nq, P, D, gated)
+
+
+def num_partials(N: int) -> int:
+    return int(nat.load().vlsa_num_partials(N))
+
+
+def vlfan_partial(X: torch.Tensor, qp: PreparedQueries, coattn_scale: float = COATTN_SCALE,
+                  kernel: int = nat.KERNEL_AUTO, want_scores: bool = False):
+    """One streaming pass over a shard's rows -> per-workgroup partials (pm[G,16], pl[G,16], pacc[G,P,D])
+    and, if asked, the log2-domain scores [P, N]."""
+    _need_gpu(X)
+    lib = nat.load()
+    X = _bag2d(X)
+    N, D = X.shape
+    if D != qp.D:
+        raise ValueError(f"feature dim mismatch: bag {D}, queries {qp.D}")
+    G = num_partials(N)
+    dev = X.device
+    pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+    pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+    pacc = torch.empty(G, qp.P, D, dtype=torch.float32, device=dev)
+    scores = torch.empty(qp.P, N, dtype=torch.float32, device=dev) if want_scores else None
+    if N == 0:
+        pm.fill_(float("-inf"))
+        pl.zero_()
+        pacc.zero_()
+        return pm, pl, pacc, scores
+    dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
+    nat.check(lib.vlsa_vlfan_partial(_p(X), dt, N, X.stride(0), D, _p(qp.buf), qp.P, float(coattn_scale), kernel,
+                                     _p(pm), _p(pl), _p(pacc), _p(scores), _stream()), "vlsa_vlfan_partial")
+    return pm, pl, pacc, scores
+
+
+def vlfan_merge(pm: torch.Tensor, pl: torch.Tensor, pacc: torch.Tensor, normalise: bool = True):
+    """Log-sum-exp merge of G partials -> (m2[16], l[16], out[P, D])."""
+    _need_gpu(pm, pl, pacc)
+    lib = nat.load()
+    G, P, D = pacc.shape
+    dev = pacc.device
+    m2 = torch.empty(nat.P_STRIDE, dtype=torch.float32, device=dev)
+    l = torch.empty(nat.P_STRIDE, dtype=torch.float32, device=dev)
+    out = torch.empty(P, D, dtype=torch.float32, device=dev)
+    nat.check(lib.vlsa_vlfan_merge(_p(pm), _p(pl), _p(pacc), G, P, D, int(normalise), _p(m2), _p(l), _p(out),
+                                   _stream()), "vlsa_vlfan_merge")
+    return m2, l, out
+
+
+def attn_normalise(scores: torch.Tensor, m2: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    _need_gpu(scores)
+    lib = nat.load()
+    P, N = scores.shape
+    A = torch.empty_like(scores)
+    nat.check(lib.vlsa_attn_normalise(_p(scores), P, N, _p(m2), _p(l), _p(A), _stream()), "vlsa_attn_normalise")
+    return A
+
+
+def normalize_rows(T: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """F.normalize(T, dim=-1) for a small [rows, D] matrix; also returns the clamped norms."""
+    _need_gpu(T)
+    lib = nat.load()
+    T = _f32c(T)
+    rows, D = T.shape
+    out = torch.empty_like(T)
+    norms = torch.empty(rows, dtype=torch.float32, device=T.device)
+    nat.check(lib.vlsa_normalize_rows(_p(T), rows, D, _p(out), _p(norms), _stream()), "vlsa_normalize_rows")
+    return out, norms
+
+
+_POOL_CODES = {"mean": nat.POOL_MEAN, "max": nat.POOL_MAX, "weight": nat.POOL_WEIGHT, "given": nat.POOL_GIVEN}
+
+
+def head_forward(rows: torch.Tensor, pool: str, pool_w: Optional[torch.Tensor], W: Optional[torch.Tensor],
+                 b: Optional[torch.Tensor], That: torch.Tensor, logit_scale: torch.Tensor,
+                 want_incidence: bool = False):
+    """Query pooling + visual adapter + cosine logits (model/deepmil.py:203-204, model/vlsa.py:188-192).
+
+    rows: [P, D] aggregated rows (or [1, D] with pool='given'); That: [K, D] unit-norm text features;
+    logit_scale: the 0-dim parameter (pre-exp), read on device.
+    """
+    _need_gpu(rows, That, logit_scale)
+    lib = nat.load()
+    rows = _f32c(rows)
+    P, D = rows.shape
+    K = That.shape[0]
+    dev = rows.device
+    That = _f32c(That)
+    W_ = _f32c(W) if W is not None else None
+    b_ = _f32c(b) if b is not None else None
+    pw = _f32c(pool_w).reshape(-1) if pool_w is not None else None
+    ls = _f32c(logit_scale).reshape(1)
+    ws = torch.empty(lib.vlsa_head_workspace_bytes(D), dtype=torch.uint8, device=dev)
+    f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
+    pooled, v, vhat, vnorm, logits = f(D), f(D), f(D), f(1), f(K)
+    inc = f(K) if want_incidence else None
+    nat.check(lib.vlsa_head_forward(_p(rows), P, D, _POOL_CODES[pool], _p(pw), _p(W_), _p(b_), _p(That), K, _p(ls),
+                                    _p(ws), _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), _p(inc), _stream()),
+              "vlsa_head_forward")
+    return dict(pooled=pooled, v=v, vhat=vhat, vnorm=vnorm, logits=logits, incidence=inc)
+
+
+def vlfan_aggregate(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
+                    kernel: int = nat.KERNEL_AUTO, want_attn: bool = False):
+    """Inference-only cross-attention aggregation: out[P, D] = softmax_N(100 cos(Q, X)) @ X, plus A[P, N]."""
+    qp = prepare_queries(Q, gated)
+    pm, pl, pacc, scores = vlfan_partial(X, qp, coattn_scale, kernel, want_scores=want_attn)
+    m2, l, out = vlfan_merge(pm, pl, pacc, normalise=True)
+    A = attn_normalise(scores, m2, l) if want_attn else None
+    return out, A, (m2, l, qp)
+
+
+def debug_probe(which: int, device="cuda") -> torch.Tensor:
+    lib = nat.load()
+    out = torch.zeros(64, 4, dtype=torch.float32, device=device)
+    nat.check(lib.vlsa_debug_probe(which, _p(out), out.numel() * 4, _stream()), "vlsa_debug_probe")
+    return out
