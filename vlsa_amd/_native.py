@@ -10,7 +10,8 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libvlsa_hip.so")
+_LIB_PATH = os.environ.get("VLSA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib",
+                                                             "libvlsa_hip.so")
 ABI_VERSION = 1
 
 # mirrors include/vlsa_hip.h

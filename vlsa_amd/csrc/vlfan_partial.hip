@@ -224,56 +224,68 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float c) {
     return c;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// LDS images are written as raw 16-B words and read back as bf16 fragments: every such access goes through
+// may_alias types so type-based alias analysis can never reorder a fragment read above the staging write.
+typedef u32x4 __attribute__((may_alias)) u32x4_ma;
+typedef bf16x8 __attribute__((may_alias)) bf16x8_ma;
+typedef bf16x4 __attribute__((may_alias)) bf16x4_ma;
+typedef f32x4 __attribute__((may_alias)) f32x4_ma;
+
+// Staging registers for one 32-row tile of this wave's 128-column slice.
+//   bf16: 8 x 16 B per lane; load i covers rows 4i..4i+3, lane -> (row 4i + g, 16-B chunk i16)
+//   fp32: 16 x 16 B per lane; load i covers rows 2i, 2i+1, lane -> (row 2i + (l >> 5), 4 floats)
+// Rows past the shard end are clamped to its last row (valid memory) and masked later.
 template <typename XT>
-struct Stage;
-template <>
-struct Stage<__bf16> {  // 8 x 16 B per lane: instruction i covers rows 4i..4i+3, lane -> (row 4i+g, 16-B chunk i16)
-    uint4 v[8];
-    __device__ __forceinline__ void load(const __bf16* X, int64_t ldx, int64_t r0, int64_t rlast, int w, int lane) {
-        const int g = lane >> 4, i16 = lane & 15;
+struct StageN { static constexpr int value = sizeof(XT) == 4 ? 16 : 8; };
+
+__device__ __forceinline__ void stage_load(u32x4 (&v)[8], const __bf16* __restrict__ X, int64_t ldx, int64_t r0,
+                                           int64_t rlast, int w, int lane) {
+    const int g = lane >> 4, i16 = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int64_t r = r0 + 4 * i + g;
-            r = r < rlast ? r : rlast;  // clamp: rows past the shard end are masked later
-            v[i] = *reinterpret_cast<const uint4*>(X + r * ldx + w * 128 + i16 * 8);
+    for (int i = 0; i < 8; ++i) {
+        int64_t r = r0 + 4 * i + g;
+        r = r < rlast ? r : rlast;
+#ifdef VLSA_NO_NT
+        v[i] = *reinterpret_cast<const u32x4*>(X + r * ldx + w * 128 + i16 * 8);
+#else
+        v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(X + r * ldx + w * 128 + i16 * 8));
+#endif
+    }
+}
+__device__ __forceinline__ void stage_store(const u32x4 (&v)[8], unsigned char* xs, int lane) {
+    const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4_ma*>(xs + swz(4 * i + g, i16 * 16)) = v[i];
+}
+__device__ __forceinline__ void stage_load(u32x4 (&v)[16], const float* __restrict__ X, int64_t ldx, int64_t r0,
+                                           int64_t rlast, int w, int lane) {
+    const int hh = lane >> 5, c4 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int64_t r = r0 + 2 * i + hh;
+        r = r < rlast ? r : rlast;
+        v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(X + r * ldx + w * 128 + c4 * 4));
+    }
+}
+// split each fp32 into hi + lo bf16 and write the two slice images (hi at xs, lo at xs + kSliceBytes)
+__device__ __forceinline__ void stage_store(const u32x4 (&v)[16], unsigned char* xs, int lane) {
+    const int hh = lane >> 5, c4 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int bits = v[i][e];  // (bit_cast straight from the vector-element glvalue miscompiles)
+            const float f = __uint_as_float(bits);
+            hi[e] = (__bf16)f;
+            lo[e] = (__bf16)(f - (float)hi[e]);
         }
+        const int off = swz(2 * i + hh, c4 * 8);
+        *reinterpret_cast<bf16x4_ma*>(xs + off) = hi;
+        *reinterpret_cast<bf16x4_ma*>(xs + kSliceBytes + off) = lo;
     }
-    __device__ __forceinline__ void store(unsigned char* xs, int lane) const {
-        const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(xs + swz(4 * i + g, i16 * 16)) = v[i];
-    }
-};
-template <>
-struct Stage<float> {  // 16 x 16 B per lane: instruction i covers rows 2i, 2i+1; lane -> (row 2i + (l>>5), 4 floats)
-    float4 v[16];
-    __device__ __forceinline__ void load(const float* X, int64_t ldx, int64_t r0, int64_t rlast, int w, int lane) {
-        const int hh = lane >> 5, c4 = lane & 31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            int64_t r = r0 + 2 * i + hh;
-            r = r < rlast ? r : rlast;
-            v[i] = *reinterpret_cast<const float4*>(X + r * ldx + w * 128 + c4 * 4);
-        }
-    }
-    // split each fp32 into hi + lo bf16 and write the two slice images (hi at xs, lo at xs + kSliceBytes)
-    __device__ __forceinline__ void store(unsigned char* xs, int lane) const {
-        const int hh = lane >> 5, c4 = lane & 31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)f[e];
-                lo[e] = (__bf16)(f[e] - (float)hi[e]);
-            }
-            const int off = swz(2 * i + hh, c4 * 8);
-            *reinterpret_cast<bf16x4*>(xs + off) = hi;
-            *reinterpret_cast<bf16x4*>(xs + kSliceBytes + off) = lo;
-        }
-    }
-};
+}
 
 template <typename XT>
 __global__ __launch_bounds__(256, 2) void k_vlfan_partial_mfma(const XT* __restrict__ X, int64_t N, int64_t ldx,
@@ -309,13 +321,17 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_partial_mfma(const XT* __restr
     float M = -INFINITY;  // running reference max of query p = i16 (log2 domain), identical in all 4 waves
     float lsum = 0.f;     // this lane's share of sum_n exp2(t - M) for p = i16
 
-    Stage<XT> st;
-    if (rbeg < rend) st.load(X, ldx, rbeg, rend - 1, w, lane);
+    u32x4 st[StageN<XT>::value];
+    const int64_t rlast = rend > rbeg ? rend - 1 : (N > 0 ? N - 1 : 0);
+    if (N > 0) stage_load(st, X, ldx, rbeg, rlast, w, lane);
     int par = 0;
     for (int64_t r0 = rbeg; r0 < rend; r0 += kTileRows, par ^= 1) {
         // ---- stage this tile into the wave-private LDS image, then prefetch the next tile --------------
-        st.store(xs, lane);
-        if (r0 + kTileRows < rend) st.load(X, ldx, r0 + kTileRows, rend - 1, w, lane);
+        stage_store(st, xs, lane);
+#ifdef VLSA_COND_LOAD
+        if (r0 + kTileRows < rend)
+#endif
+        stage_load(st, X, ldx, r0 + kTileRows, rlast, w, lane);  // unconditional: clamped rows are valid memory
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -323,49 +339,75 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_partial_mfma(const XT* __restr
         // ---- contraction 1: partial scores over this wave's 128 columns + partial row sum-of-squares ----
         f32x4 S[2];
         float ss[2];
+        {
+            bf16x8 xa[2][4], xl[2][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ss[h] = 0.f;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int off = swz(16 * h + i16, kk * 64 + g * 16);
-                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xs + off);
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, qf[0][kk], S[h], 0, 0, 0);
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, qf[1][kk], S[h], 0, 0, 0);
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, qf[2][kk], S[h], 0, 0, 0);
-                ss[h] = dot8(xa, xa, ss[h]);
-                if constexpr (F32) {
-                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xs + kSliceBytes + off);
-                    S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qf[0][kk], S[h], 0, 0, 0);
-                    S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qf[1][kk], S[h], 0, 0, 0);
-                    ss[h] = dot8(xl, xl, dot8(xa, xl, dot8(xa, xl, ss[h])));
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int off = swz(16 * h + i16, kk * 64 + g * 16);
+                    xa[h][kk] = *reinterpret_cast<const bf16x8_ma*>(xs + off);
+                    if constexpr (F32) xl[h][kk] = *reinterpret_cast<const bf16x8_ma*>(xs + kSliceBytes + off);
                 }
+            // two independent accumulator chains per row group keep the matrix pipe busy
+            f32x4 Sa[2], Sb[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Sa[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Sb[h] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            ss[h] = quad_rows_sum(ss[h]);  // all lanes with the same i16 now hold the wave-partial |x_n|^2, n = 16h + i16
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    Sa[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[0][kk], Sa[h], 0, 0, 0);
+                    Sb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[1][kk], Sb[h], 0, 0, 0);
+                    Sb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[2][kk], Sb[h], 0, 0, 0);
+                    if constexpr (F32) {
+                        Sa[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[h][kk], qf[0][kk], Sa[h], 0, 0, 0);
+                        Sb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[h][kk], qf[1][kk], Sb[h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float a = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    a = dot8(xa[h][kk], xa[h][kk], a);
+                    if constexpr (F32) a = dot8(xl[h][kk], xl[h][kk], dot8(xa[h][kk], xl[h][kk], dot8(xa[h][kk], xl[h][kk], a)));
+                }
+                ss[h] = quad_rows_sum(a);  // lanes with the same i16 now hold the wave-partial |x_n|^2, n = 16h + i16
+                S[h] = Sa[h] + Sb[h];
+            }
         }
 
         // ---- exchange the partials between the 4 waves (one barrier per tile, parity double-buffered) ----
         {
             unsigned char* mine = exch + par * kExchParity + w * kExchWave;
-            *reinterpret_cast<f32x4*>(mine + (0 * 64 + lane) * 16) = S[0];
-            *reinterpret_cast<f32x4*>(mine + (1 * 64 + lane) * 16) = S[1];
+            *reinterpret_cast<f32x4_ma*>(mine + (0 * 64 + lane) * 16) = S[0];
+            *reinterpret_cast<f32x4_ma*>(mine + (1 * 64 + lane) * 16) = S[1];
             if (g == 0) {
-                reinterpret_cast<float*>(mine + 2048)[i16] = ss[0];
-                reinterpret_cast<float*>(mine + 2048)[16 + i16] = ss[1];
+                typedef float __attribute__((may_alias)) float_ma;
+                reinterpret_cast<float_ma*>(mine + 2048)[i16] = ss[0];
+                reinterpret_cast<float_ma*>(mine + 2048)[16 + i16] = ss[1];
             }
         }
         __syncthreads();
         f32x4 T[2], R2[2];
+        {
+            f32x4 tv[2][4], rv[2][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            T[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-            R2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const unsigned char* o = exch + par * kExchParity + ww * kExchWave;
-                T[h] += *reinterpret_cast<const f32x4*>(o + (h * 64 + lane) * 16);
-                R2[h] += *reinterpret_cast<const f32x4*>(o + 2048 + (16 * h + 4 * g) * 4);
+                for (int ww = 0; ww < 4; ++ww) {
+                    const unsigned char* o = exch + par * kExchParity + ww * kExchWave;
+                    tv[h][ww] = *reinterpret_cast<const f32x4_ma*>(o + (h * 64 + lane) * 16);
+                    rv[h][ww] = *reinterpret_cast<const f32x4_ma*>(o + 2048 + (16 * h + 4 * g) * 4);
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                T[h] = (tv[h][0] + tv[h][1]) + (tv[h][2] + tv[h][3]);
+                R2[h] = (rv[h][0] + rv[h][1]) + (rv[h][2] + rv[h][3]);
             }
         }
 
