@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Contract benchmark: patches/s of the per-slide VLSA forward (language-guided patch aggregation).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json): synthetic 50k x 512 bf16 CONCH bag, P = 12 text-prototype queries, K = 4 ordinal
+rank prompts, mean query pooling, Linear(512,512) visual adapter -- `configs[2]`, the configuration the
+metric is quoted on.  A step = one bag through query/text normalisation, the streaming aggregation kernel,
+the partial merge and the incidence head (= VLSA.forward in eval mode with cached text features,
+reference model/vlsa.py:181-198).  Bags are resident in HBM before the timed region; 8 distinct bags are
+rotated (410 MB > the 256 MiB Infinity Cache) so the stream really comes from HBM.
+
+N > 1: the bag is N x 50k patches, patch-sharded across the ranks (weak scaling: 50k rows per GPU); each
+rank streams its shard, the ranks all-gather their compact (m, l, acc[P,512]) partials over RCCL, every
+rank merges and runs the replicated head.  value = whole-job patches/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 50_000
+D, P, K = 512, 12, 4
+N_BAGS = 8
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def synth(device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    bags = [torch.randn(N_PER_GPU, D, device=device, generator=g).to(torch.bfloat16) for _ in range(N_BAGS)]
+    gq = torch.Generator(device=device).manual_seed(1234)  # parameters identical on every rank
+    Q = 0.5 * torch.randn(P, D, device=device, generator=gq) + torch.randn(P, D, device=device, generator=gq)
+    T = torch.randn(K, D, device=device, generator=gq)
+    W = (torch.rand(D, D, device=device, generator=gq) * 2 - 1) / D ** 0.5
+    b = (torch.rand(D, device=device, generator=gq) * 2 - 1) / D ** 0.5
+    ls = torch.tensor(4.0309, device=device)
+    return bags, Q, T, W, b, ls
+
+
+def cpu_baseline(seconds=10.0):
+    """The CPU oracle (restatement of the reference's torch op sequence, pinned to the reference by
+    tests/golden) timed on this host's cores on the same workload: kind = "port"."""
+    from oracle import vlsa_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(N_PER_GPU, D, generator=g).to(torch.bfloat16).float()
+    Q = torch.randn(P, D, generator=g)
+    T = torch.randn(K, D, generator=g)
+    W = torch.randn(D, D, generator=g) / D ** 0.5
+    b = torch.randn(D, generator=g) / D ** 0.5
+    ls = torch.tensor(4.0309)
+    with torch.no_grad():
+        for _ in range(2):
+            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": N_PER_GPU * n / dt, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{n} bags of 50000x512 (fp32 math on bf16-rounded values) in {dt:.1f} s, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from vlsa_amd import functional as F
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    bags, Q, T, W, b, ls = synth(device, 100 + rank)
+    if world == 1:
+        plan = F.VlfanInferencePlan(N_PER_GPU, D, P, K, device)
+        step = lambda i: plan.run(bags[i % N_BAGS], Q, T, ls, W, b)  # noqa: E731
+    else:
+        from vlsa_amd.sharded import ShardedVlfanPlan
+        plan = ShardedVlfanPlan(N_PER_GPU, D, P, K, device, dist)
+        step = lambda i: plan.run(bags[i % N_BAGS], Q, T, ls, W, b)  # noqa: E731
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (also JIT-free: everything is precompiled) ------------------------------------------------
+    for i in range(a.warmup):
+        step(i)
+    sync()
+
+    use_graph = (not a.no_graph) and world == 1
+    if use_graph:
+        chunk = min(a.steps, 64)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        graphs = {}
+        with torch.cuda.stream(s):
+            for n in {chunk, a.steps % chunk} - {0}:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=s):
+                    for i in range(n):
+                        step(i)
+                graphs[n] = gr
+        torch.cuda.current_stream().wait_stream(s)
+        for gr in graphs.values():  # one untimed replay each
+            gr.replay()
+        sync()
+
+    sync()
+    t0 = time.perf_counter()
+    if use_graph:
+        for _ in range(a.steps // chunk):
+            graphs[chunk].replay()
+        if a.steps % chunk:
+            graphs[a.steps % chunk].replay()
+    else:
+        for i in range(a.steps):
+            step(i)
+    if hasattr(plan, "finish"):
+        plan.finish()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: HIP events around each launch on the launching stream ----------
+    roof = None
+    if rank == 0:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+        base = plan.local if hasattr(plan, "local") else plan
+        for i in range(10):
+            base.run_partial_only(bags[i % N_BAGS])
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(ev):
+            e0.record()
+            base.run_partial_only(bags[i % N_BAGS])
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        avg_ms = sum(ts) / len(ts)
+        algo_bytes = N_PER_GPU * D * 2  # 1024 B per bf16 patch row
+        ach = algo_bytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_vlfan_partial_mfma<bf16>", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "avg_us": round(avg_ms * 1e3, 2), "min_us": round(ts[0] * 1e3, 2),
+                "bytes_per_launch": algo_bytes}
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        total_patches = N_PER_GPU * world * a.steps
+        out = {
+            "metric": "patches/sec per slide (50k x 512 CONCH bag)", "value": total_patches / dt, "unit": "patches/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[2]: synthetic 50k x 512 bf16 bag per GPU, P=12 queries, K=4 rank prompts, "
+                                   "mean pooling + Linear(512,512) head; N GPUs = one N*50k-patch bag patch-sharded",
+                       "rows_per_gpu": N_PER_GPU, "D": D, "P": P, "K": K, "bags_rotated": N_BAGS,
+                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,8 @@ extern "C" {
 /* kernel selection for vlsa_vlfan_partial */
 #define VLSA_KERNEL_AUTO 0
 #define VLSA_KERNEL_GENERIC 1 /* fp32 VALU kernel, any D <= VLSA_MAX_D with D % 8 == 0 */
-#define VLSA_KERNEL_MFMA 2    /* split-bf16 MFMA kernel, D == 512 */
+#define VLSA_KERNEL_MFMA 2    /* split-bf16 MFMA kernel, register-staged, D == 512, fp32 or bf16 rows */
+#define VLSA_KERNEL_DMA 3     /* split-bf16 MFMA kernel, LDS-DMA ring, D == 512, bf16 rows (the tuned path) */
 
 /* query pooling over the P aggregated rows (model/deepmil.py:133-150) */
 #define VLSA_POOL_MEAN 0
@@ -65,10 +66,12 @@ size_t vlsa_qprep_bytes(int D);
  * A_[:, :-1] - A_[:, -1:] (model/deepmil.py:187,192-195) -- folded into effective queries
  * e_p = q^_p - q^_gate, which is exact because the score is linear in the query.
  *   Q      [nq, D] fp32 raw queries (nq = P, or P+1 when gated)
- *   qprep  opaque block of vlsa_qprep_bytes(D): fp32 effective queries, their 3-term bf16 split,
- *          fp32 unit queries q^ [nq, D] and raw norms [nq] (the last two are what backward needs).
+ *   coattn_scale  the reference's exp(coattn_logit_scale) = 100 (model/deepmil.py:120-126,197)
+ *   qprep  opaque block of vlsa_qprep_bytes(D): fp32 effective queries, the 3-term bf16 split of
+ *          coattn_scale * log2(e) * e_p, fp32 unit queries q^ [nq, D] and raw norms [nq] (the last two are
+ *          what backward needs).
  */
-int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, void* qprep, void* stream);
+int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, float coattn_scale, void* qprep, void* stream);
 /* Accessors into the opaque block (device pointers; for backward and for tests). */
 const float* vlsa_qprep_qeff(const void* qprep, int D);   /* [16, D] effective queries, rows >= P zero */
 const float* vlsa_qprep_qhat(const void* qprep, int D);   /* [17, D] unit queries */
@@ -83,11 +86,9 @@ const float* vlsa_qprep_qnorm(const void* qprep, int D);  /* [17] max(||q||, 1e-
  *   pacc [G, P, D] sum_n exp2(t_pn - pm) x_n
  *   scores (nullable) [P, N] log2-domain scores t_pn, needed only when attention weights are wanted.
  * X: [N, D] rows, dtype VLSA_DT_F32 or VLSA_DT_BF16, row stride ldx elements, 16-byte aligned rows.
- * coattn_scale: the reference's exp(coattn_logit_scale) = 100 (model/deepmil.py:120-126,197).
  */
 int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int P,
-                       float coattn_scale, int kernel, float* pm, float* pl, float* pacc, float* scores,
-                       void* stream);
+                       int kernel, float* pm, float* pl, float* pacc, float* scores, void* stream);
 
 /*
  * Log-sum-exp merge of G partials (from this GPU's workgroups, or all-gathered from the other ranks):
@@ -104,7 +105,8 @@ int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, 
 /* out[r, :] = in[r, :] / max(||in[r, :]||, 1e-12); norms[r] (nullable) = that denominator. (F.normalize) */
 int vlsa_normalize_rows(const float* in, int rows, int D, float* out, float* norms, void* stream);
 
-/* Bytes of scratch vlsa_head_forward needs (ticket counter + slabs). */
+/* Bytes of scratch vlsa_head_forward needs (a ticket counter).  The caller zeroes it ONCE after allocation; every
+ * call leaves it zeroed again, so no per-call memset is needed (one workspace per stream in flight). */
 size_t vlsa_head_workspace_bytes(int D);
 
 /*

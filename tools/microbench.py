@@ -41,7 +41,7 @@ def main():
     That, _ = F.normalize_rows(T)
     nbytes = a.n * 512 * bags[0].element_size()
     print(f"N={a.n} dtype={a.dtype} P={a.p} bag={nbytes/1e6:.1f} MB partials={F.num_partials(a.n)}")
-    for name, kern in (("mfma", 2), ("generic", 1)):
+    for name, kern in (("dma", 3), ("mfma", 2)):
         us = timeit(lambda i: F.vlfan_partial(bags[i % a.bags], qp, kernel=kern), a.iters)
         print(f"partial[{name}] (rotating {a.bags} bags, incl. python+alloc): {us:8.2f} us  {nbytes/us/1e3:8.1f} GB/s")
         us = timeit(lambda i: F.vlfan_partial(bags[0], qp, kernel=kern), a.iters)

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 # mirrors include/vlsa_hip.h
 DT_F32, DT_BF16 = 0, 1
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_DMA = 0, 1, 2, 3
 POOL_MEAN, POOL_MAX, POOL_WEIGHT, POOL_GIVEN = 0, 1, 2, 3
 MAX_P, MAX_K, MAX_D = 16, 64, 1024
 P_STRIDE = 16
@@ -34,8 +34,8 @@ _SIGNATURES = {
     "vlsa_qprep_qeff": (c_void_p, [c_void_p, c_int]),
     "vlsa_qprep_qhat": (c_void_p, [c_void_p, c_int]),
     "vlsa_qprep_qnorm": (c_void_p, [c_void_p, c_int]),
-    "vlsa_prepare_queries": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "vlsa_vlfan_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_float, c_int,
+    "vlsa_prepare_queries": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "vlsa_vlfan_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),

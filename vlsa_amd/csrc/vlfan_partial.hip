@@ -17,10 +17,11 @@
 namespace vlsa {
 
 // ---------------------------------------------------------------------------------------------------
-// Query preparation: q^ = q / max(||q||, eps); effective e_p = q^_p - gated * q^_gate; 3-term bf16 split.
+// Query preparation: q^ = q / max(||q||, eps); effective e_p = q^_p - gated * q^_gate; 3-term bf16 split of
+// scale * log2(e) * e_p (so MFMA scores come out directly in the log2 domain).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict__ Q, int nq, int D, int gated,
-                                                          unsigned char* __restrict__ qprep) {
+                                                          float scale2, unsigned char* __restrict__ qprep) {
     __shared__ float red[4];
     const QPrepLayout L(D);
     float* qeff = reinterpret_cast<float*>(qprep + L.qeff);
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict
     const int P = gated ? nq - 1 : nq;
     const int tid = threadIdx.x;
     if (p == 16) {  // block 16: unit vector + norm of the gate row only (row index nq-1 when gated)
+        if (tid == 0) qnorm[31] = scale2;  // coattn scale * log2(e), read back by the generic kernel
         if (!gated) return;
         const float* q = Q + (size_t)(nq - 1) * D;
         float ss = 0.f;
@@ -66,8 +68,9 @@ __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict
         float e = u;
         if (gated) e = u - qg[d] / gn;
         qeff[(size_t)p * D + d] = e;
-        const __bf16 h0 = (__bf16)e;
-        const float r1 = e - (float)h0;
+        const float es = e * scale2;  // the MFMA kernels contract against scale * log2(e) * e_p
+        const __bf16 h0 = (__bf16)es;
+        const float r1 = es - (float)h0;
         const __bf16 h1 = (__bf16)r1;
         const float r2 = r1 - (float)h1;
         const __bf16 h2 = (__bf16)r2;
@@ -83,8 +86,10 @@ __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void block_rows(int64_t N, int b, int G, int64_t& rbeg, int64_t& rend) {
     const int64_t units = (N + 15) >> 4;
-    rbeg = (units * b / G) << 4;
-    rend = (units * (b + 1) / G) << 4;
+    const int64_t uq = units / G, ur = units % G;
+    const int64_t ubeg = b * uq + (b < ur ? b : ur);
+    rbeg = ubeg << 4;
+    rend = (ubeg + uq + (b < ur ? 1 : 0)) << 4;
     if (rend > N) rend = N;
     if (rbeg > N) rbeg = N;
 }
@@ -96,12 +101,13 @@ __device__ __forceinline__ void block_rows(int64_t N, int b, int G, int64_t& rbe
 template <typename XT, int DPL>
 __global__ __launch_bounds__(256) void k_vlfan_partial_generic(const XT* __restrict__ X, int64_t N, int64_t ldx,
                                                                 int D, const float* __restrict__ qeff, int P,
-                                                                float scale2, float* __restrict__ pm,
+                                                                const float* __restrict__ qmeta, float* __restrict__ pm,
                                                                 float* __restrict__ pl, float* __restrict__ pacc,
                                                                 float* __restrict__ scores, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x, p0 = blockIdx.y * 4;
+    const float scale2 = qmeta[31];
     int64_t rbeg, rend;
     block_rows(N, b, G, rbeg, rend);
 
@@ -290,7 +296,7 @@ __device__ __forceinline__ void stage_store(const u32x4 (&v)[16], unsigned char*
 template <typename XT>
 __global__ __launch_bounds__(256, 2) void k_vlfan_partial_mfma(const XT* __restrict__ X, int64_t N, int64_t ldx,
                                                                 const __bf16* __restrict__ qsplit, int P,
-                                                                float scale2, float* __restrict__ pm,
+                                                                float* __restrict__ pm,
                                                                 float* __restrict__ pl, float* __restrict__ pacc,
                                                                 float* __restrict__ scores, int G) {
     constexpr bool F32 = sizeof(XT) == 4;
@@ -420,8 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_partial_mfma(const XT* __restr
             for (int r = 0; r < 4; ++r) {
                 const int64_t n = r0 + 16 * h + 4 * g + r;
                 valid[h][r] = n < rend;
-                const float inv = scale2 / fmaxf(sqrtf(R2[h][r]), kNormEps);
-                T[h][r] *= inv;
+                T[h][r] *= fminf(__builtin_amdgcn_rsqf(R2[h][r]), 1e12f);  // 1 / max(|x|, 1e-12); scale is in the queries
                 if (valid[h][r]) tmax = fmaxf(tmax, T[h][r]);
             }
         if (scores != nullptr && i16 < P && (w & 1) == ((g >> 1) & 1)) {
@@ -524,17 +529,18 @@ extern "C" const float* vlsa_qprep_qnorm(const void* qprep, int D) {
     return reinterpret_cast<const float*>(static_cast<const unsigned char*>(qprep) + QPrepLayout(D).qnorm);
 }
 
-extern "C" int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, void* qprep, void* stream) {
+extern "C" int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, float coattn_scale, void* qprep,
+                                    void* stream) {
     if (!Q || !qprep || D <= 0 || D > VLSA_MAX_D || (D % 8) != 0) return VLSA_EINVAL;
     const int P = gated ? nq - 1 : nq;
-    if (P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
+    if (P < 1 || P > VLSA_MAX_P || !(coattn_scale > 0.f)) return VLSA_EINVAL;
     hipLaunchKernelGGL(k_prepare_queries, dim3(17), dim3(256), 0, (hipStream_t)stream, Q, nq, D, gated,
-                       static_cast<unsigned char*>(qprep));
+                       coattn_scale * kLog2e, static_cast<unsigned char*>(qprep));
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
 template <typename XT>
-static int launch_generic(const XT* X, int64_t N, int64_t ldx, int D, const float* qeff, int P, float scale2,
+static int launch_generic(const XT* X, int64_t N, int64_t ldx, int D, const float* qeff, int P, const float* qmeta,
                           float* pm, float* pl, float* pacc, float* scores, int G, hipStream_t s) {
     const dim3 grid(G, (P + 3) / 4), block(256);
 #define VLSA_GEN(DPL)                                                                                              \
@@ -542,7 +548,7 @@ static int launch_generic(const XT* X, int64_t N, int64_t ldx, int D, const floa
         const size_t lds = (32 + (size_t)16 * DPL * 64) * sizeof(float);                                           \
         auto kern = k_vlfan_partial_generic<XT, DPL>;                                                              \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, X, N, ldx, D, qeff, P, scale2, pm, pl, pacc, scores, G);     \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, X, N, ldx, D, qeff, P, qmeta, pm, pl, pacc, scores, G);     \
     }
     if (D <= 256) VLSA_GEN(4)
     else if (D <= 512) VLSA_GEN(8)
@@ -553,7 +559,7 @@ static int launch_generic(const XT* X, int64_t N, int64_t ldx, int D, const floa
 }
 
 template <typename XT>
-static int launch_mfma(const XT* X, int64_t N, int64_t ldx, const __bf16* qsplit, int P, float scale2, float* pm,
+static int launch_mfma(const XT* X, int64_t N, int64_t ldx, const __bf16* qsplit, int P, float* pm,
                        float* pl, float* pacc, float* scores, int G, hipStream_t s) {
     constexpr bool F32 = sizeof(XT) == 4;
     constexpr int lds = mfma_lds_bytes<F32>();
@@ -563,34 +569,43 @@ static int launch_mfma(const XT* X, int64_t N, int64_t ldx, const __bf16* qsplit
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, X, N, ldx, qsplit, P, scale2, pm, pl, pacc, scores, G);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, X, N, ldx, qsplit, P, pm, pl, pacc, scores, G);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
+int vlsa_launch_partial_dma(const __bf16* X, int64_t N, int64_t ldx, const __bf16* qsplit_scaled, int P, float* pm,
+                            float* pl, float* pacc, float* scores, int G, hipStream_t s);
+
 extern "C" int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep,
-                                  int P, float coattn_scale, int kernel, float* pm, float* pl, float* pacc,
-                                  float* scores, void* stream) {
+                                  int P, int kernel, float* pm, float* pl, float* pacc, float* scores,
+                                  void* stream) {
     if (!qprep || !pm || !pl || !pacc || N < 0 || (N > 0 && !X)) return VLSA_EINVAL;
     if (D <= 0 || D > VLSA_MAX_D || (D % 8) != 0 || P < 1 || P > VLSA_MAX_P || ldx < D) return VLSA_EINVAL;
     if (x_dtype != VLSA_DT_F32 && x_dtype != VLSA_DT_BF16) return VLSA_EINVAL;
     const size_t esz = x_dtype == VLSA_DT_F32 ? 4 : 2;
     if ((reinterpret_cast<uintptr_t>(X) & 15) != 0 || ((size_t)ldx * esz) % 16 != 0) return VLSA_EINVAL;
-    if (kernel == VLSA_KERNEL_AUTO) kernel = (D == 512) ? VLSA_KERNEL_MFMA : VLSA_KERNEL_GENERIC;
-    if (kernel == VLSA_KERNEL_MFMA && D != 512) return VLSA_EUNSUPPORTED;
-    if (kernel != VLSA_KERNEL_MFMA && kernel != VLSA_KERNEL_GENERIC) return VLSA_EINVAL;
     const int G = vlsa_num_partials(N);
-    const float scale2 = coattn_scale * kLog2e;
+    // the DMA kernel addresses a workgroup's rows through a 32-bit buffer descriptor
+    const bool dma_ok = D == 512 && x_dtype == VLSA_DT_BF16 && ((N / G + 64) * ldx * 2) < (int64_t)0x7fff0000;
+    if (kernel == VLSA_KERNEL_AUTO)
+        kernel = (D != 512) ? VLSA_KERNEL_GENERIC : (dma_ok ? VLSA_KERNEL_DMA : VLSA_KERNEL_MFMA);
+    if (kernel == VLSA_KERNEL_MFMA && D != 512) return VLSA_EUNSUPPORTED;
+    if (kernel == VLSA_KERNEL_DMA && !dma_ok) return VLSA_EUNSUPPORTED;
+    if (kernel != VLSA_KERNEL_MFMA && kernel != VLSA_KERNEL_GENERIC && kernel != VLSA_KERNEL_DMA) return VLSA_EINVAL;
     const QPrepLayout L(D);
     const unsigned char* qp = static_cast<const unsigned char*>(qprep);
     hipStream_t s = (hipStream_t)stream;
+    const __bf16* qsplit = reinterpret_cast<const __bf16*>(qp + L.qsplit);
+    if (kernel == VLSA_KERNEL_DMA)
+        return vlsa_launch_partial_dma((const __bf16*)X, N, ldx, qsplit, P, pm, pl, pacc, scores, G, s);
     if (kernel == VLSA_KERNEL_MFMA) {
-        const __bf16* qsplit = reinterpret_cast<const __bf16*>(qp + L.qsplit);
         return x_dtype == VLSA_DT_F32
-                   ? launch_mfma<float>((const float*)X, N, ldx, qsplit, P, scale2, pm, pl, pacc, scores, G, s)
-                   : launch_mfma<__bf16>((const __bf16*)X, N, ldx, qsplit, P, scale2, pm, pl, pacc, scores, G, s);
+                   ? launch_mfma<float>((const float*)X, N, ldx, qsplit, P, pm, pl, pacc, scores, G, s)
+                   : launch_mfma<__bf16>((const __bf16*)X, N, ldx, qsplit, P, pm, pl, pacc, scores, G, s);
     }
     const float* qeff = reinterpret_cast<const float*>(qp + L.qeff);
+    const float* qmeta = reinterpret_cast<const float*>(qp + L.qnorm);
     return x_dtype == VLSA_DT_F32
-               ? launch_generic<float>((const float*)X, N, ldx, D, qeff, P, scale2, pm, pl, pacc, scores, G, s)
-               : launch_generic<__bf16>((const __bf16*)X, N, ldx, D, qeff, P, scale2, pm, pl, pacc, scores, G, s);
+               ? launch_generic<float>((const float*)X, N, ldx, D, qeff, P, qmeta, pm, pl, pacc, scores, G, s)
+               : launch_generic<__bf16>((const __bf16*)X, N, ldx, D, qeff, P, qmeta, pm, pl, pacc, scores, G, s);
 }

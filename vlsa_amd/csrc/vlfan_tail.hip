@@ -20,24 +20,38 @@ __global__ __launch_bounds__(256) void k_vlfan_merge(const float* __restrict__ p
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = blockIdx.y, c0 = blockIdx.x * 64;
     const int c4 = tid & 15, gs = tid >> 4;
+    const int col = c0 + c4 * 4;
+    const bool incol = col < D;
 
+    // One round of independent loads per thread (its partials gs, gs+16, ...): the partial maxima, the partial
+    // normalisers and the 16-byte accumulator pieces are all in flight together; the exp2 factors follow.
+    constexpr int U = 16;  // up to 256 partials per pass
     float mx = -INFINITY;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = 0.f;
+    // pass 1: global max over all G partials (each thread scans a strided subset; G is small)
     for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * kPStride + p]);
     mx = wave_max(mx);
     if (lane == 0) red[wv] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    float lt = 0.f;
-    const int col = c0 + c4 * 4;
-    for (int gI = gs; gI < G; gI += 16) {
-        const float mg = pm[(size_t)gI * kPStride + p];
-        const float f = (mg == -INFINITY) ? 0.f : fast_exp2(mg - mx);
-        lt += pl[(size_t)gI * kPStride + p] * f;
-        if (col < D) {
-            const float4 v = *reinterpret_cast<const float4*>(pacc + ((size_t)gI * P + p) * D + col);
-            a.x += v.x * f; a.y += v.y * f; a.z += v.z * f; a.w += v.w * f;
+    for (int g0 = gs; g0 < G; g0 += 16 * U) {
+        float mg[U], lg[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gI = g0 + 16 * u;
+            const bool ok = gI < G;
+            mg[u] = ok ? pm[(size_t)gI * kPStride + p] : -INFINITY;
+            lg[u] = ok ? pl[(size_t)gI * kPStride + p] : 0.f;
+            v[u] = (ok && incol) ? *reinterpret_cast<const float4*>(pacc + ((size_t)gI * P + p) * D + col)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float f = (mg[u] == -INFINITY) ? 0.f : fast_exp2(mg[u] - mx);
+            lt += lg[u] * f;
+            a.x += v[u].x * f; a.y += v[u].y * f; a.z += v[u].z * f; a.w += v[u].w * f;
         }
     }
     sacc[gs][c4] = a;
@@ -97,22 +111,29 @@ constexpr int kHeadRowsPerBlock = 8;
 
 __device__ __forceinline__ float pooled_col(const float* __restrict__ rows, int P, int D, int c, int pool_mode,
                                             const float* pw) {
+    // all P <= 16 row loads are issued together (fully unrolled, predicated): one memory latency, not P of them
+    float x[VLSA_MAX_P];
+#pragma unroll
+    for (int p = 0; p < VLSA_MAX_P; ++p) x[p] = p < P ? rows[(size_t)p * D + c] : 0.f;
     if (pool_mode == VLSA_POOL_MEAN) {
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += rows[(size_t)p * D + c];
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p) s += x[p];  // same left-to-right order as torch.mean's sum for P <= 16
         return s / (float)P;
     }
     if (pool_mode == VLSA_POOL_MAX) {
         float s = -INFINITY;
-        for (int p = 0; p < P; ++p) s = fmaxf(s, rows[(size_t)p * D + c]);
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p) s = p < P ? fmaxf(s, x[p]) : s;
         return s;
     }
     if (pool_mode == VLSA_POOL_WEIGHT) {
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += pw[p] * rows[(size_t)p * D + c];
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p) s += p < P ? pw[p] * x[p] : 0.f;
         return s;
     }
-    return rows[c];  // VLSA_POOL_GIVEN
+    return x[0];  // VLSA_POOL_GIVEN
 }
 
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, int P, int D, int pool_mode,
@@ -129,6 +150,22 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
+    // W rows of this workgroup first: their loads are in flight while the pooled vector is being formed
+    float4 wq[2][VLSA_MAX_D / 256];
+    float bj[2] = {0.f, 0.f};
+    if (W != nullptr) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int j = blockIdx.x * kHeadRowsPerBlock + wv * 2 + rr;
+#pragma unroll
+            for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+                const int c = lane * 4 + 256 * i;
+                wq[rr][i] = (j < D && c < D) ? *reinterpret_cast<const float4*>(W + (size_t)j * D + c)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (j < D && bias != nullptr) bj[rr] = bias[j];
+        }
+    }
     if (pool_mode == VLSA_POOL_WEIGHT) {  // softmax over the raw 'weight' parameter (model/deepmil.py:148)
         if (tid == 0) {
             float mx = -INFINITY, s = 0.f;
@@ -145,39 +182,34 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     }
     __syncthreads();
 
+    // publish v write-through (sc1: relaxed agent-scope atomic stores), so no release fence is needed
     if (W != nullptr) {
-        // each wave: 2 output rows; lanes stride the D columns in float4
+#pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int j = blockIdx.x * kHeadRowsPerBlock + wv * 2 + rr;
-            if (j < D) {
-                const float* wr = W + (size_t)j * D;
-                float s = 0.f;
-                for (int c = lane * 4; c < D; c += 256) {
-                    const float4 wq = *reinterpret_cast<const float4*>(wr + c);
-                    s += wq.x * sp[c] + wq.y * sp[c + 1] + wq.z * sp[c + 2] + wq.w * sp[c + 3];
-                }
-                s = wave_sum(s);
-                if (lane == 0) v[j] = s + (bias != nullptr ? bias[j] : 0.f);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < D) s += wq[rr][i].x * sp[c] + wq[rr][i].y * sp[c + 1] + wq[rr][i].z * sp[c + 2] + wq[rr][i].w * sp[c + 3];
             }
+            s = wave_sum(s);
+            if (lane == 0 && j < D) __hip_atomic_store(v + j, s + bj[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
-        for (int c = tid; c < D; c += 256) v[c] = sp[c];
+        for (int c = tid; c < D; c += 256) __hip_atomic_store(v + c, sp[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-
-    // publish + ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == (unsigned int)(NB - 1));
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!s_last) return;
 
     // ---- last arriver: v^ = v / max(|v|, eps); logits = exp(ls) * v^ . T^_k; incidence = softmax ----
+    // v is read with agent-scope (sc1) loads: L1 is bypassed, so no acquire fence is needed either.
     float ss = 0.f;
     for (int c = tid; c < D; c += 256) {
         const float x = __hip_atomic_load(v + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
         for (int k = 0; k < K; ++k) s += expf(slog[k] - mx);
         for (int k = 0; k < K; ++k) incidence[k] = expf(slog[k] - mx) / s;
     }
-    if (tid == 0) *counter = 0u;  // leave the ticket clean for callers that skip the memset
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ticket back to zero
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -309,7 +341,6 @@ extern "C" int vlsa_head_forward(const float* rows, int P, int D, int pool_mode,
     if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_GIVEN) return VLSA_EINVAL;
     if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) return VLSA_ELAUNCH;
     const int NB = W ? (D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock : 1;
     hipLaunchKernelGGL(k_head, dim3(NB), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
                        static_cast<unsigned int*>(workspace), pooled, v, vhat, vnorm, logits, incidence, NB);

@@ -85,7 +85,7 @@ class PreparedQueries:
         return self.buf[off:off + 128].view(torch.float32)[: self.nq]
 
 
-def prepare_queries(Q: torch.Tensor, gated: bool = False) -> PreparedQueries:
+def prepare_queries(Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE) -> PreparedQueries:
     _need_gpu(Q)
     lib = nat.load()
     Q = _f32c(Q)
@@ -94,7 +94,8 @@ def prepare_queries(Q: torch.Tensor, gated: bool = False) -> PreparedQueries:
     if not (1 <= P <= nat.MAX_P):
         raise ValueError(f"number of queries P={P} outside [1, {nat.MAX_P}]")
     buf = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=Q.device)
-    nat.check(lib.vlsa_prepare_queries(_p(Q), nq, D, int(gated), _p(buf), _stream()), "vlsa_prepare_queries")
+    nat.check(lib.vlsa_prepare_queries(_p(Q), nq, D, int(gated), float(coattn_scale), _p(buf), _stream()),
+              "vlsa_prepare_queries")
     return PreparedQueries(buf, nq, P, D, gated)
 
 
@@ -102,8 +103,7 @@ def num_partials(N: int) -> int:
     return int(nat.load().vlsa_num_partials(N))
 
 
-def vlfan_partial(X: torch.Tensor, qp: PreparedQueries, coattn_scale: float = COATTN_SCALE,
-                  kernel: int = nat.KERNEL_AUTO, want_scores: bool = False):
+def vlfan_partial(X: torch.Tensor, qp: PreparedQueries, kernel: int = nat.KERNEL_AUTO, want_scores: bool = False):
     """One streaming pass over a shard's rows -> per-workgroup partials (pm[G,16], pl[G,16], pacc[G,P,D])
     and, if asked, the log2-domain scores [P, N]."""
     _need_gpu(X)
@@ -124,7 +124,7 @@ def vlfan_partial(X: torch.Tensor, qp: PreparedQueries, coattn_scale: float = CO
         pacc.zero_()
         return pm, pl, pacc, scores
     dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
-    nat.check(lib.vlsa_vlfan_partial(_p(X), dt, N, X.stride(0), D, _p(qp.buf), qp.P, float(coattn_scale), kernel,
+    nat.check(lib.vlsa_vlfan_partial(_p(X), dt, N, X.stride(0), D, _p(qp.buf), qp.P, kernel,
                                      _p(pm), _p(pl), _p(pacc), _p(scores), _stream()), "vlsa_vlfan_partial")
     return pm, pl, pacc, scores
 
@@ -186,7 +186,7 @@ def head_forward(rows: torch.Tensor, pool: str, pool_w: Optional[torch.Tensor], 
     b_ = _f32c(b) if b is not None else None
     pw = _f32c(pool_w).reshape(-1) if pool_w is not None else None
     ls = _f32c(logit_scale).reshape(1)
-    ws = torch.empty(lib.vlsa_head_workspace_bytes(D), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.vlsa_head_workspace_bytes(D), dtype=torch.uint8, device=dev)
     f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)  # noqa: E731
     pooled, v, vhat, vnorm, logits = f(D), f(D), f(D), f(1), f(K)
     inc = f(K) if want_incidence else None
@@ -199,8 +199,8 @@ def head_forward(rows: torch.Tensor, pool: str, pool_w: Optional[torch.Tensor], 
 def vlfan_aggregate(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
                     kernel: int = nat.KERNEL_AUTO, want_attn: bool = False):
     """Inference-only cross-attention aggregation: out[P, D] = softmax_N(100 cos(Q, X)) @ X, plus A[P, N]."""
-    qp = prepare_queries(Q, gated)
-    pm, pl, pacc, scores = vlfan_partial(X, qp, coattn_scale, kernel, want_scores=want_attn)
+    qp = prepare_queries(Q, gated, coattn_scale)
+    pm, pl, pacc, scores = vlfan_partial(X, qp, kernel, want_scores=want_attn)
     m2, l, out = vlfan_merge(pm, pl, pacc, normalise=True)
     A = attn_normalise(scores, m2, l) if want_attn else None
     return out, A, (m2, l, qp)
@@ -211,3 +211,66 @@ def debug_probe(which: int, device="cuda") -> torch.Tensor:
     out = torch.zeros(64, 4, dtype=torch.float32, device=device)
     nat.check(lib.vlsa_debug_probe(which, _p(out), out.numel() * 4, _stream()), "vlsa_debug_probe")
     return out
+
+
+class VlfanInferencePlan:
+    """Pre-allocated buffers + raw C-ABI calls for the fused inference forward of one bag shape.
+
+    One ``run(X, Q, T, ...)`` = what ``VLSA.forward`` does per bag in eval mode with cached text features
+    (model/vlsa.py:181-198 via the branch at 160-161): query normalisation, text normalisation, the
+    streaming aggregation, the partial merge and the incidence head.  No torch allocation or sync inside,
+    so a sequence of runs can be captured in a hipGraph.
+    """
+
+    def __init__(self, N: int, D: int, P: int, K: int, device, gated: bool = False, pool: str = "mean",
+                 identity_head: bool = False, kernel: int = nat.KERNEL_AUTO, want_attn: bool = False,
+                 coattn_scale: float = COATTN_SCALE):
+        lib = nat.load()
+        self.lib, self.N, self.D, self.P, self.K = lib, N, D, P, K
+        self.gated, self.pool, self.kernel, self.scale = gated, _POOL_CODES[pool], kernel, float(coattn_scale)
+        self.identity_head = identity_head
+        self.G = num_partials(N)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        self.qprep = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=device)
+        self.pm, self.pl, self.pacc = f(self.G, nat.P_STRIDE), f(self.G, nat.P_STRIDE), f(self.G, P, D)
+        self.m2, self.l, self.out = f(nat.P_STRIDE), f(nat.P_STRIDE), f(P, D)
+        self.That, self.tnorm = f(K, D), f(K)
+        self.ws = torch.zeros(lib.vlsa_head_workspace_bytes(D), dtype=torch.uint8, device=device)
+        self.pooled, self.v, self.vhat, self.vnorm = f(D), f(D), f(D), f(1)
+        self.logits, self.incidence = f(K), f(K)
+        self.scores = f(P, N) if want_attn else None
+        self.A = f(P, N) if want_attn else None
+
+    def run(self, X: torch.Tensor, Q: torch.Tensor, T: torch.Tensor, logit_scale: torch.Tensor,
+            W: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
+            pool_w: Optional[torch.Tensor] = None):
+        """X [N, D] (fp32/bf16, unit inner stride), Q [nq, D] fp32, T [K, D] fp32 raw text features,
+        logit_scale 0-dim fp32 -- all contiguous device tensors (not checked here: hot path)."""
+        lib, s = self.lib, _stream()
+        nq = self.P + 1 if self.gated else self.P
+        c = nat.check
+        c(lib.vlsa_prepare_queries(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), s),
+          "prepare_queries")
+        c(lib.vlsa_normalize_rows(_p(T), self.K, self.D, _p(self.That), _p(self.tnorm), s), "normalize_rows")
+        dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
+        c(lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
+                                 self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc), _p(self.scores), s),
+          "vlfan_partial")
+        c(lib.vlsa_vlfan_merge(_p(self.pm), _p(self.pl), _p(self.pacc), self.G, self.P, self.D, 1, _p(self.m2),
+                               _p(self.l), _p(self.out), s), "vlfan_merge")
+        if self.scores is not None:
+            c(lib.vlsa_attn_normalise(_p(self.scores), self.P, self.N, _p(self.m2), _p(self.l), _p(self.A), s),
+              "attn_normalise")
+        c(lib.vlsa_head_forward(_p(self.out), self.P, self.D, self.pool, _p(pool_w),
+                                None if self.identity_head else _p(W), None if self.identity_head else _p(b),
+                                _p(self.That), self.K, _p(logit_scale), _p(self.ws), _p(self.pooled), _p(self.v),
+                                _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence), s),
+          "head_forward")
+        return self.logits
+
+    def run_partial_only(self, X: torch.Tensor):
+        """Just the streaming kernel (for roofline timing); queries must have been prepared by a run()."""
+        dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
+        nat.check(self.lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
+                                              self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc),
+                                              _p(self.scores), _stream()), "vlfan_partial")
