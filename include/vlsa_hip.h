@@ -98,6 +98,19 @@ int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D
 int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int normalise,
                      float* m2, float* l, float* out, void* stream);
 
+/*
+ * Backward of the aggregation w.r.t. the EFFECTIVE queries (what torch.autograd does through
+ * model/deepmil.py:187-200; X carries no gradient).  Given dout = dLoss/d(out) [P, D] and the forward's out, m2, l:
+ * one more streaming pass writes per-workgroup partial SUMS of
+ *     de_p = coattn_scale * sum_n A_pn (dout_p . x_n - dout_p . out_p) x_n / max(|x_n|, 1e-12)
+ * into pm (= 0), pl (= 1), pacc [G, P, D]; reduce them with vlsa_vlfan_merge(..., normalise = 0).
+ * bwd_prep: scratch of vlsa_bwd_prep_bytes(D).  D must be 512 (VLSA_EUNSUPPORTED otherwise).
+ */
+size_t vlsa_bwd_prep_bytes(int D);
+int vlsa_vlfan_backward(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int P,
+                        float coattn_scale, const float* dout, const float* out, const float* m2, const float* l,
+                        void* bwd_prep, float* pm, float* pl, float* pacc, void* stream);
+
 /* A[p, n] = exp2(scores[p, n] - m2[p]) / l[p]   (softmax of model/deepmil.py:198). */
 int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, const float* l, float* A,
                         void* stream);
@@ -121,6 +134,40 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
                       const float* b, const float* That, int K, const float* logit_scale, void* workspace,
                       float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
                       void* stream);
+
+/* ---- the other MIL encoders the VLSA wrapper accepts (FeatMIL, DeepMIL) and the zero-shot path ---------- */
+
+/* Partials written by vlsa_scored_pool_partial / scratch rows of vlsa_colmax for N rows. */
+int vlsa_pool_num_partials(int64_t N);
+
+/*
+ * Replaces: A = softmax(a, dim=N); out = A @ x (model/layers.py:115-116,146-147) and, with scores == NULL,
+ * torch.mean(X, dim=1) (model/deepmil.py:57-58,271-272).  One query: pm/pl [G,16] (column 0 used),
+ * pacc [G,1,D]; merge with vlsa_vlfan_merge(P = 1).  scores [N] are natural-log-domain raw attention scores.
+ */
+int vlsa_scored_pool_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* scores,
+                             float* pm, float* pl, float* pacc, void* stream);
+
+/* Replaces: torch.max(X, dim=1) (model/deepmil.py:59-60,273-274). partials [G, D] scratch, out [D]. */
+int vlsa_colmax(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float* partials, float* out, void* stream);
+
+/*
+ * Replaces the elementwise part of Attention_Pooling / Gated_Attention_Pooling scoring (model/layers.py:110-113,
+ * 144): a[n] = w2 . (tanh(H[n] + b1) [* sigmoid(Hg[n] + bg)]) + b2, H = x W1^T (and Hg = x Wg^T) being plain
+ * [N,512]x[512,hid] GEMMs done by the caller (rocBLAS).  Hg/bg NULL => ungated.
+ */
+int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const float* b1, const float* bg,
+                     const float* w2, const float* b2, float* a, void* stream);
+
+/* out[n] = x_n . v  -- the N-sized piece of the attention-pooling backward. */
+int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out, void* stream);
+
+/*
+ * Replaces: logits.topk(min(k, N), 0).values.mean(0) and logits.mean(0) (logit_pooling, model/deepmil.py:16-37)
+ * on class-major scores S [C, N]; out[c] = out_scale * mean of the k largest of S[c, :] (k >= N: plain mean).
+ * k <= 32 unless k >= N (VLSA_EUNSUPPORTED otherwise).
+ */
+int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, float* out, void* stream);
 
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);

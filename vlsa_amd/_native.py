@@ -39,12 +39,23 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
+    "vlsa_bwd_prep_bytes": (c_size_t, [c_int]),
+    "vlsa_vlfan_backward": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_float, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_attn_normalise": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_head_workspace_bytes": (c_size_t, [c_int]),
     "vlsa_head_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "vlsa_pool_num_partials": (c_int, [c_int64]),
+    "vlsa_scored_pool_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
+    "vlsa_colmax": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_attn_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "vlsa_rowdot": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_topk_mean": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vlsa_debug_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
 }
 

@@ -1,0 +1,292 @@
+// N-sized pieces of the other MIL encoders the VLSA wrapper accepts:
+//   * scored pooling      out = softmax_N(a) @ X     (Attention_Pooling / Gated_Attention_Pooling over all patches,
+//                         model/layers.py:116,147; with a == const it is FeatMIL / DeepMIL mean pooling)
+//   * column max          FeatMIL / DeepMIL max pooling (model/deepmil.py:59-60,273-274)
+//   * attention scores    a_n = w2 . tanh(h_n + b1) [* sigmoid(hg_n + bg)] + b2 from the hidden projections
+//                         (the [N,512]x[512,256] projections themselves are plain GEMMs: rocBLAS via torch)
+//   * row dots            x_n . v for the pooling backward
+//   * per-class top-k mean of the zero-shot logits (logit_pooling, model/deepmil.py:16-37)
+// All of them are HBM-bound streaming reductions: one wave per patch row, 16-byte (bf16) / 8-byte loads per
+// lane are not needed here because a row is spread over the 64 lanes with unit stride (fully coalesced).
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+__device__ __forceinline__ void rows_of_block(int64_t N, int b, int G, int64_t& rbeg, int64_t& rend) {
+    const int64_t q = N / G, r = N % G;
+    rbeg = b * q + (b < r ? b : r);
+    rend = rbeg + q + (b < r ? 1 : 0);
+}
+
+// ---- scored pooling: per-workgroup online-softmax partial with ONE query (P = 1 layout of the VLFAN partials)
+template <typename XT, int DPL>
+__global__ __launch_bounds__(256) void k_scored_pool_partial(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                              const float* __restrict__ scores, float* __restrict__ pm,
+                                                              float* __restrict__ pl, float* __restrict__ pacc, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    int64_t rbeg, rend;
+    rows_of_block(N, b, G, rbeg, rend);
+    float acc[DPL], M = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+    for (int64_t r = rbeg + w; r < rend; r += 4) {
+        const float t = scores != nullptr ? scores[r] * kLog2e : 0.f;
+        float x[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            x[i] = d < D ? load_as_float(X + r * ldx + d) : 0.f;
+        }
+        if (t > M) {
+            const float f = fast_exp2(M - t);
+            l *= f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) acc[i] *= f;
+            M = t;
+        }
+        const float wgt = fast_exp2(t - M);
+        l += wgt;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] += wgt * x[i];
+    }
+    float* sm = reinterpret_cast<float*>(smem);  // [4] M, [4] l, then [4][DPL*64] acc
+    float* sl = sm + 4;
+    float* sacc = sm + 8;
+    constexpr int DW = DPL * 64;
+    if (lane == 0) {
+        sm[w] = M;
+        sl[w] = l;
+    }
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) sacc[w * DW + lane + 64 * i] = acc[i];
+    __syncthreads();
+    const float mm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float f[4], lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (sm[k] == -INFINITY) ? 0.f : fast_exp2(sm[k] - mm);
+        lt += sl[k] * f[k];
+    }
+    if (tid == 0) {
+        pm[(size_t)b * kPStride] = mm;
+        pl[(size_t)b * kPStride] = lt;
+    }
+    for (int d = tid; d < D; d += 256)
+        pacc[(size_t)b * D + d] = sacc[d] * f[0] + sacc[DW + d] * f[1] + sacc[2 * DW + d] * f[2] + sacc[3 * DW + d] * f[3];
+}
+
+// ---- column max: per-workgroup partial [G, D], then a tiny reduce
+template <typename XT, int DPL>
+__global__ __launch_bounds__(256) void k_colmax_partial(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                         float* __restrict__ part, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    int64_t rbeg, rend;
+    rows_of_block(N, b, G, rbeg, rend);
+    float mx[DPL];
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) mx[i] = -INFINITY;
+    for (int64_t r = rbeg + w; r < rend; r += 4) {
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int d = lane + 64 * i;
+            if (d < D) mx[i] = fmaxf(mx[i], load_as_float(X + r * ldx + d));
+        }
+    }
+    float* s = reinterpret_cast<float*>(smem);
+    constexpr int DW = DPL * 64;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) s[w * DW + lane + 64 * i] = mx[i];
+    __syncthreads();
+    for (int d = tid; d < D; d += 256)
+        part[(size_t)b * D + d] = fmaxf(fmaxf(s[d], s[DW + d]), fmaxf(s[2 * DW + d], s[3 * DW + d]));
+}
+
+__global__ __launch_bounds__(256) void k_colmax_merge(const float* __restrict__ part, int G, int D, float* __restrict__ out) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float m = -INFINITY;
+    for (int g = 0; g < G; ++g) m = fmaxf(m, part[(size_t)g * D + d]);
+    out[d] = m;
+}
+
+// ---- attention scores from the hidden projections: one wave per patch row
+__global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ H, const float* __restrict__ Hg, int64_t N,
+                                                      int hid, const float* __restrict__ b1, const float* __restrict__ bg,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave; n < N; n += nwaves) {
+        float s = 0.f;
+        for (int j = lane; j < hid; j += 64) {
+            float e = tanhf(H[n * hid + j] + b1[j]);
+            if (Hg != nullptr) e *= 1.f / (1.f + expf(-(Hg[n * hid + j] + bg[j])));
+            s += w2[j] * e;
+        }
+        s = wave_sum(s);
+        if (lane == 0) a[n] = s + b2[0];
+    }
+}
+
+// ---- out[n] = x_n . v  (pooling backward: d a_n = A_n (x_n . dpooled - pooled . dpooled))
+template <typename XT>
+__global__ __launch_bounds__(256) void k_rowdot(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                 const float* __restrict__ v, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t n = wave; n < N; n += nwaves) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += load_as_float(X + n * ldx + d) * v[d];
+        s = wave_sum(s);
+        if (lane == 0) out[n] = s;
+    }
+}
+
+// ---- per-class top-k mean over N (k <= 32): one workgroup per class.
+// Each thread keeps the k largest of its strided subset (sorted insertion in registers), the 256 lists are
+// merged by k rounds of workgroup-wide arg-max.  k >= N degenerates to the mean of all N.
+constexpr int kTopKMax = 32;
+__global__ __launch_bounds__(256) void k_topk_mean(const float* __restrict__ S, int64_t N, int k, float scale_log2e_inv,
+                                                    float* __restrict__ out) {
+    __shared__ float sval[256];
+    __shared__ int sidx[256];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, cls = blockIdx.x;
+    const float* s = S + (size_t)cls * N;
+    if ((int64_t)k >= N) {  // mean over everything
+        float a = 0.f;
+        for (int64_t n = tid; n < N; n += 256) a += s[n];
+        a = block_sum_256(a, red);
+        if (tid == 0) out[cls] = a / (float)N * scale_log2e_inv;
+        return;
+    }
+    float top[kTopKMax];
+#pragma unroll
+    for (int i = 0; i < kTopKMax; ++i) top[i] = -INFINITY;
+    for (int64_t n = tid; n < N; n += 256) {
+        float v = s[n];
+        // sorted insertion (descending); static indices only
+#pragma unroll
+        for (int i = 0; i < kTopKMax; ++i) {
+            if (i < k) {
+                const float hi = fmaxf(top[i], v);
+                v = fminf(top[i], v);
+                top[i] = hi;
+            }
+        }
+    }
+    float sum = 0.f;
+    int head = 0;  // position of this thread's best remaining candidate
+    for (int round = 0; round < k; ++round) {
+        float mine = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kTopKMax; ++i)
+            if (i == head) mine = top[i];
+        sval[tid] = mine;
+        sidx[tid] = tid;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off && sval[tid + off] > sval[tid]) {
+                sval[tid] = sval[tid + off];
+                sidx[tid] = sidx[tid + off];
+            }
+            __syncthreads();
+        }
+        const int winner = sidx[0];
+        sum += sval[0];
+        __syncthreads();
+        if (tid == winner) ++head;
+    }
+    if (tid == 0) out[cls] = sum / (float)k * scale_log2e_inv;
+}
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+static inline int st() { return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH; }
+
+extern "C" int vlsa_pool_num_partials(int64_t N) {
+    const int64_t t = (N + 63) / 64;
+    return (int)(t < 1 ? 1 : (t > 512 ? 512 : t));
+}
+
+template <typename XT>
+static int launch_scored(const XT* X, int64_t N, int64_t ldx, int D, const float* scores, float* pm, float* pl, float* pacc,
+                         int G, hipStream_t s) {
+#define VLSA_SP(DPL)                                                                                                \
+    {                                                                                                               \
+        const size_t lds = (8 + (size_t)4 * DPL * 64) * sizeof(float);                                              \
+        hipLaunchKernelGGL((k_scored_pool_partial<XT, DPL>), dim3(G), dim3(256), lds, s, X, N, ldx, D, scores, pm, pl, pacc, G); \
+    }
+    if (D <= 256) VLSA_SP(4) else if (D <= 512) VLSA_SP(8) else if (D <= 768) VLSA_SP(12) else VLSA_SP(16)
+#undef VLSA_SP
+    return st();
+}
+
+extern "C" int vlsa_scored_pool_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* scores,
+                                        float* pm, float* pl, float* pacc, void* stream) {
+    if (!X || !pm || !pl || !pacc || N < 1 || D < 1 || D > VLSA_MAX_D || ldx < D) return VLSA_EINVAL;
+    const int G = vlsa_pool_num_partials(N);
+    if (x_dtype == VLSA_DT_F32) return launch_scored<float>((const float*)X, N, ldx, D, scores, pm, pl, pacc, G, (hipStream_t)stream);
+    if (x_dtype == VLSA_DT_BF16) return launch_scored<__bf16>((const __bf16*)X, N, ldx, D, scores, pm, pl, pacc, G, (hipStream_t)stream);
+    return VLSA_EINVAL;
+}
+
+template <typename XT>
+static int launch_colmax(const XT* X, int64_t N, int64_t ldx, int D, float* part, float* out, int G, hipStream_t s) {
+#define VLSA_CM(DPL)                                                                                               \
+    {                                                                                                              \
+        const size_t lds = (size_t)4 * DPL * 64 * sizeof(float);                                                   \
+        hipLaunchKernelGGL((k_colmax_partial<XT, DPL>), dim3(G), dim3(256), lds, s, X, N, ldx, D, part, G);        \
+    }
+    if (D <= 256) VLSA_CM(4) else if (D <= 512) VLSA_CM(8) else if (D <= 768) VLSA_CM(12) else VLSA_CM(16)
+#undef VLSA_CM
+    hipLaunchKernelGGL(k_colmax_merge, dim3((D + 255) / 256), dim3(256), 0, s, part, G, D, out);
+    return st();
+}
+
+extern "C" int vlsa_colmax(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float* partials, float* out,
+                           void* stream) {
+    if (!X || !partials || !out || N < 1 || D < 1 || D > VLSA_MAX_D || ldx < D) return VLSA_EINVAL;
+    const int G = vlsa_pool_num_partials(N);
+    if (x_dtype == VLSA_DT_F32) return launch_colmax<float>((const float*)X, N, ldx, D, partials, out, G, (hipStream_t)stream);
+    if (x_dtype == VLSA_DT_BF16) return launch_colmax<__bf16>((const __bf16*)X, N, ldx, D, partials, out, G, (hipStream_t)stream);
+    return VLSA_EINVAL;
+}
+
+extern "C" int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const float* b1, const float* bg,
+                                const float* w2, const float* b2, float* a, void* stream) {
+    if (!H || !b1 || !w2 || !b2 || !a || N < 1 || hid < 1 || (Hg && !bg)) return VLSA_EINVAL;
+    int64_t nb = (N + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, H, Hg, N, hid, b1, bg, w2, b2, a);
+    return st();
+}
+
+extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out,
+                           void* stream) {
+    if (!X || !v || !out || N < 1 || D < 1 || ldx < D) return VLSA_EINVAL;
+    int64_t nb = (N + 3) / 4;
+    if (nb > 2048) nb = 2048;
+    if (x_dtype == VLSA_DT_F32)
+        hipLaunchKernelGGL(k_rowdot<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)X, N, ldx, D, v, out);
+    else if (x_dtype == VLSA_DT_BF16)
+        hipLaunchKernelGGL(k_rowdot<__bf16>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, N, ldx, D, v, out);
+    else
+        return VLSA_EINVAL;
+    return st();
+}
+
+extern "C" int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, float* out, void* stream) {
+    if (!S || !out || C < 1 || N < 1 || k < 1) return VLSA_EINVAL;
+    if (k > kTopKMax && (int64_t)k < N) return VLSA_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_topk_mean, dim3(C), dim3(256), 0, (hipStream_t)stream, S, N, k, out_scale, out);
+    return st();
+}

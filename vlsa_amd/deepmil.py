@@ -1,0 +1,226 @@
+"""MIL encoders usable as ``VLSA.mil_encoder`` -- drop-in counterparts of the reference's ``model/deepmil.py``
+classes (same constructor kwargs, attribute names and state-dict keys), with the N-sized arithmetic in HIP.
+
+    VLFAN         model/deepmil.py:74-215     language-guided cross-attention aggregation (the shipped encoder)
+    FeatMIL       model/deepmil.py:40-67      mean / max / identity (zero-shot)
+    DeepMIL       model/deepmil.py:222-292    ABMIL-style (gated-)attention pooling over the N patches
+    logit_pooling model/deepmil.py:16-37      top-k / mean pooling of per-patch class logits
+
+The reference picks the encoder with ``getattr(model.deepmil, cfg['name'])(**cfg)`` (model/utils_vl.py:129-138);
+``vlsa_amd.vlsa.build_mil_encoder`` does the same lookup in this module.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as VF
+from .layers import Adapter, Attention_Pooling, Feat_Projecter, Gated_Attention_Pooling
+
+__all__ = ["logit_pooling", "FeatMIL", "VLFAN", "DeepMIL"]
+
+
+def _parse_logit_pooling(method: str):
+    if method[:9] in ("logit_max", "logit_top"):
+        return 1 if method == "logit_max" else int(method.split("top")[-1])
+    if method == "logit_mean":
+        return None
+    raise NotImplementedError(f"The pooling ({method}) is not implemented.")
+
+
+def logit_pooling(logits: torch.Tensor, method: str):
+    """logits: [N, C] per-patch class logits -> (preds[1], pooled[1, C]).  (model/deepmil.py:16-37)"""
+    topk = _parse_logit_pooling(method)
+    N = logits.size(0)
+    k = N if topk is None else min(topk, N)
+    pooled = VF.topk_mean(logits.t().contiguous(), k)[None, :]
+    return pooled.argmax(dim=1), pooled
+
+
+class FeatMIL(nn.Module):
+    """Feature aggregation only: 'mean' | 'max' over the patches, anything else = identity (zero-shot)."""
+
+    def __init__(self, pooling="mean", **kwargs):
+        super().__init__()
+        self.network = nn.Identity()
+        self.pooling = pooling
+
+    def forward(self, X):
+        assert X.shape[0] == 1
+        if self.pooling == "mean":
+            return VF.scored_pool(X, None)[None, :]
+        if self.pooling == "max":
+            return VF.colmax(X)[None, :]
+        return X.squeeze(0)
+
+
+class VLFAN(nn.Module):
+    """Language-guided visual feature aggregation network (model/deepmil.py:74-215).
+
+    P query vectors (text prototypes through a query network, or an ``nn.Parameter``) cross-attend over the N
+    patches with cosine scores x 100, softmax over the patches; the P aggregated rows are pooled over the queries
+    and passed through the visual adapter.  The cross attention runs in the HIP streaming kernels.
+    """
+
+    def __init__(self, dim_in=1024, dim_hid=256, use_feat_proj=True, drop_rate=0.25, query="Parameter", num_query=10,
+                 gated_query=False, query_pooling="mean", pred_head="default", dim_reduction=4, keep_ratio=0.8, **kwargs):
+        super().__init__()
+        self._pos_gated_query = -1
+        self.feat_proj = Feat_Projecter(dim_in, dim_in) if use_feat_proj else None
+        self.num_query = num_query
+        self.query_type = query
+        self.gated_query = gated_query
+        assert self.query_type in ["Parameter", "Text"]
+        if self.query_type != "Parameter":
+            self.Q = None  # call reset_query() with the query network
+        else:
+            self.Q = nn.Parameter(torch.randn(num_query + 1 if gated_query else num_query, dim_in))
+        assert query_pooling in ["mean", "max", "weight", "attention", "gated_attention"]
+        if query_pooling == "attention":
+            self.query_pooling = Attention_Pooling(dim_in, dim_hid)
+        elif query_pooling == "gated_attention":
+            self.query_pooling = Gated_Attention_Pooling(dim_in, dim_hid, dropout=drop_rate)
+        elif query_pooling == "weight":
+            self.query_pooling = nn.Parameter(torch.randn(1, num_query))
+        else:
+            self.query_pooling = query_pooling
+        self.pred_head = pred_head
+        self.visual_adapter = nn.Identity() if pred_head == "Identity" else nn.Linear(dim_in, dim_in)
+        self.use_custom_coattn = True
+        self.coattn_logit_scale = torch.ones([]) * math.log(100)  # plain tensor attribute, as in the reference
+
+    # -- reference API ---------------------------------------------------------------------------------
+    def get_coattn_logit_scale(self):
+        return self.coattn_logit_scale.exp()
+
+    def reset_query(self, query_network):
+        assert self.query_type != "Parameter", f"Cannot override Q (query) for query_type ({self.query_type})."
+        self.Q = query_network
+
+    def get_query(self):
+        assert self.Q is not None, f"You have to call `reset_query` to reset query for query_type ({self.query_type})."
+        return self.Q() if callable(self.Q) else self.Q
+
+    def query_div_loss(self, last_div=True, **kws):
+        Q = self.get_query()
+        nQ = F.normalize(Q, dim=-1)
+        if len(Q) == self.num_query + 1 and last_div:
+            sim = nQ[-1:] @ nQ[:-1].T
+        else:
+            sim = nQ @ nQ.T
+            sim = sim[~torch.eye(len(Q), dtype=torch.bool, device=sim.device)]
+        return sim.abs().mean()
+
+    def forward_query_pooling(self, X):
+        """[B, P, C] -> ([B, C], scores or None)"""
+        if isinstance(self.query_pooling, str):
+            if self.query_pooling == "mean":
+                return torch.mean(X, dim=1), None
+            return torch.max(X, dim=1)[0], None
+        if callable(self.query_pooling) and not isinstance(self.query_pooling, nn.Parameter):
+            return self.query_pooling(X)
+        weight = F.softmax(self.query_pooling, dim=-1).unsqueeze(0)
+        return torch.matmul(weight, X).squeeze(1), None
+
+    # -- fused inference support -------------------------------------------------------------------------
+    def fused_head_spec(self):
+        """(pool mode, pool weight, W, b) if pooling + adapter can run in the fused HIP head, else None."""
+        if self.feat_proj is not None:
+            return None
+        if isinstance(self.query_pooling, str):
+            mode, pw = self.query_pooling, None
+        elif isinstance(self.query_pooling, nn.Parameter):
+            mode, pw = "weight", self.query_pooling
+        else:
+            return None
+        if isinstance(self.visual_adapter, nn.Linear):
+            return mode, pw, self.visual_adapter.weight, self.visual_adapter.bias
+        return mode, pw, None, None
+
+    def forward(self, X, ret_with_attn=False):
+        assert X.shape[0] == 1
+        if self.feat_proj is not None:
+            X = self.feat_proj(X)
+        Q = self.get_query()
+        if self.gated_query:
+            assert self._pos_gated_query == -1, "The gated query is placed at the end by default."
+            assert Q.shape[0] == self.num_query + 1, f"Query number is expected to be {self.num_query + 1}."
+        scale = float(self.coattn_logit_scale.exp())
+        out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
+        pooled_out, pooled_ext = self.forward_query_pooling(out.unsqueeze(0))
+        visual_features = self.visual_adapter(pooled_out)
+        if ret_with_attn:
+            A = A.unsqueeze(0)
+            attn = (A, pooled_ext.detach()) if pooled_ext is not None else A
+            return visual_features, attn
+        return visual_features
+
+
+class DeepMIL(nn.Module):
+    """ABMIL-style encoder (model/deepmil.py:222-292): optional Feat_Projecter, mean / max / (gated-)attention pooling
+    over the N patches, Adapter head mixed with ``keep_ratio`` or a Linear head."""
+
+    def __init__(self, dim_in=1024, dim_hid=256, num_cls=2, use_feat_proj=True, drop_rate=0.25, pooling="attention",
+                 pred_head="default", dim_reduction=4, keep_ratio=0.8, **kwargs):
+        super().__init__()
+        assert pooling in ["mean", "max", "attention", "gated_attention"]
+        assert pred_head in ["default", "Adapter"]
+        self.feat_proj = Feat_Projecter(dim_in, dim_in) if use_feat_proj else None
+        if pooling == "gated_attention":
+            self.sigma = Gated_Attention_Pooling(dim_in, dim_hid, dropout=drop_rate)
+        elif pooling == "attention":
+            self.sigma = Attention_Pooling(dim_in, dim_hid)
+        else:
+            self.sigma = pooling
+        self.pred_head = pred_head
+        if pred_head == "Adapter":
+            assert 0 <= keep_ratio <= 1.0
+            self.keep_ratio = keep_ratio
+            self.visual_adapter = Adapter(dim_in, dim_reduction)
+        else:
+            self.g = nn.Linear(dim_in, num_cls)
+
+    def _attention_scores(self, X2):
+        """raw scores a[N] of the pooling module on all patches: hidden projections by rocBLAS, the rest in HIP when
+        no autograd graph is needed (else torch elementwise ops so the pooling parameters get gradients)."""
+        sg = self.sigma
+        Xf = X2 if X2.dtype == torch.float32 else X2.float()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in sg.parameters())
+        if isinstance(sg, Attention_Pooling):
+            lin1, lin2 = sg.attention[0], sg.attention[2]
+            H = Xf @ lin1.weight.t()
+            if need_grad:
+                return (torch.tanh(H + lin1.bias) @ lin2.weight.t() + lin2.bias).squeeze(-1)
+            return VF.attn_scores(H, None, lin1.bias, None, lin2.weight, lin2.bias)
+        la, lg, l2 = sg.fc1[0], sg.score[0], sg.fc2
+        H, Hg = Xf @ la.weight.t(), Xf @ lg.weight.t()
+        if need_grad or (sg.training and sg.fc1[2].p > 0):
+            e = sg.fc1[2](torch.tanh(H + la.bias)) * sg.score[2](torch.sigmoid(Hg + lg.bias))
+            return (e @ l2.weight.t() + l2.bias).squeeze(-1)
+        return VF.attn_scores(H, Hg, la.bias, lg.bias, l2.weight, l2.bias)
+
+    def forward(self, X, ret_with_attn=False):
+        assert X.shape[0] == 1
+        if self.feat_proj is not None:
+            X = self.feat_proj(X)
+        raw_attn = None
+        if self.sigma == "mean":
+            out_feat = VF.scored_pool(X, None)[None, :]
+        elif self.sigma == "max":
+            out_feat = VF.colmax(X)[None, :]
+        else:
+            X2 = VF._bag2d(X)
+            a = self._attention_scores(X2)
+            out_feat = VF.scored_pool(X2, a)[None, :]
+            # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
+            raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
+        if self.pred_head == "Adapter":
+            logit = self.keep_ratio * out_feat + (1 - self.keep_ratio) * self.visual_adapter(out_feat)
+        else:
+            logit = self.g(out_feat)
+        if ret_with_attn:
+            return logit, raw_attn.detach()
+        return logit

@@ -274,3 +274,168 @@ class VlfanInferencePlan:
         nat.check(self.lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
                                               self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc),
                                               _p(self.scores), _stream()), "vlfan_partial")
+
+
+# ------------------------------------------------------------------------------------------------------
+# autograd: cross-attention aggregation with gradient w.r.t. the queries (X has none in the reference)
+# ------------------------------------------------------------------------------------------------------
+class _VlfanAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, Q, gated, coattn_scale, kernel, want_attn):
+        X2 = _bag2d(X)
+        qp = prepare_queries(Q, gated, coattn_scale)
+        pm, pl, pacc, scores = vlfan_partial(X2, qp, kernel, want_scores=want_attn)
+        m2, l, out = vlfan_merge(pm, pl, pacc, normalise=True)
+        A = attn_normalise(scores, m2, l) if want_attn else torch.empty(0, device=X2.device)
+        ctx.save_for_backward(X2, out, m2, l, qp.buf)
+        ctx.meta = (qp.nq, qp.P, qp.D, bool(gated), float(coattn_scale))
+        ctx.mark_non_differentiable(A)
+        return out, A
+
+    @staticmethod
+    def backward(ctx, dout, _dA):
+        X2, out, m2, l, qbuf = ctx.saved_tensors
+        nq, P, D, gated, scale = ctx.meta
+        lib = nat.load()
+        N = X2.shape[0]
+        dev = X2.device
+        dout = _f32c(dout)
+        G = num_partials(N)
+        pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pacc = torch.empty(G, P, D, dtype=torch.float32, device=dev)
+        prep = torch.empty(lib.vlsa_bwd_prep_bytes(D), dtype=torch.uint8, device=dev)
+        dt = nat.DT_F32 if X2.dtype == torch.float32 else nat.DT_BF16
+        if N == 0:
+            dE = torch.zeros(P, D, dtype=torch.float32, device=dev)
+        else:
+            nat.check(lib.vlsa_vlfan_backward(_p(X2), dt, N, X2.stride(0), D, _p(qbuf), P, scale, _p(dout), _p(out),
+                                              _p(m2), _p(l), _p(prep), _p(pm), _p(pl), _p(pacc), _stream()),
+                      "vlsa_vlfan_backward")
+            _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
+        # chain rule through e_p = q^_p - gated * q^_gate and q^ = q / max(|q|, eps): P x D host-side math
+        qp = PreparedQueries(qbuf, nq, P, D, gated)
+        qhat, qnorm = qp.qhat, qp.qnorm
+        dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
+        dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
+        return None, dQ, None, None, None, None
+
+
+def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
+                          kernel: int = nat.KERNEL_AUTO, want_attn: bool = False):
+    """out[P, D] = softmax_N(coattn_scale * cos(Q, X)) @ X (model/deepmil.py:187-200), differentiable w.r.t. Q.
+    Returns (out, A) with A[P, N] the detached attention weights (None unless want_attn)."""
+    _need_gpu(X, Q)
+    out, A = _VlfanAggregateFn.apply(X, Q.float(), bool(gated), float(coattn_scale), int(kernel), bool(want_attn))
+    return out, (A if want_attn else None)
+
+
+# ------------------------------------------------------------------------------------------------------
+# FeatMIL / DeepMIL / zero-shot pieces (model/deepmil.py:16-67,222-292; model/layers.py:85-153)
+# ------------------------------------------------------------------------------------------------------
+def _dt(X):
+    return nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
+
+
+def _scored_pool_raw(X2: torch.Tensor, scores: Optional[torch.Tensor]):
+    lib = nat.load()
+    N, D = X2.shape
+    G = int(lib.vlsa_pool_num_partials(N))
+    dev = X2.device
+    pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+    pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+    pacc = torch.empty(G, 1, D, dtype=torch.float32, device=dev)
+    nat.check(lib.vlsa_scored_pool_partial(_p(X2), _dt(X2), N, X2.stride(0), D, _p(scores), _p(pm), _p(pl), _p(pacc),
+                                           _stream()), "vlsa_scored_pool_partial")
+    return vlfan_merge(pm, pl, pacc, normalise=True)  # m2[16], l[16], out[1, D]
+
+
+def rowdot(X: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    _need_gpu(X, v)
+    lib = nat.load()
+    X2 = _bag2d(X)
+    N, D = X2.shape
+    out = torch.empty(N, dtype=torch.float32, device=X2.device)
+    nat.check(lib.vlsa_rowdot(_p(X2), _dt(X2), N, X2.stride(0), D, _p(_f32c(v)), _p(out), _stream()), "vlsa_rowdot")
+    return out
+
+
+class _ScoredPoolFn(torch.autograd.Function):
+    """pooled[D] = softmax_N(a) @ X, differentiable w.r.t. the raw scores a[N] (X has no gradient)."""
+
+    @staticmethod
+    def forward(ctx, X2, a):
+        a = _f32c(a).reshape(-1)
+        m2, l, out = _scored_pool_raw(X2, a)
+        ctx.save_for_backward(X2, a, m2, l, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        X2, a, m2, l, out = ctx.saved_tensors
+        dp = _f32c(dpooled)
+        xd = rowdot(X2, dp)                                    # N-sized piece in HIP
+        A = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]  # [N] vector math
+        da = A * (xd - (out[0] * dp).sum())
+        return None, da
+
+
+def scored_pool(X: torch.Tensor, scores: Optional[torch.Tensor]) -> torch.Tensor:
+    """softmax_N(scores) @ X -> [D]; scores None => mean over the N rows."""
+    _need_gpu(X, scores)
+    X2 = _bag2d(X)
+    if X2.shape[0] == 0:
+        raise ValueError("empty bag")
+    if scores is None:
+        return _scored_pool_raw(X2, None)[2][0]
+    return _ScoredPoolFn.apply(X2, scores)
+
+
+def colmax(X: torch.Tensor) -> torch.Tensor:
+    _need_gpu(X)
+    lib = nat.load()
+    X2 = _bag2d(X)
+    N, D = X2.shape
+    G = int(lib.vlsa_pool_num_partials(N))
+    part = torch.empty(G, D, dtype=torch.float32, device=X2.device)
+    out = torch.empty(D, dtype=torch.float32, device=X2.device)
+    nat.check(lib.vlsa_colmax(_p(X2), _dt(X2), N, X2.stride(0), D, _p(part), _p(out), _stream()), "vlsa_colmax")
+    return out
+
+
+def attn_scores(H: torch.Tensor, Hg: Optional[torch.Tensor], b1, bg, w2, b2) -> torch.Tensor:
+    """a[n] = w2 . (tanh(H[n] + b1) [* sigmoid(Hg[n] + bg)]) + b2 (inference path; H = X W1^T from rocBLAS)."""
+    _need_gpu(H)
+    lib = nat.load()
+    H = _f32c(H)
+    N, hid = H.shape
+    a = torch.empty(N, dtype=torch.float32, device=H.device)
+    Hg_ = _f32c(Hg) if Hg is not None else None
+    nat.check(lib.vlsa_attn_scores(_p(H), _p(Hg_), N, hid, _p(_f32c(b1)), _p(_f32c(bg)) if bg is not None else None,
+                                   _p(_f32c(w2).reshape(-1)), _p(_f32c(b2).reshape(-1)), _p(a), _stream()),
+              "vlsa_attn_scores")
+    return a
+
+
+def topk_mean(S: torch.Tensor, k: int, out_scale: float = 1.0) -> torch.Tensor:
+    """Per-class mean of the k largest entries of S[C, N] (k >= N: plain mean), times out_scale."""
+    _need_gpu(S)
+    lib = nat.load()
+    S = _f32c(S)
+    C, N = S.shape
+    out = torch.empty(C, dtype=torch.float32, device=S.device)
+    nat.check(lib.vlsa_topk_mean(_p(S), C, N, int(k), float(out_scale), _p(out), _stream()), "vlsa_topk_mean")
+    return out
+
+
+def class_cosines(X: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    """cos(T_k, x_n) for every class / patch: [K, N] (zero-shot logits before the logit scale; model/vlsa.py:185-192).
+    Runs the streaming MFMA kernel with the K text embeddings as queries and keeps its score output."""
+    _need_gpu(X, T)
+    K = T.shape[0]
+    outs = []
+    for k0 in range(0, K, nat.MAX_P):
+        qp = prepare_queries(T[k0:k0 + nat.MAX_P], False, 1.0 / 1.4426950408889634)  # scores come back as plain cosines
+        _, _, _, sc = vlfan_partial(X, qp, want_scores=True)
+        outs.append(sc)
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)

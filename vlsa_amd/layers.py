@@ -1,0 +1,74 @@
+"""Pooling / adapter layers with the reference's attribute and state-dict names (model/layers.py:50-153).
+
+These operate on small inputs in the shipped configuration (the P <= 16 aggregated rows inside VLFAN, the
+[1, D] bag vector in the Adapter head): plain torch modules on the device.  When DeepMIL applies the attention
+poolings to all N patches the N-sized part runs in HIP (vlsa_amd.deepmil.DeepMIL)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class Adapter(nn.Module):
+    """Bias-free bottleneck MLP with ReLU after both layers (model/layers.py:50-62). Keys: fc.0.weight, fc.2.weight."""
+
+    def __init__(self, c_in: int, reduction: int = 4):
+        super().__init__()
+        hid = c_in // reduction
+        self.fc = nn.Sequential(nn.Linear(c_in, hid, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(hid, c_in, bias=False), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class Feat_Projecter(nn.Module):
+    """Linear + LayerNorm on every row (model/layers.py:65-82). Keys: projecter.0.*, projecter.1.*."""
+
+    def __init__(self, in_dim: int = 1024, out_dim: int = 1024):
+        super().__init__()
+        self.projecter = nn.Sequential(nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
+
+    def forward(self, x):
+        if x.dim() == 3:
+            b, n, d = x.shape
+            return self.projecter(x.reshape(-1, d)).reshape(b, n, -1)
+        return self.projecter(x)
+
+
+class Gated_Attention_Pooling(nn.Module):
+    """ABMIL gated attention (model/layers.py:85-122). Keys: fc1.0.*, score.0.*, fc2.*.
+    Returns (pooled[B, d], attn) where attn is the softmax weights, or the raw scores if ret_raw_attn."""
+
+    def __init__(self, in_dim: int, hid_dim: int, dropout: float = 0.5):
+        super().__init__()
+        self.fc1 = nn.Sequential(nn.Linear(in_dim, hid_dim), nn.Tanh(), nn.Dropout(dropout))
+        self.score = nn.Sequential(nn.Linear(in_dim, hid_dim), nn.Sigmoid(), nn.Dropout(dropout))
+        self.fc2 = nn.Linear(hid_dim, 1)
+
+    def forward(self, x, ret_raw_attn: bool = False):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        raw = self.fc2(self.fc1(x) * self.score(x)).transpose(2, 1)  # [B, 1, n]
+        attn = F.softmax(raw, dim=2)
+        out = torch.matmul(attn, x).squeeze(1)
+        return (out, raw.squeeze(1)) if ret_raw_attn else (out, attn.squeeze(1))
+
+
+class Attention_Pooling(nn.Module):
+    """ABMIL attention (model/layers.py:125-153). Keys: attention.0.*, attention.2.*.
+    The reference returns the RAW scores by default; its ret_raw_attn=False branch raises (UnboundLocalError,
+    SURVEY.md 7.4-9) -- here that branch returns the softmax weights, which is what the code evidently meant."""
+
+    def __init__(self, in_dim: int = 1024, hid_dim: int = 512):
+        super().__init__()
+        self.attention = nn.Sequential(nn.Linear(in_dim, hid_dim), nn.Tanh(), nn.Linear(hid_dim, 1))
+
+    def forward(self, x, ret_raw_attn: bool = True):
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        raw = self.attention(x).transpose(2, 1)  # [B, 1, n]
+        attn = F.softmax(raw, dim=2)
+        out = torch.matmul(attn, x).squeeze(1)
+        return (out, raw.squeeze(1)) if ret_raw_attn else (out, attn.squeeze(1))

@@ -1,0 +1,155 @@
+"""Drop-in counterpart of the reference's ``VLSA`` model (model/vlsa.py:21-198) for the per-bag forward.
+
+What callers of the reference touch exists here with the same names and meaning:
+``net(X) -> (logits[1,K], image_features, text_features)``, ``get_logit_scale()``, ``logit_scale``,
+``mil_encoder`` (``VLFAN`` / ``FeatMIL`` / ``DeepMIL`` from ``vlsa_amd.deepmil``), ``forward_text_only()``,
+``encode_instances()``, ``prompt_learner`` / ``prompt_encoder`` (whatever objects the caller plugs in -- the CONCH
+text tower is out of scope and is consumed through ``text_provider``), and ``state_dict()`` keys
+``logit_scale``, ``mil_encoder.visual_adapter.{weight,bias}``, ``mil_encoder.Q.residual_features`` ...
+
+Text features are bag-independent; the reference re-runs its 12-layer text tower for every bag.
+Here ``forward_text_only`` caches the provider's output keyed on the parameter versions of the provider, which is
+exact: it is recomputed whenever an optimizer step (or any in-place update) touched those parameters.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import deepmil as mil_encoders
+from . import functional as VF
+from .deepmil import FeatMIL, VLFAN, logit_pooling
+from .prompt_adapter import PromptAdapter
+
+
+def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
+    """getattr(model.deepmil, cfg['name'])(**cfg)  (model/utils_vl.py:129-138)."""
+    name = image_encoder_cfg["name"]
+    cls = getattr(mil_encoders, name, None)
+    if cls is None or name.startswith("_"):
+        raise ValueError(f"Got an invalid MIL encoder name: {name}.")
+    return cls(**image_encoder_cfg)
+
+
+class VLSA(nn.Module):
+    def __init__(self, image_encoder_cfg: dict, text_provider: Optional[Callable[[], torch.Tensor]] = None,
+                 pretrained_text_features: Optional[torch.Tensor] = None, query_network: Optional[nn.Module] = None,
+                 logit_scale_init: float = math.log(1 / 0.07), prompt_learner: Optional[nn.Module] = None,
+                 prompt_encoder: Optional[nn.Module] = None, cache_text_features: bool = True, **kwargs):
+        """image_encoder_cfg: the ``vlsa_img_encoder_*`` keys of cfg_vlsa_conch.yaml with the prefix stripped
+        (runner/vlsa_handler.py:110-111).  Text side: ``pretrained_text_features`` [K, D] (the reference's cached
+        branch, model/vlsa.py:160-161) or ``text_provider`` -- any callable returning [K, D], e.g. the reference's
+        ``lambda: prompt_encoder(prompts_embedding=prompt_learner(), prompts_pseudo_tokens=...)``."""
+        super().__init__()
+        self.kwargs = kwargs
+        self.image_encoder_cfg = dict(image_encoder_cfg)
+        self.mil_encoder = build_mil_encoder(self.image_encoder_cfg)
+        if isinstance(self.mil_encoder, VLFAN) and self.mil_encoder.query_type == "Text":
+            if query_network is None:
+                raise ValueError("VLFAN(query='Text') needs `query_network` (e.g. vlsa_amd.prompt_adapter.PromptAdapter)")
+            self.mil_encoder.reset_query(query_network)
+        if pretrained_text_features is not None:
+            self.register_buffer("pretrained_text_features", pretrained_text_features.detach().clone(), persistent=False)
+        if prompt_learner is not None:
+            self.prompt_learner = prompt_learner
+        if prompt_encoder is not None:
+            self.prompt_encoder = prompt_encoder
+        self.text_provider = text_provider
+        self.cache_text_features = cache_text_features
+        self._text_cache = None
+        self._text_cache_key = None
+        self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init)  # CoCa init, model/conch/coca_model.py:187
+        self._plans = {}
+
+    # -- text side -----------------------------------------------------------------------------------------
+    def _provider_key(self):
+        mods = [m for m in (getattr(self, "prompt_learner", None), getattr(self, "prompt_encoder", None)) if m is not None]
+        key = []
+        for m in mods:
+            key.extend((id(p), p._version) for p in m.parameters())
+        return tuple(key), torch.is_grad_enabled()
+
+    def forward_text_only(self):
+        if hasattr(self, "pretrained_text_features"):
+            return self.pretrained_text_features.clone()
+        if self.text_provider is None:
+            raise RuntimeError("no text features: give `pretrained_text_features` or `text_provider`")
+        if not self.cache_text_features:
+            return self.text_provider()
+        key = self._provider_key()
+        if self._text_cache is None or key != self._text_cache_key:
+            self._text_cache, self._text_cache_key = self.text_provider(), key
+        return self._text_cache
+
+    def encode_instances(self, X):
+        return self.mil_encoder(X)
+
+    def get_logit_scale(self):
+        return self.logit_scale.exp()
+
+    # -- forward -----------------------------------------------------------------------------------------
+    def _needs_grad(self, text_features):
+        if not torch.is_grad_enabled():
+            return False
+        return text_features.requires_grad or any(p.requires_grad for p in self.parameters())
+
+    def _fused_vlfan(self, X, text_features):
+        enc = self.mil_encoder
+        spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
+        if spec is None or X.dim() != 3 or X.shape[0] != 1 or not X.is_cuda or X.shape[1] == 0:
+            return None
+        mode, pw, W, b = spec
+        X2 = VF._bag2d(X)
+        N, D = X2.shape
+        Q = enc.get_query().detach().float().contiguous()
+        P = Q.shape[0] - (1 if enc.gated_query else 0)
+        K = text_features.shape[0]
+        if not (1 <= P <= 16 and 1 <= K <= 64 and D % 8 == 0 and D <= 1024):
+            return None
+        key = (N, D, P, K, X2.dtype, X2.device, enc.gated_query, mode, W is None)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            plan = VF.VlfanInferencePlan(N, D, P, K, X2.device, gated=enc.gated_query, pool=mode, identity_head=W is None,
+                                         coattn_scale=float(enc.coattn_logit_scale.exp()))
+            self._plans[key] = plan
+        plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
+                 None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
+                 None if pw is None else pw.detach().float().reshape(-1).contiguous())
+        return plan.logits.clone()[None, :], plan.vhat.clone()[None, :], plan.That.clone()
+
+    def forward(self, X):
+        """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm))."""
+        text_features = self.forward_text_only()
+        if not self._needs_grad(text_features):
+            fused = self._fused_vlfan(X, text_features)
+            if fused is not None:
+                return fused
+        enc = self.mil_encoder
+        if isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max"):
+            return self._forward_zeroshot(X, text_features)
+        text_features = F.normalize(text_features, dim=-1)
+        image_features = F.normalize(self.encode_instances(X), dim=-1)
+        logits = self.logit_scale.exp() * image_features @ text_features.t()
+        if logits.shape[0] > 1:
+            _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
+        return logits, image_features, text_features
+
+    def _forward_zeroshot(self, X, text_features):
+        """Identity FeatMIL: per-patch cosine logits pooled over the patches (model/vlsa.py:194-196)."""
+        from .deepmil import _parse_logit_pooling
+        assert X.shape[0] == 1
+        X2 = VF._bag2d(X)
+        N = X2.shape[0]
+        topk = _parse_logit_pooling(self.image_encoder_cfg["pooling"])
+        cosines = VF.class_cosines(X2, text_features.detach())                 # [K, N]
+        pooled = VF.topk_mean(cosines, N if topk is None else min(topk, N))      # [K]
+        logits = (self.logit_scale.exp() * pooled)[None, :]
+        That, _ = VF.normalize_rows(text_features.detach())
+        image_features, _ = VF.normalize_rows(X2 if X2.dtype == torch.float32 else X2.float())
+        return logits, image_features, That
