@@ -47,8 +47,7 @@ def cpu_baseline(seconds=10.0):
     """The CPU oracle (restatement of the reference's torch op sequence, pinned to the reference by
     tests/golden) timed on this host's cores on the same workload: kind = "port"."""
     from oracle import vlsa_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(7)
     X = torch.randn(N_PER_GPU, D, generator=g).to(torch.bfloat16).float()
     Q = torch.randn(P, D, generator=g)
@@ -57,15 +56,25 @@ def cpu_baseline(seconds=10.0):
     b = torch.randn(D, generator=g) / D ** 0.5
     ls = torch.tensor(4.0309)
     with torch.no_grad():
-        for _ in range(2):
+        # torch CPU kernels stop scaling (and then regress) well below the core count of a GPU host: pick the
+        # fastest thread count from a short calibration and report THAT many cores.
+        best = (float("inf"), 1)
+        for th in sorted({1, 8, 16, 32, 64, ncpu} & set(range(1, ncpu + 1))):
+            torch.set_num_threads(th)
             O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+            t0 = time.perf_counter()
+            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+            best = min(best, (time.perf_counter() - t0, th))
+        cores = best[1]
+        torch.set_num_threads(cores)
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
             O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
             n += 1
         dt = time.perf_counter() - t0
     return {"value": N_PER_GPU * n / dt, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{n} bags of 50000x512 (fp32 math on bf16-rounded values) in {dt:.1f} s, torch {torch.__version__} CPU"}
+            "sample": f"{n} bags of 50000x512 (fp32 math on bf16-rounded values) in {dt:.1f} s, torch {torch.__version__} CPU, "
+                      f"best of 1/8/16/32/64/{ncpu} threads"}
 
 
 def main():
@@ -88,12 +97,15 @@ def main():
     from vlsa_amd import functional as F
 
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("VLSA_BENCH_FORCE_SHARDED") == "1"  # exercise the N > 1 code path on one GPU
+    if world > 1 or force_sharded:
         import torch.distributed as dist
+        if force_sharded and "RANK" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     bags, Q, T, W, b, ls = synth(device, 100 + rank)
-    if world == 1:
+    if world == 1 and not force_sharded:
         plan = F.VlfanInferencePlan(N_PER_GPU, D, P, K, device)
         step = lambda i: plan.run(bags[i % N_BAGS], Q, T, ls, W, b)  # noqa: E731
     else:
@@ -111,7 +123,7 @@ def main():
         step(i)
     sync()
 
-    use_graph = (not a.no_graph) and world == 1
+    use_graph = (not a.no_graph) and world == 1 and not force_sharded
     if use_graph:
         chunk = min(a.steps, 64)
         s = torch.cuda.Stream()
@@ -186,7 +198,13 @@ def main():
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        try:  # flush anything native libraries (RCCL banner) left in the C stdio buffer, so the JSON is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -97,6 +97,11 @@ int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D
  */
 int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int normalise,
                      float* m2, float* l, float* out, void* stream);
+/* Same with explicit strides (in floats) between consecutive partials -- lets the all-gathered per-rank records
+ * [m2(16) | l(16) | acc(P*D)] of the multi-GPU path be merged in place.  pacc_stride % 4 == 0. */
+int vlsa_vlfan_merge_strided(const float* pm, int64_t pm_stride, const float* pl, int64_t pl_stride, const float* pacc,
+                             int64_t pacc_stride, int G, int P, int D, int normalise, float* m2, float* l, float* out,
+                             void* stream);
 
 /*
  * Backward of the aggregation w.r.t. the EFFECTIVE queries (what torch.autograd does through

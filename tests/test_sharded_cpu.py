@@ -1,0 +1,71 @@
+"""N > 1 path on CPU with gloo (world_size 2): the shard partition, the one-collective exchange of compact records and
+the log-sum-exp merge reproduce the single-process result.  The local partial and the merge arithmetic are provided
+here by the CPU oracle (test infrastructure) -- on a GPU box the same driver code calls the HIP kernels."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from oracle import vlsa_oracle as O
+
+
+def test_shard_bounds_partition_rows():
+    from vlsa_amd.sharded import shard_bounds
+    for N in (0, 1, 15, 16, 17, 1000, 50_000, 200_000, 199_999):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(N, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == N
+            for (a, b), (c, d) in zip(edges[:-1], edges[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 32
+            assert all(a % 16 == 0 or a == N for a, _ in edges)
+
+
+def _worker(rank, world, port, N, P, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vlsa_amd import sharded
+        X = cases.make_bag(N, 11)
+        params = cases.make_params(P, 4, 12)
+        Q = 0.5 * params["resid"] + params["prompt"]
+        a, b = sharded.shard_bounds(N, world, rank)
+        Qh = O.l2_normalize(Q)
+        m, l, acc, s = O.vlfan_partial(X[a:b], Qh)              # natural-log-domain partial of this shard
+        LOG2E = 1.4426950408889634
+        rec = torch.zeros(sharded.record_floats(P, 512))
+        rec[:P] = m * LOG2E                                       # ABI records carry the log2-domain max
+        rec[16:16 + P] = l
+        rec[32:] = acc.reshape(-1)
+        gathered = torch.empty(world, rec.numel())
+        sharded.all_gather_records(rec, gathered)
+        ms = [gathered[r, :P] / LOG2E for r in range(world)]
+        ls = [gathered[r, 16:16 + P] for r in range(world)]
+        accs = [gathered[r, 32:].reshape(P, 512) for r in range(world)]
+        mg, lg, out = O.merge_partials(ms, ls, accs)
+        A_local = torch.exp(s - mg[:, None]) / lg[:, None]
+        ref = O.vlfan_forward(X, Q)
+        err_out = (out - ref["out"]).abs().max().item()
+        err_A = (A_local - ref["A"][:, a:b]).abs().max().item()
+        ret[rank] = (err_out, err_A, a, b)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [1000, 33])
+def test_two_rank_gloo_exchange_matches_single_process(N):
+    world, P = 2, 12
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 500) + N % 7
+    mp.spawn(_worker, args=(world, port, N, P, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        err_out, err_A, a, b = ret[r]
+        assert err_out < 1e-4 and err_A < 1e-5, (r, err_out, err_A)
+    assert ret[0][3] == ret[1][2]

@@ -39,6 +39,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
+    "vlsa_vlfan_merge_strided": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_bwd_prep_bytes": (c_size_t, [c_int]),
     "vlsa_vlfan_backward": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_float, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

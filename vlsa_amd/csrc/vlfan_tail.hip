@@ -13,7 +13,7 @@ namespace vlsa {
 __global__ __launch_bounds__(256) void k_vlfan_merge(const float* __restrict__ pm, const float* __restrict__ pl,
                                                       const float* __restrict__ pacc, int G, int P, int D,
                                                       int normalise, float* __restrict__ m2, float* __restrict__ l,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, int64_t sm, int64_t sl_, int64_t sa) {
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
     __shared__ float sl[16];
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_vlfan_merge(const float* __restrict__ p
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     float lt = 0.f;
     // pass 1: global max over all G partials (each thread scans a strided subset; G is small)
-    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * kPStride + p]);
+    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * sm + p]);
     mx = wave_max(mx);
     if (lane == 0) red[wv] = mx;
     __syncthreads();
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void k_vlfan_merge(const float* __restrict__ p
         for (int u = 0; u < U; ++u) {
             const int gI = g0 + 16 * u;
             const bool ok = gI < G;
-            mg[u] = ok ? pm[(size_t)gI * kPStride + p] : -INFINITY;
-            lg[u] = ok ? pl[(size_t)gI * kPStride + p] : 0.f;
-            v[u] = (ok && incol) ? *reinterpret_cast<const float4*>(pacc + ((size_t)gI * P + p) * D + col)
+            mg[u] = ok ? pm[(size_t)gI * sm + p] : -INFINITY;
+            lg[u] = ok ? pl[(size_t)gI * sl_ + p] : 0.f;
+            v[u] = (ok && incol) ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * sa + (size_t)p * D + col)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -304,13 +304,22 @@ extern "C" const char* vlsa_error_string(int code) {
 
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH; }
 
-extern "C" int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D,
-                                int normalise, float* m2, float* l, float* out, void* stream) {
+extern "C" int vlsa_vlfan_merge_strided(const float* pm, int64_t pm_stride, const float* pl, int64_t pl_stride,
+                                        const float* pacc, int64_t pacc_stride, int G, int P, int D, int normalise,
+                                        float* m2, float* l, float* out, void* stream) {
     if (!pm || !pl || !pacc || !m2 || !l || !out) return VLSA_EINVAL;
     if (G < 1 || P < 1 || P > VLSA_MAX_P || D <= 0 || D > VLSA_MAX_D || (D % 8) != 0) return VLSA_EINVAL;
+    if (pm_stride < P || pl_stride < P || pacc_stride < (int64_t)P * D || (pacc_stride % 4) != 0 ||
+        (reinterpret_cast<uintptr_t>(pacc) & 15) != 0)
+        return VLSA_EINVAL;
     hipLaunchKernelGGL(k_vlfan_merge, dim3((D + 63) / 64, P), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D,
-                       normalise, m2, l, out);
+                       normalise, m2, l, out, pm_stride, pl_stride, pacc_stride);
     return launch_status();
+}
+
+extern "C" int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D,
+                                int normalise, float* m2, float* l, float* out, void* stream) {
+    return vlsa_vlfan_merge_strided(pm, kPStride, pl, kPStride, pacc, (int64_t)P * D, G, P, D, normalise, m2, l, out, stream);
 }
 
 extern "C" int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, const float* l, float* A,

@@ -1,0 +1,150 @@
+"""Patch-sharded multi-GPU execution of one bag: one process per GPU, rows split contiguously.
+
+Each rank streams its shard with the same HIP kernel, folds its workgroup partials into ONE compact record
+``[m2(16) | l(16) | acc(P*D)]`` (24.7 KB at P=12, D=512), the ranks exchange the records with a single RCCL all-gather
+over xGMI, and every rank merges the ``world`` records and runs the (replicated) incidence head.  The softmax over the
+patches is permutation invariant, so any row partition gives the single-GPU result up to fp32 summation order.
+Attention weights stay sharded: each rank normalises its own scores with the global (m2, l).
+
+The exchange is latency bound (tens of microseconds for a 25 KB collective), so ``ShardedVlfanPlan`` software-pipelines
+it: the all-gather of bag i runs on a side stream while the streaming kernel of bag i+1 runs; the merge + head of bag i
+is enqueued after that.  ``finish()`` drains the pipeline.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from . import functional as VF
+
+REC_HDR = 2 * nat.P_STRIDE  # floats of (m2, l) in front of acc in a compact record
+
+
+def shard_bounds(N: int, world: int, rank: int, align: int = 16) -> Tuple[int, int]:
+    """Contiguous row range of `rank`: boundaries at multiples of `align` rows, balanced to within one unit."""
+    units = (N + align - 1) // align
+    q, r = divmod(units, world)
+    ub = rank * q + min(rank, r)
+    ue = ub + q + (1 if rank < r else 0)
+    return min(ub * align, N), min(ue * align, N)
+
+
+def record_floats(P: int, D: int) -> int:
+    return REC_HDR + P * D
+
+
+def all_gather_records(record: torch.Tensor, out: torch.Tensor, group=None, async_op: bool = False):
+    """One collective: every rank contributes its compact record; out is [world, record_floats]."""
+    import torch.distributed as dist
+    return dist.all_gather_into_tensor(out.view(-1), record.view(-1), group=group, async_op=async_op)
+
+
+class ShardedVlfanPlan:
+    """Fused inference forward of a patch-sharded bag; same results on every rank."""
+
+    def __init__(self, N_local: int, D: int, P: int, K: int, device, dist_module=None, group=None, gated: bool = False,
+                 pool: str = "mean", identity_head: bool = False, want_attn: bool = False, pipeline: bool = True):
+        import torch.distributed as dist
+        self.dist = dist_module or dist
+        self.group = group
+        self.world = self.dist.get_world_size(group)
+        self.local = VF.VlfanInferencePlan(N_local, D, P, K, device, gated=gated, pool=pool, identity_head=identity_head,
+                                           want_attn=want_attn)
+        self.P, self.D, self.K = P, D, K
+        rf = record_floats(P, D)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        self.rec = [f(rf), f(rf)]                       # double-buffered: bag i's record is in flight while i+1 computes
+        self.gathered = [f(self.world, rf), f(self.world, rf)]
+        self.comm_stream = torch.cuda.Stream(device=device) if pipeline else None
+        self.done_local = [torch.cuda.Event(), torch.cuda.Event()]
+        self.done_comm = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pipeline = pipeline
+        self._pending: Optional[tuple] = None
+        self._i = 0
+        self.lib = nat.load()
+
+    # -- pieces ----------------------------------------------------------------------------------------------
+    def _local_record(self, X, Q, slot):
+        pl_, lib, s = self.local, self.lib, VF._stream()
+        nq = self.P + 1 if pl_.gated else self.P
+        c, p = nat.check, VF._p
+        c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
+        dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
+        c(lib.vlsa_vlfan_partial(p(X), dt, pl_.N, X.stride(0), self.D, p(pl_.qprep), self.P, pl_.kernel, p(pl_.pm),
+                                 p(pl_.pl), p(pl_.pacc), p(pl_.scores), s), "vlfan_partial")
+        rec = self.rec[slot]
+        # fold the workgroup partials into the compact record in place: m2 -> rec[0:16], l -> rec[16:32], acc -> rec[32:]
+        c(lib.vlsa_vlfan_merge(p(pl_.pm), p(pl_.pl), p(pl_.pacc), pl_.G, self.P, self.D, 0, p(rec),
+                               ctypes.c_void_p(rec.data_ptr() + 4 * nat.P_STRIDE),
+                               ctypes.c_void_p(rec.data_ptr() + 4 * REC_HDR), s), "vlfan_merge(local)")
+
+    def _tail(self, slot, T, ls, W, b, pool_w):
+        pl_, lib, s = self.local, self.lib, VF._stream()
+        c, p = nat.check, VF._p
+        g = self.gathered[slot]
+        rf = record_floats(self.P, self.D)
+        base = g.data_ptr()
+        c(lib.vlsa_vlfan_merge_strided(ctypes.c_void_p(base), rf, ctypes.c_void_p(base + 4 * nat.P_STRIDE), rf,
+                                       ctypes.c_void_p(base + 4 * REC_HDR), rf, self.world, self.P, self.D, 1,
+                                       p(pl_.m2), p(pl_.l), p(pl_.out), s), "vlfan_merge(global)")
+        if pl_.scores is not None:
+            c(lib.vlsa_attn_normalise(p(pl_.scores), self.P, pl_.N, p(pl_.m2), p(pl_.l), p(pl_.A), s), "attn_normalise")
+        c(lib.vlsa_normalize_rows(p(T), self.K, self.D, p(pl_.That), p(pl_.tnorm), s), "normalize_rows")
+        c(lib.vlsa_head_forward(p(pl_.out), self.P, self.D, pl_.pool, p(pool_w), None if pl_.identity_head else p(W),
+                                None if pl_.identity_head else p(b), p(pl_.That), self.K, p(ls), p(pl_.ws), p(pl_.pooled),
+                                p(pl_.v), p(pl_.vhat), p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s), "head_forward")
+
+    # -- driver ----------------------------------------------------------------------------------------------
+    def run(self, X_local, Q, T, logit_scale, W=None, b=None, pool_w=None):
+        """Enqueue one bag. With pipeline=True the logits of THIS bag are valid after the next run() or finish()."""
+        slot = self._i & 1
+        self._i += 1
+        cur = torch.cuda.current_stream()
+        if self.pipeline:
+            cur.wait_event(self.done_comm[slot])      # the gather buffers of bag i-2 are free again
+        self._local_record(X_local, Q, slot)
+        if not self.pipeline:
+            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            self._tail(slot, T, logit_scale, W, b, pool_w)
+            return self.local.logits
+        self.done_local[slot].record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.done_local[slot])
+            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            self.done_comm[slot].record(self.comm_stream)
+        if self._pending is not None:
+            self._drain()
+        self._pending = (slot, T, logit_scale, W, b, pool_w)
+        return self.local.logits
+
+    def _drain(self):
+        slot, T, ls, W, b, pw = self._pending
+        torch.cuda.current_stream().wait_event(self.done_comm[slot])
+        self._tail(slot, T, ls, W, b, pw)
+        self._pending = None
+
+    def finish(self):
+        if self._pending is not None:
+            self._drain()
+        return self.local.logits
+
+
+def sharded_vlfan_forward(X_local: torch.Tensor, Q: torch.Tensor, gated: bool = False, group=None,
+                          want_attn: bool = False, coattn_scale: float = VF.COATTN_SCALE):
+    """Functional, unpipelined form: returns (out[P, D] identical on every rank, A_local[P, N_local] or None)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    qp = VF.prepare_queries(Q, gated, coattn_scale)
+    pm, pl, pacc, scores = VF.vlfan_partial(X_local, qp, want_scores=want_attn)
+    m2, l, acc = VF.vlfan_merge(pm, pl, pacc, normalise=False)
+    rec = torch.cat([m2, l, acc.reshape(-1)])
+    gathered = torch.empty(world, rec.numel(), dtype=torch.float32, device=rec.device)
+    all_gather_records(rec, gathered, group)
+    P, D = acc.shape
+    m2g, lg, out = VF.vlfan_merge(gathered[:, :nat.P_STRIDE].contiguous(), gathered[:, nat.P_STRIDE:REC_HDR].contiguous(),
+                                  gathered[:, REC_HDR:].reshape(world, P, D).contiguous(), normalise=True)
+    A = VF.attn_normalise(scores, m2g, lg) if want_attn else None
+    return out, A
