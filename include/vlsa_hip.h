@@ -140,6 +140,48 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
                       float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
                       void* stream);
 
+/* ---- batched forward: B bags per launch ------------------------------------------------------------------- */
+
+/* One bag of a batch (device-resident array of these is passed to vlsa_vlfan_forward_batch). */
+typedef struct vlsa_bag_desc {
+    const void* X;   /* [N, 512] bf16 rows, 16-byte aligned */
+    int64_t N;       /* patches in this bag (>= 0) */
+    int64_t ldx;     /* row stride in elements (>= 512, multiple of 8) */
+} vlsa_bag_desc;
+
+int vlsa_batch_max_bags(void);                                /* B <= this (64) */
+size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE after allocation; calls leave it reusable */
+
+/*
+ * B independent bags through the whole per-bag forward (model/vlsa.py:181-198 with cached text features, called once
+ * per bag by runner/vlsa_handler.py:267-269,322-330) in THREE launches: one persistent streaming kernel that walks all
+ * bags with the LDS-DMA ring running across bag boundaries, a batched merge and a batched incidence head.
+ * Queries (qprep) and unit text features (That) are shared by the batch.  bf16 rows, D == 512.
+ * Outputs: m2, l [B,16]; out [B,P,D]; pooled, v, vhat [B,D]; vnorm [B]; logits, incidence (nullable) [B,K].
+ */
+/* Only the persistent streaming kernel of the batch (partials into `workspace`); vlsa_vlfan_forward_batch = this +
+ * the batched merge + the batched head. */
+int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, void* workspace,
+                             void* stream);
+int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, int pool_mode,
+                             const float* pool_w, const float* W, const float* b, const float* That, int K,
+                             const float* logit_scale, void* workspace, float* m2, float* l, float* out, float* pooled,
+                             float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
+
+/*
+ * Batched log-sum-exp merge with explicit strides (in floats): strides9 (HOST array) = {partial stride of pm, pl, pacc;
+ * bag stride of pm, pl, pacc; bag stride of the outputs m2, l, out}.  Used by the multi-GPU batch path to fold the
+ * workgroup partials of B bags into B compact records and, after the all-gather, the per-rank records into the result.
+ */
+int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
+                                   int normalise, const int64_t* strides9, float* m2, float* l, float* out, void* stream);
+
+/* vlsa_head_forward for B bags in one launch: rows [B,P,D]; counters: B zeroed uint32; outputs [B, ...]. */
+int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                            const float* b, const float* That, int K, const float* logit_scale, void* counters,
+                            float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                            void* stream);
+
 /* ---- the other MIL encoders the VLSA wrapper accepts (FeatMIL, DeepMIL) and the zero-shot path ---------- */
 
 /* Partials written by vlsa_scored_pool_partial / scratch rows of vlsa_colmax for N rows. */

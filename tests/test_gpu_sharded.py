@@ -73,6 +73,17 @@ def test_sharded_plan_over_one_rank_rccl_group():
             torch.cuda.synchronize()
             for g, r in zip(got, refs):
                 assert (g - r).abs().max().item() < 1e-5, pipeline
+        # batched sharded plan (B bags per launch, one all-gather per batch)
+        from vlsa_amd.sharded import ShardedVlfanBatchPlan
+        for pipeline in (False, True):
+            bp = ShardedVlfanBatchPlan(3, P, K, dev, dist, pipeline=pipeline)
+            bp.set_bags(bags)
+            bp.run(Q, T, ls, W, b)
+            bp.run(Q, T, ls, W, b)
+            got = bp.finish().clone()
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert (got[i] - refs[i]).abs().max().item() < 2e-5, (pipeline, i)
         out, A = sharded_vlfan_forward(bags[0], Q, want_attn=True)
         ref_out, ref_A, _ = F.vlfan_aggregate(bags[0], Q, want_attn=True)
         assert (out - ref_out).abs().max().item() < 1e-5 and (A - ref_A).abs().max().item() < 1e-6

@@ -50,6 +50,17 @@ _SIGNATURES = {
     "vlsa_head_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "vlsa_batch_max_bags": (c_int, []),
+    "vlsa_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "vlsa_vlfan_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "vlsa_vlfan_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_vlfan_merge_batch_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_head_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
     "vlsa_pool_num_partials": (c_int, [c_int64]),
     "vlsa_scored_pool_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),

@@ -1,0 +1,530 @@
+// Batched (multi-bag) forward: ONE persistent launch of the LDS-DMA streaming kernel over a list of bags, then a
+// batched merge and a batched incidence head -- three launches for B slides.
+//
+// Why: at 50k patches a bag streams in ~9 us but a launch of the single-bag kernel has a fixed ~8 us latency chain
+// (descriptor/TLB misses, first tile, epilogue; profiles/README.md).  Here every workgroup walks its row range of bag
+// 0, 1, 2, ... with the DMA ring running straight across bag boundaries: the first tile of the next bag is already in
+// flight while the current bag's partial is merged and stored, so the fixed cost is paid once per batch and the HBM
+// stream never drains.  The evaluation loop of the reference (runner/vlsa_handler.py:315-345) and its 32-bag training
+// step (189-289) process independent bags back to back -- exactly this shape.
+//
+// Per-tile arithmetic, LDS image, exchange and epilogue are those of k_vlfan_partial_dma (vlfan_partial_dma.hip).
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef bf16x8 __attribute__((may_alias)) bf16x8_ma;
+typedef f32x4 __attribute__((may_alias)) f32x4_ma;
+typedef float __attribute__((may_alias)) float_ma;
+typedef int __attribute__((may_alias)) int_ma;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct BagDesc {  // device-side description of one bag (mirrors vlsa_bag_desc in vlsa_hip.h)
+    const void* X;
+    int64_t N;
+    int64_t ldx;
+};
+
+#ifdef VLSA_TIMING
+__device__ long long vlsa_dbg_batch[64];
+#define BSTAMP(k)                                                                                            \
+    do {                                                                                                     \
+        const int k_ = (k);                                                                                  \
+        if (blockIdx.x == 3 && threadIdx.x == 0 && k_ < 64) vlsa_dbg_batch[k_] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define BSTAMP(k) do {} while (0)
+#endif
+
+namespace bt {
+constexpr int kTile = 32;
+constexpr int kSlot = kTile * 256;
+constexpr int kWaveRing = 2 * kSlot;
+constexpr int kRingBytes = 8 * kWaveRing;        // 128 KiB
+constexpr int kExchWave = 2048 + 128;
+constexpr int kExchGroup = 4 * kExchWave;
+constexpr int kTabOff = kRingBytes + 2 * kExchGroup;  // bag table: 8 ints per bag
+constexpr int kMaxBags = 64;
+constexpr int kMlOff = kTabOff + kMaxBags * 32;       // (M, l) hand-off: 8 waves x 32 floats
+constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;        // 151,552 B
+constexpr float kThr = 16.0f;
+}  // namespace bt
+
+__device__ __forceinline__ int bswz(int row, int byte_off) { return row * 256 + (byte_off ^ ((row & 7) << 5)); }
+
+#define VLSA_BAR()                                           \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("" ::: "memory");                       \
+    } while (0)
+
+__global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDesc* __restrict__ bags, int B,
+                                                                     const __bf16* __restrict__ qsplit, int P,
+                                                                     float* __restrict__ pm, float* __restrict__ pl,
+                                                                     float* __restrict__ pacc) {
+    using namespace bt;
+    constexpr int D = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = w >> 2, cw = w & 3;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int b = blockIdx.x, G = gridDim.x;
+
+    unsigned char* ring = smem + w * kWaveRing;
+    unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
+    int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
+
+    // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
+    if (tid < B) {
+        const BagDesc d = bags[tid];
+        // 64-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
+        // unit rotates with the bag index so that the extra iterations even out over the batch
+        const unsigned long long units = (unsigned long long)((d.N + 63) >> 6);
+        const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
+        const unsigned int vb = (unsigned int)((b + tid * 37) % G);  // virtual workgroup index for this bag
+        const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
+        const long long rbeg = (long long)(ubeg << 6);
+        long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 6);
+        if (rend > d.N) rend = d.N;
+        const int nrows = rend > rbeg ? (int)(rend - rbeg) : 0;
+        const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 2ull;
+        int_ma* e = tab + tid * 8;
+        e[0] = (int)(unsigned int)addr;
+        e[1] = (int)((addr >> 32) & 0xffffu);
+        e[2] = nrows > 0 ? (int)(((long long)(nrows - 1) * d.ldx + D) * 2) : 0;  // descriptor span in bytes
+        e[3] = (int)(d.ldx * 2);                                                    // row pitch in bytes
+        e[4] = nrows;
+        e[5] = (nrows + kTile - 1) / kTile;
+        e[6] = (int)vb;  // partial slot of this workgroup for this bag
+    }
+    // query B-fragments (scale * log2 e folded in): lane holds Q[p = i16][128 cw + 32 kk + 8 g .. +8]
+    bf16x8 qf[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[t][kk] = *reinterpret_cast<const bf16x8*>(qsplit + ((size_t)t * 16 + i16) * D + cw * 128 + kk * 32 + g * 8);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(qf[t][kk]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * 8 + k]); };
+
+    const unsigned int ring_lds = (unsigned int)(uintptr_t)(lds_void_ptr)ring;
+    const int lr = lane >> 4;
+    const int chunk_e = ((lane & 15) ^ (lr << 1)) << 4, chunk_o = ((lane & 15) ^ (lr << 1) ^ 8) << 4;
+    // LDS-DMA of one 32-row tile of `bag` into ring slot `slot` (see k_vlfan_partial_dma for the layout)
+    auto issue_tile = [&](int bag, int tile, int slot) {
+        i32x4 rsrc;
+        rsrc[0] = tab_get(bag, 0);
+        rsrc[1] = tab_get(bag, 1);
+        rsrc[2] = tab_get(bag, 2);
+        rsrc[3] = 0x00020000;
+        const int ldb = tab_get(bag, 3);
+        const int voff_e = lr * ldb + cw * 256 + chunk_e, voff_o = lr * ldb + cw * 256 + chunk_o;
+        const int sbase = tile * kTile * ldb;
+        const unsigned int dst = ring_lds + slot * kSlot;
+        unsigned int keep;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst + i * 1024), "v"((i & 1) ? voff_o : voff_e), "s"(rsrc), "s"(sbase + i * 4 * ldb)
+                : "memory");
+        }
+    };
+    // this row group's next own tile after (bag, tile): same bag if it has one, else the first of a later bag
+    auto next_of = [&](int bag, int tile, int& nb, int& nt) {
+        if (tile + 2 < tab_get(bag, 5)) {
+            nb = bag;
+            nt = tile + 2;
+            return;
+        }
+        nb = bag + 1;
+        while (nb < B && tab_get(nb, 5) <= rg) ++nb;
+        nt = rg;
+    };
+
+    int kown = 0;      // own tiles consumed so far by this wave; own tile k lives in ring slot k & 1
+    int k0 = 0, k1 = 0;  // tiles consumed so far by row group 0 / 1 (for the epilogue's free-slot bookkeeping)
+    {
+        int fb = 0;  // first own tile of the whole batch
+        while (fb < B && tab_get(fb, 5) <= rg) ++fb;
+        if (fb < B) issue_tile(fb, rg, 0);
+    }
+
+    int stamp = 0;
+    BSTAMP(stamp++);
+    for (int bag = 0; bag < B; ++bag) {
+        const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
+        const int niter = (ntiles + 1) >> 1;
+        f32x4 acc[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float M = -INFINITY, lsum = 0.f;
+
+        for (int it = 0; it < niter; ++it) {
+            const int tile = 2 * it + rg;
+            const bool have = tile < ntiles;  // wave-uniform
+            const int slot = kown & 1;
+            const unsigned char* xs = ring + slot * kSlot;
+            const int row0 = tile * kTile;
+            f32x4 S[2], Nd[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Nd[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (have) {
+                int nb, nt;
+                next_of(bag, tile, nb, nt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
+                if (nb < B) {
+                    issue_tile(nb, nt, slot ^ 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this tile landed; the next 8 pieces stay in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                bf16x8 xa[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        xa[h][kk] = *reinterpret_cast<const bf16x8_ma*>(xs + bswz(16 * h + i16, kk * 64 + g * 16));
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 Sb[2];
+                Sb[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Sb[1] = Sb[0];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        S[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[0][kk], S[h], 0, 0, 0);
+                        Sb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[1][kk], Sb[h], 0, 0, 0);
+                        Nd[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], xa[h][kk], Nd[h], 0, 0, 0);
+                        Sb[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[h][kk], qf[2][kk], Sb[h], 0, 0, 0);
+                    }
+                S[0] += Sb[0];
+                S[1] += Sb[1];
+            }
+
+            VLSA_BAR();  // readers of the previous exchange are done
+            {
+                unsigned char* mine = exch + cw * kExchWave;
+                *reinterpret_cast<f32x4_ma*>(mine + (0 * 64 + lane) * 16) = S[0];
+                *reinterpret_cast<f32x4_ma*>(mine + (1 * 64 + lane) * 16) = S[1];
+                if (g == (i16 >> 2)) {
+                    const int r = i16 & 3;
+                    const float d0 = r == 0 ? Nd[0][0] : r == 1 ? Nd[0][1] : r == 2 ? Nd[0][2] : Nd[0][3];
+                    const float d1 = r == 0 ? Nd[1][0] : r == 1 ? Nd[1][1] : r == 2 ? Nd[1][2] : Nd[1][3];
+                    reinterpret_cast<float_ma*>(mine + 2048)[i16] = d0;
+                    reinterpret_cast<float_ma*>(mine + 2048)[16 + i16] = d1;
+                }
+            }
+            VLSA_BAR();
+            if (have) {
+                f32x4 T[2], R2[2];
+                {
+                    f32x4 tv[2][4], rv[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) {
+                            const unsigned char* o = exch + ww * kExchWave;
+                            tv[h][ww] = *reinterpret_cast<const f32x4_ma*>(o + (h * 64 + lane) * 16);
+                            rv[h][ww] = *reinterpret_cast<const f32x4_ma*>(o + 2048 + (16 * h + 4 * g) * 4);
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        T[h] = (tv[h][0] + tv[h][1]) + (tv[h][2] + tv[h][3]);
+                        R2[h] = (rv[h][0] + rv[h][1]) + (rv[h][2] + rv[h][3]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[h][r] *= fminf(__builtin_amdgcn_rsqf(R2[h][r]), 1e12f);
+                if (row0 + kTile > nrows) {  // ragged last tile of this workgroup's range
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (row0 + 16 * h + 4 * g + r >= nrows) T[h][r] = -INFINITY;
+                }
+                const float tmax = fmaxf(fmaxf(fmaxf(T[0][0], T[0][1]), fmaxf(T[0][2], T[0][3])),
+                                         fmaxf(fmaxf(T[1][0], T[1][1]), fmaxf(T[1][2], T[1][3])));
+                if (__builtin_amdgcn_ballot_w64(tmax > M + kThr) != 0) {
+                    const float newM = fmaxf(M, quad_rows_max(tmax));
+                    const float f = (M == -INFINITY) ? 0.f : fast_exp2(M - newM);
+                    lsum *= f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float fr = __shfl(f, 4 * g + r);
+#pragma unroll
+                        for (int ct = 0; ct < 8; ++ct) acc[ct][r] *= fr;
+                    }
+                    M = newM;
+                }
+                bf16x8 ahi, alo;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wv = fast_exp2(T[h][r] - M);
+                        lsum += wv;
+                        const __bf16 hi = (__bf16)wv;
+                        ahi[4 * h + r] = hi;
+                        alo[4 * h + r] = (__bf16)(wv - (float)hi);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    const int c_off = ct * 32 + (i16 & 3) * 8;
+                    const int rr = 4 * g + (i16 >> 2);
+                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xs + bswz(rr, c_off)));
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xs + bswz(16 + rr, c_off)));
+                    const bf16x8 bh = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bh, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc[ct], 0, 0, 0);
+                }
+                ++kown;
+            }
+            BSTAMP(stamp++);
+        }
+        k0 += (ntiles + 1) >> 1;
+        k1 += ntiles >> 1;
+
+        // ---- bag epilogue.  Waves (0, cw) and (1, cw) each park the half of their accumulators the partner merges in
+        // their just-consumed ring slot (the other slot holds the next bag's first tile, already in flight); after ONE
+        // barrier wave (rg, cw) merges column tiles [4 rg, 4 rg + 4) of quarter cw from both, transposes them through
+        // the other half of its own slot and stores 16-byte row pieces.  A second barrier frees the slots for the ring.
+        lsum = quad_rows_sum(lsum);
+        const int kmine = rg == 0 ? k0 : k1, kother = rg == 0 ? k1 : k0;
+        unsigned char* myslot = ring + (((kmine - 1) & 1) * kSlot);
+        const unsigned char* otherslot = smem + ((rg ^ 1) * 4 + cw) * kWaveRing + (((kother - 1) & 1) * kSlot);
+        float_ma* mlw = reinterpret_cast<float_ma*>(smem + kMlOff);  // [8 waves][2][16]: (M, l) of every wave
+        // first 4 KiB of my free slot: the 4 column tiles the partner wave merges; last 4 KiB: my transpose tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_ma*>(myslot + (j * 64 + lane) * 16) = rg == 0 ? acc[4 + j] : acc[j];
+        if (g == 0) {
+            mlw[w * 32 + i16] = M;
+            mlw[w * 32 + 16 + i16] = lsum;
+        }
+        VLSA_BAR();
+        {
+            const int wo = (rg ^ 1) * 4 + cw;
+            const float Mo = mlw[wo * 32 + i16], lo = mlw[wo * 32 + 16 + i16];
+            const float Mn = fmaxf(M, Mo);
+            const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
+            const float fo = (Mo == -INFINITY) ? 0.f : fast_exp2(Mo - Mn);
+            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
+            if (w == 0 && g == 0 && i16 < P) {
+                pm[slotg * kPStride + i16] = Mn;
+                pl[slotg * kPStride + i16] = lsum * fm + lo * fo;
+            }
+            float am[4], ao[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                am[r] = __shfl(fm, 4 * g + r);
+                ao[r] = __shfl(fo, 4 * g + r);
+            }
+            // merged [16 p][64 c] tile -> tail half of my own slot ([ct >= 4] region is free once read below)
+            f32x4 oth[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oth[j] = *reinterpret_cast<const f32x4_ma*>(otherslot + (j * 64 + lane) * 16);
+            float_ma* tp = reinterpret_cast<float_ma*>(myslot + 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 mine = rg == 0 ? acc[j] : acc[4 + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[(4 * g + r) * 64 + j * 16 + i16] = mine[r] * am[r] + oth[j][r] * ao[r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float* dstp = pacc + slotg * P * D + cw * 128 + rg * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = 4 * k + (lane >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4_ma*>(reinterpret_cast<unsigned char*>(tp) + (p * 64 + (lane & 15) * 4) * 4);
+                if (p < P) *reinterpret_cast<f32x4*>(dstp + (size_t)p * D) = v;
+            }
+        }
+        VLSA_BAR();  // lent slots and the transpose area are free again
+        BSTAMP(stamp++);
+    }
+}
+#ifdef VLSA_TIMING
+extern "C" __global__ void k_dummy_batch_dbg() {}
+#endif
+
+// ---- batched merge: grid (D/64, P, B); explicit strides (in floats) so it serves both the local fold of workgroup
+// partials and the fold of all-gathered per-rank records (see vlsa_vlfan_merge_batch_strided in vlsa_hip.h) ----------
+struct MergeStrides {
+    int64_t sm, sl, sa;  // between consecutive partials of one bag
+    int64_t bm, bl, ba;  // between bags, inputs
+    int64_t om, ol, oo;  // between bags, outputs
+};
+
+__global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                            const float* __restrict__ pacc, int G, int P, int D,
+                                                            int normalise, float* __restrict__ m2, float* __restrict__ l,
+                                                            float* __restrict__ out, MergeStrides st) {
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
+    __shared__ float sl[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = blockIdx.y, c0 = blockIdx.x * 64, bag = blockIdx.z;
+    pm += (size_t)bag * st.bm;
+    pl += (size_t)bag * st.bl;
+    pacc += (size_t)bag * st.ba;
+    const int c4 = tid & 15, gs = tid >> 4;
+    const int col = c0 + c4 * 4;
+    constexpr int U = 16;
+    float mx = -INFINITY;
+    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * st.sm + p]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = 0.f;
+    for (int g0 = gs; g0 < G; g0 += 16 * U) {
+        float mg[U], lg[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gI = g0 + 16 * u;
+            const bool ok = gI < G;
+            mg[u] = ok ? pm[(size_t)gI * st.sm + p] : -INFINITY;
+            lg[u] = ok ? pl[(size_t)gI * st.sl + p] : 0.f;
+            v[u] = ok ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * st.sa + (size_t)p * D + col)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float f = (mg[u] == -INFINITY) ? 0.f : fast_exp2(mg[u] - mx);
+            lt += lg[u] * f;
+            a.x += v[u].x * f; a.y += v[u].y * f; a.z += v[u].z * f; a.w += v[u].w * f;
+        }
+    }
+    sacc[gs][c4] = a;
+    if (c4 == 0) sl[gs] = lt;
+    __syncthreads();
+    if (tid < 16) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ls = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = sacc[k][tid];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            ls += sl[k];
+        }
+        if (normalise) {
+            const float inv = 1.f / ls;
+            s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)bag * st.oo + (size_t)p * D + c0 + tid * 4) = s;
+        if (tid == 0 && blockIdx.x == 0) {
+            m2[(size_t)bag * st.om + p] = mx;
+            l[(size_t)bag * st.ol + p] = ls;
+        }
+    }
+}
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                           const float* b, const float* That, int K, const float* logit_scale, unsigned int* counters,
+                           float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                           hipStream_t s);  // vlfan_tail.hip
+
+#ifdef VLSA_TIMING
+extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vlsa::vlsa_dbg_batch), sizeof(long long) * 64) == hipSuccess ? 0 : -3;
+}
+#endif
+
+extern "C" int vlsa_batch_max_bags(void) { return bt::kMaxBags; }
+
+extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
+    const size_t G = 256;
+    return ((size_t)B * G * kPStride * 2 + (size_t)B * G * P * D) * sizeof(float) + (size_t)B * 64;
+}
+
+extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                        void* workspace, void* stream) {
+    if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
+    if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
+    if (D != 512 || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
+    const int G = 256;
+    float* pm = static_cast<float*>(workspace);
+    float* pl = pm + (size_t)B * G * kPStride;
+    float* pacc = pl + (size_t)B * G * kPStride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bt::kLdsBytes);
+        attr_set = true;
+    }
+    const QPrepLayout L(D);
+    const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
+    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(G), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
+                       static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                        int pool_mode, const float* pool_w, const float* W, const float* b,
+                                        const float* That, int K, const float* logit_scale, void* workspace, float* m2,
+                                        float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
+                                        float* logits, float* incidence, void* stream) {
+    if (!That || !logit_scale || !m2 || !l || !out || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
+    if (K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    const int rc = vlsa_vlfan_partial_batch(bag_desc, B, x_dtype, D, qprep, P, workspace, stream);
+    if (rc != VLSA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = 256;
+    float* pm = static_cast<float*>(workspace);
+    float* pl = pm + (size_t)B * G * kPStride;
+    float* pacc = pl + (size_t)B * G * kPStride;
+    unsigned int* counters = reinterpret_cast<unsigned int*>(pacc + (size_t)B * G * P * D);
+    const MergeStrides st{kPStride, kPStride, (int64_t)P * D, (int64_t)G * kPStride, (int64_t)G * kPStride,
+                          (int64_t)G * P * D, kPStride, kPStride, (int64_t)P * D};
+    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3(D / 64, P, B), dim3(256), 0, s, pm, pl, pacc, G, P, D, 1, m2, l, out, st);
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    return vlsa_launch_head_batch(out, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, counters, pooled, v, vhat, vnorm,
+                                  logits, incidence, s);
+}
+
+extern "C" int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
+                                              int normalise, const int64_t* strides9, float* m2, float* l, float* out,
+                                              void* stream) {
+    if (!pm || !pl || !pacc || !strides9 || !m2 || !l || !out) return VLSA_EINVAL;
+    if (B < 1 || G < 1 || P < 1 || P > VLSA_MAX_P || D < 64 || (D % 64) != 0 || D > VLSA_MAX_D) return VLSA_EINVAL;
+    MergeStrides st{strides9[0], strides9[1], strides9[2], strides9[3], strides9[4], strides9[5], strides9[6], strides9[7], strides9[8]};
+    if ((st.sa % 4) || (st.ba % 4) || (st.oo % 4) || (reinterpret_cast<uintptr_t>(pacc) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return VLSA_EINVAL;
+    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3(D / 64, P, B), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D, normalise,
+                       m2, l, out, st);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                       const float* b, const float* That, int K, const float* logit_scale, void* counters,
+                                       float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                                       void* stream) {
+    if (!rows || !That || !logit_scale || !counters || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
+    if (B < 1 || P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D <= 0 || D > VLSA_MAX_D || (D % 4) != 0) return VLSA_EINVAL;
+    return vlsa_launch_head_batch(rows, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, static_cast<unsigned int*>(counters),
+                                  pooled, v, vhat, vnorm, logits, incidence, (hipStream_t)stream);
+}

@@ -149,6 +149,17 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     __shared__ float red[4];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {   // batched launch: blockIdx.y selects the bag; every per-bag pointer is advanced here
+        const int bag = blockIdx.y;
+        rows += (size_t)bag * P * D;
+        counter += bag;
+        pooled += (size_t)bag * D;
+        v += (size_t)bag * D;
+        vhat += (size_t)bag * D;
+        vnorm += bag;
+        logits += (size_t)bag * K;
+        if (incidence != nullptr) incidence += (size_t)bag * K;
+    }
 
     // W rows of this workgroup first: their loads are in flight while the pooled vector is being formed
     float4 wq[2][VLSA_MAX_D / 256];
@@ -353,6 +364,18 @@ extern "C" int vlsa_head_forward(const float* rows, int P, int D, int pool_mode,
     const int NB = W ? (D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock : 1;
     hipLaunchKernelGGL(k_head, dim3(NB), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
                        static_cast<unsigned int*>(workspace), pooled, v, vhat, vnorm, logits, incidence, NB);
+    return launch_status();
+}
+
+int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                           const float* b, const float* That, int K, const float* logit_scale, unsigned int* counters,
+                           float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                           hipStream_t s) {
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_GIVEN) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    const int NB = W ? (D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock : 1;
+    hipLaunchKernelGGL(k_head, dim3(NB, B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
+                       counters, pooled, v, vhat, vnorm, logits, incidence, NB);
     return launch_status();
 }
 

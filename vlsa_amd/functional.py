@@ -439,3 +439,65 @@ def class_cosines(X: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
         _, _, _, sc = vlfan_partial(X, qp, want_scores=True)
         outs.append(sc)
     return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+
+class VlfanBatchPlan:
+    """B bags per launch (bf16 rows, D = 512): one persistent streaming kernel over all bags + batched merge + batched
+    head = 3 launches per batch (plus the shared query / text preparation).  Bags may have different N.
+
+    ``set_bags`` writes the device-side descriptor table (pointer, N, row stride per bag); ``run`` enqueues the batch.
+    Outputs are [B, ...] tensors owned by the plan (logits [B, K], incidence, vhat [B, D], out [B, P, D], m2/l [B, 16]).
+    """
+
+    def __init__(self, B: int, P: int, K: int, device, D: int = 512, gated: bool = False, pool: str = "mean",
+                 identity_head: bool = False, coattn_scale: float = COATTN_SCALE):
+        lib = nat.load()
+        if not (1 <= B <= lib.vlsa_batch_max_bags()):
+            raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_max_bags()}]")
+        self.lib, self.B, self.D, self.P, self.K = lib, B, D, P, K
+        self.gated, self.pool, self.identity_head, self.scale = gated, _POOL_CODES[pool], identity_head, float(coattn_scale)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        self.desc_host = torch.zeros(B, 3, dtype=torch.int64).pin_memory() if torch.cuda.is_available() else torch.zeros(B, 3, dtype=torch.int64)
+        self.desc = torch.zeros(B, 3, dtype=torch.int64, device=device)
+        self.ws = torch.zeros(lib.vlsa_batch_workspace_bytes(B, P, D), dtype=torch.uint8, device=device)
+        self.qprep = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=device)
+        self.That, self.tnorm = f(K, D), f(K)
+        self.m2, self.l, self.out = f(B, nat.P_STRIDE), f(B, nat.P_STRIDE), f(B, P, D)
+        self.pooled, self.v, self.vhat, self.vnorm = f(B, D), f(B, D), f(B, D), f(B)
+        self.logits, self.incidence = f(B, K), f(B, K)
+        self._bags = None
+
+    def set_bags(self, bags):
+        """bags: list of B device tensors [N_i, 512] bf16 (unit inner stride, 16-byte aligned rows). Kept alive by the plan."""
+        if len(bags) != self.B:
+            raise ValueError(f"expected {self.B} bags, got {len(bags)}")
+        keep = []
+        for i, x in enumerate(bags):
+            _need_gpu(x)
+            x = _bag2d(x)
+            if x.dtype != torch.bfloat16 or x.shape[1] != self.D:
+                raise VlsaNativeError("the batched path takes bf16 bags with D == 512")
+            keep.append(x)
+            self.desc_host[i, 0] = x.data_ptr()
+            self.desc_host[i, 1] = x.shape[0]
+            self.desc_host[i, 2] = x.stride(0) if x.shape[0] > 0 else self.D
+        self._bags = keep
+        self.desc.copy_(self.desc_host, non_blocking=True)
+
+    def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
+        lib, s, c = self.lib, _stream(), nat.check
+        nq = self.P + 1 if self.gated else self.P
+        c(lib.vlsa_prepare_queries(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), s), "prepare_queries")
+        c(lib.vlsa_normalize_rows(_p(T), self.K, self.D, _p(self.That), _p(self.tnorm), s), "normalize_rows")
+        c(lib.vlsa_vlfan_forward_batch(_p(self.desc), self.B, nat.DT_BF16, self.D, _p(self.qprep), self.P, self.pool,
+                                       _p(pool_w), None if self.identity_head else _p(W),
+                                       None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
+                                       _p(self.ws), _p(self.m2), _p(self.l), _p(self.out), _p(self.pooled), _p(self.v),
+                                       _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence), s),
+          "vlfan_forward_batch")
+        return self.logits
+
+    def run_partial_only(self):
+        """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
+        nat.check(self.lib.vlsa_vlfan_partial_batch(_p(self.desc), self.B, nat.DT_BF16, self.D, _p(self.qprep), self.P,
+                                                    _p(self.ws), _stream()), "vlfan_partial_batch")

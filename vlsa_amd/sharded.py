@@ -148,3 +148,98 @@ def sharded_vlfan_forward(X_local: torch.Tensor, Q: torch.Tensor, gated: bool = 
                                   gathered[:, REC_HDR:].reshape(world, P, D).contiguous(), normalise=True)
     A = VF.attn_normalise(scores, m2g, lg) if want_attn else None
     return out, A
+
+
+class ShardedVlfanBatchPlan:
+    """B patch-sharded bags per launch: the persistent streaming kernel walks this rank's shard of every bag, the
+    workgroup partials are folded into B compact records, ONE all-gather moves ``world x B x 24.7 KB``, then a strided
+    merge over the ranks and the batched head (replicated).  The collective of batch i overlaps the streaming kernel of
+    batch i+1 (side stream); ``finish()`` drains.  Results (``logits [B, K]`` ...) are identical on every rank."""
+
+    G = 256
+
+    def __init__(self, B: int, P: int, K: int, device, dist_module=None, group=None, D: int = 512, gated: bool = False,
+                 pool: str = "mean", identity_head: bool = False, pipeline: bool = True):
+        import torch.distributed as dist
+        self.dist = dist_module or dist
+        self.group = group
+        self.world = self.dist.get_world_size(group)
+        self.local = VF.VlfanBatchPlan(B, P, K, device, D=D, gated=gated, pool=pool, identity_head=identity_head)
+        self.B, self.P, self.K, self.D = B, P, K, D
+        self.rf = record_floats(P, D)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        self.rec = [f(B, self.rf), f(B, self.rf)]
+        self.gathered = [f(self.world, B, self.rf), f(self.world, B, self.rf)]
+        self.comm_stream = torch.cuda.Stream(device=device) if pipeline else None
+        self.done_local = [torch.cuda.Event(), torch.cuda.Event()]
+        self.done_comm = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pipeline = pipeline
+        self._pending = None
+        self._i = 0
+        self.lib = nat.load()
+        G, rf = self.G, self.rf
+        i64 = ctypes.c_int64 * 9
+        self._st_local = i64(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D, rf, rf, rf)
+        self._st_global = i64(B * rf, B * rf, B * rf, rf, rf, rf, nat.P_STRIDE, nat.P_STRIDE, P * D)
+
+    def set_bags(self, local_shards):
+        self.local.set_bags(local_shards)
+
+    def _local(self, Q, slot):
+        pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
+        nq = self.P + 1 if pl_.gated else self.P
+        c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
+        c(lib.vlsa_vlfan_partial_batch(p(pl_.desc), self.B, nat.DT_BF16, self.D, p(pl_.qprep), self.P, p(pl_.ws), s),
+          "vlfan_partial_batch")
+        base = pl_.ws.data_ptr()
+        n_ml = self.B * self.G * nat.P_STRIDE * 4
+        rec = self.rec[slot].data_ptr()
+        c(lib.vlsa_vlfan_merge_batch_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + n_ml),
+                                             ctypes.c_void_p(base + 2 * n_ml), self.B, self.G, self.P, self.D, 0,
+                                             self._st_local, ctypes.c_void_p(rec), ctypes.c_void_p(rec + 4 * nat.P_STRIDE),
+                                             ctypes.c_void_p(rec + 4 * REC_HDR), s), "merge_batch(local)")
+
+    def _tail(self, slot, T, ls, W, b, pool_w):
+        pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
+        g = self.gathered[slot].data_ptr()
+        c(lib.vlsa_vlfan_merge_batch_strided(ctypes.c_void_p(g), ctypes.c_void_p(g + 4 * nat.P_STRIDE),
+                                             ctypes.c_void_p(g + 4 * REC_HDR), self.B, self.world, self.P, self.D, 1,
+                                             self._st_global, p(pl_.m2), p(pl_.l), p(pl_.out), s), "merge_batch(global)")
+        c(lib.vlsa_normalize_rows(p(T), self.K, self.D, p(pl_.That), p(pl_.tnorm), s), "normalize_rows")
+        counters = ctypes.c_void_p(pl_.ws.data_ptr() + pl_.ws.numel() - self.B * 64)
+        c(lib.vlsa_head_forward_batch(p(pl_.out), self.B, self.P, self.D, pl_.pool, p(pool_w),
+                                      None if pl_.identity_head else p(W), None if pl_.identity_head else p(b),
+                                      p(pl_.That), self.K, p(ls), counters, p(pl_.pooled), p(pl_.v), p(pl_.vhat),
+                                      p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s), "head_forward_batch")
+
+    def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
+        slot = self._i & 1
+        self._i += 1
+        cur = torch.cuda.current_stream()
+        if self.pipeline:
+            cur.wait_event(self.done_comm[slot])
+        self._local(Q, slot)
+        if not self.pipeline:
+            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            self._tail(slot, T, logit_scale, W, b, pool_w)
+            return self.local.logits
+        self.done_local[slot].record(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.done_local[slot])
+            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            self.done_comm[slot].record(self.comm_stream)
+        if self._pending is not None:
+            self._drain()
+        self._pending = (slot, T, logit_scale, W, b, pool_w)
+        return self.local.logits
+
+    def _drain(self):
+        slot, T, ls, W, b, pw = self._pending
+        torch.cuda.current_stream().wait_event(self.done_comm[slot])
+        self._tail(slot, T, ls, W, b, pw)
+        self._pending = None
+
+    def finish(self):
+        if self._pending is not None:
+            self._drain()
+        return self.local.logits
