@@ -13,7 +13,6 @@ for _ in range(3): plan.run(Q, T, ls, W, b)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 64)()
 raw.vlsa_debug_read_batch_cycles(buf)
-t = list(buf)
-d = [t[i] - t[i-1] for i in range(1, 48) if t[i] > 0]
-print("deltas (cycles) between stamps [iteration ... epilogue] block 3:", d)
-print("total", t[len(d)] - t[0])
+t = [x for x in list(buf) if x > 0]
+print("deltas (cycles) block 3:", [t[i] - t[i-1] for i in range(1, len(t))])
+print("total", t[-1] - t[0], "stamps", len(t))

@@ -120,14 +120,21 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     const int lr = lane >> 4;
     const int chunk_e = ((lane & 15) ^ (lr << 1)) << 4, chunk_o = ((lane & 15) ^ (lr << 1) ^ 8) << 4;
     // LDS-DMA of one 32-row tile of `bag` into ring slot `slot` (see k_vlfan_partial_dma for the layout)
+    // descriptor of the bag the DMA currently streams from, cached in SGPRs (reloaded from the table on a bag change)
+    int ib = -1, ildb = 0, voff_e = 0, voff_o = 0;
+    i32x4 rsrc = {0, 0, 0, 0x00020000};
     auto issue_tile = [&](int bag, int tile, int slot) {
-        i32x4 rsrc;
-        rsrc[0] = tab_get(bag, 0);
-        rsrc[1] = tab_get(bag, 1);
-        rsrc[2] = tab_get(bag, 2);
-        rsrc[3] = 0x00020000;
-        const int ldb = tab_get(bag, 3);
-        const int voff_e = lr * ldb + cw * 256 + chunk_e, voff_o = lr * ldb + cw * 256 + chunk_o;
+        if (bag != ib) {
+            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * 32);
+            rsrc[0] = __builtin_amdgcn_readfirstlane(e.x);
+            rsrc[1] = __builtin_amdgcn_readfirstlane(e.y);
+            rsrc[2] = __builtin_amdgcn_readfirstlane(e.z);
+            ildb = __builtin_amdgcn_readfirstlane(e.w);
+            voff_e = lr * ildb + cw * 256 + chunk_e;
+            voff_o = lr * ildb + cw * 256 + chunk_o;
+            ib = bag;
+        }
+        const int ldb = ildb;
         const int sbase = tile * kTile * ldb;
         const unsigned int dst = ring_lds + slot * kSlot;
         unsigned int keep;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %1\n\t"
                 "s_nop 0\n\t"
-                "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
                 : "s"(dst + i * 1024), "v"((i & 1) ? voff_o : voff_e), "s"(rsrc), "s"(sbase + i * 4 * ldb)
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         }
     };
     // this row group's next own tile after (bag, tile): same bag if it has one, else the first of a later bag
-    auto next_of = [&](int bag, int tile, int& nb, int& nt) {
-        if (tile + 2 < tab_get(bag, 5)) {
+    auto next_of = [&](int bag, int tile, int ntiles_bag, int& nb, int& nt) {
+        if (tile + 2 < ntiles_bag) {
             nb = bag;
             nt = tile + 2;
             return;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
             }
             if (have) {
                 int nb, nt;
-                next_of(bag, tile, nb, nt);
+                next_of(bag, tile, ntiles, nb, nt);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
                 if (nb < B) {
                     issue_tile(nb, nt, slot ^ 1);
@@ -323,25 +330,29 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         VLSA_BAR();
         {
             const int wo = (rg ^ 1) * 4 + cw;
+            // one round of LDS reads: both waves' reference maxima for the 4 queries of my accumulator rows, the
+            // partner's normaliser, and the partner's 4 parked column tiles
+            const f32x4 Mm4 = *reinterpret_cast<const f32x4_ma*>(&mlw[w * 32 + 4 * g]);
+            const f32x4 Mo4 = *reinterpret_cast<const f32x4_ma*>(&mlw[wo * 32 + 4 * g]);
             const float Mo = mlw[wo * 32 + i16], lo = mlw[wo * 32 + 16 + i16];
-            const float Mn = fmaxf(M, Mo);
-            const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
-            const float fo = (Mo == -INFINITY) ? 0.f : fast_exp2(Mo - Mn);
-            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
-            if (w == 0 && g == 0 && i16 < P) {
-                pm[slotg * kPStride + i16] = Mn;
-                pl[slotg * kPStride + i16] = lsum * fm + lo * fo;
-            }
-            float am[4], ao[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                am[r] = __shfl(fm, 4 * g + r);
-                ao[r] = __shfl(fo, 4 * g + r);
-            }
-            // merged [16 p][64 c] tile -> tail half of my own slot ([ct >= 4] region is free once read below)
             f32x4 oth[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) oth[j] = *reinterpret_cast<const f32x4_ma*>(otherslot + (j * 64 + lane) * 16);
+            float am[4], ao[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mn = fmaxf(Mm4[r], Mo4[r]);
+                am[r] = (Mm4[r] == -INFINITY) ? 0.f : fast_exp2(Mm4[r] - mn);
+                ao[r] = (Mo4[r] == -INFINITY) ? 0.f : fast_exp2(Mo4[r] - mn);
+            }
+            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
+            if (w == 0 && g == 0 && i16 < P) {
+                const float Mn = fmaxf(M, Mo);
+                const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
+                const float fo = (Mo == -INFINITY) ? 0.f : fast_exp2(Mo - Mn);
+                pm[slotg * kPStride + i16] = Mn;
+                pl[slotg * kPStride + i16] = lsum * fm + lo * fo;
+            }
             float_ma* tp = reinterpret_cast<float_ma*>(myslot + 4096);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
