@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=640)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--bags-per-launch", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -117,20 +118,33 @@ def main():
         pl.set_bags(bags[:nb])
         return pl
 
-    plans = {BPL: make_plan(BPL)}
+    # Independent launches alternate between NS streams (each with its own plan = its own output / workspace buffers):
+    # the small merge / head / prepare kernels of one launch overlap the streaming kernel of the next.
+    NS = max(1, a.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(NS)]
+    plans = {BPL: [make_plan(BPL) for _ in range(NS)]}
 
     def run_steps(n_steps):
         """exactly n_steps bags: full launches of BPL bags + one smaller launch for the remainder"""
-        for _ in range(n_steps // BPL):
-            plans[BPL].run(Q, T, ls, W, b)
+        cur = torch.cuda.current_stream()
+        for st in streams:
+            st.wait_stream(cur)
+        for i in range(n_steps // BPL):
+            with torch.cuda.stream(streams[i % NS]):
+                plans[BPL][i % NS].run(Q, T, ls, W, b)
         rem = n_steps % BPL
         if rem:
             if rem not in plans:
-                plans[rem] = make_plan(rem)
-            plans[rem].run(Q, T, ls, W, b)
-        for pl in plans.values():
-            if hasattr(pl, "finish"):
-                pl.finish()
+                plans[rem] = [make_plan(rem)]
+            with torch.cuda.stream(streams[0]):
+                plans[rem][0].run(Q, T, ls, W, b)
+        for i, pls in enumerate(plans.values()):
+            for j, pl in enumerate(pls):
+                if hasattr(pl, "finish"):
+                    with torch.cuda.stream(streams[j % NS]):
+                        pl.finish()
+        for st in streams:
+            cur.wait_stream(st)
 
     def sync():
         if dist is not None:
@@ -154,7 +168,7 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around each launch on the launching stream ----------------
     roof = None
     if rank == 0:
-        base = plans[BPL].local if hasattr(plans[BPL], "local") else plans[BPL]
+        base = plans[BPL][0].local if hasattr(plans[BPL][0], "local") else plans[BPL][0]
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
         for _ in range(3):
             base.run_partial_only()
@@ -192,7 +206,7 @@ def main():
             "config": {"workload": "configs[2]: synthetic 50k x 512 bf16 bag per GPU, P=12 queries, K=4 rank prompts, "
                                    "mean pooling + Linear(512,512) head; N GPUs = bags of N*50k patches, patch-sharded",
                        "rows_per_gpu": N_PER_GPU, "D": D, "P": P, "K": K, "bags_per_launch": BPL,
-                       "distinct_bags": BPL, "launch": "eager, 5 launches per 32 bags"},
+                       "distinct_bags": BPL, "launch": f"eager, 5 kernel launches per {BPL} bags, launches alternate over {NS} streams"},
             "roofline": roof,
         }
         if not a.no_cpu_baseline:

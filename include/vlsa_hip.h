@@ -150,6 +150,7 @@ typedef struct vlsa_bag_desc {
 } vlsa_bag_desc;
 
 int vlsa_batch_max_bags(void);                                /* B <= this (64) */
+int vlsa_batch_partials_per_bag(int B);                       /* partial records per bag the batch kernel leaves (256/S) */
 size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE after allocation; calls leave it reusable */
 
 /*

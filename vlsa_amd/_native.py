@@ -51,6 +51,7 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
     "vlsa_batch_max_bags": (c_int, []),
+    "vlsa_batch_partials_per_bag": (c_int, [c_int]),
     "vlsa_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlsa_vlfan_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vlsa_vlfan_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

@@ -60,10 +60,13 @@ __device__ __forceinline__ int bswz(int row, int byte_off) { return row * 256 + 
         asm volatile("" ::: "memory");                       \
     } while (0)
 
+// S = number of workgroup groups: bag t is streamed by the Gb = G / S workgroups of group t % S only, so S bags are in
+// flight at once, every workgroup sees S times more rows per bag (fewer bag epilogues, better tile quantisation) and a
+// bag leaves Gb instead of G partials behind.
 __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDesc* __restrict__ bags, int B,
                                                                      const __bf16* __restrict__ qsplit, int P,
                                                                      float* __restrict__ pm, float* __restrict__ pl,
-                                                                     float* __restrict__ pacc) {
+                                                                     float* __restrict__ pacc, int S) {
     using namespace bt;
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = w >> 2, cw = w & 3;
     const int g = lane >> 4, i16 = lane & 15;
-    const int b = blockIdx.x, G = gridDim.x;
+    const int Gb = gridDim.x / S;            // workgroups (and partials) per bag
+    const int grp = blockIdx.x / Gb, b = blockIdx.x % Gb, G = Gb;
 
     unsigned char* ring = smem + w * kWaveRing;
     unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
@@ -84,12 +88,13 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         // unit rotates with the bag index so that the extra iterations even out over the batch
         const unsigned long long units = (unsigned long long)((d.N + 63) >> 6);
         const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
-        const unsigned int vb = (unsigned int)((b + tid * 37) % G);  // virtual workgroup index for this bag
+        const unsigned int vb = (unsigned int)((b + (tid / S) * 37) % G);  // virtual workgroup index for this bag
+        const bool mine = (tid % S) == grp;
         const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
         const long long rbeg = (long long)(ubeg << 6);
         long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 6);
         if (rend > d.N) rend = d.N;
-        const int nrows = rend > rbeg ? (int)(rend - rbeg) : 0;
+        const int nrows = (mine && rend > rbeg) ? (int)(rend - rbeg) : 0;
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 2ull;
         int_ma* e = tab + tid * 8;
         e[0] = (int)(unsigned int)addr;
@@ -99,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         e[4] = nrows;
         e[5] = (nrows + kTile - 1) / kTile;
         e[6] = (int)vb;  // partial slot of this workgroup for this bag
+        e[7] = mine ? 1 : 0;
     }
     // query B-fragments (scale * log2 e folded in): lane holds Q[p = i16][128 cw + 32 kk + 8 g .. +8]
     bf16x8 qf[3][4];
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     int stamp = 0;
     BSTAMP(stamp++);
     for (int bag = 0; bag < B; ++bag) {
+        if (tab_get(bag, 7) == 0) continue;  // another group's bag (workgroup-uniform)
         const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
         const int niter = (ntiles + 1) >> 1;
         f32x4 acc[8];
@@ -389,16 +396,20 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restri
                                                             const float* __restrict__ pacc, int G, int P, int D,
                                                             int normalise, float* __restrict__ m2, float* __restrict__ l,
                                                             float* __restrict__ out, MergeStrides st) {
+    // workgroup (cchunk, p, bag): 128 threads x float4 = 512 columns of query p, 2 partial subsets (even / odd g);
+    // every thread keeps up to 16 accumulator pieces in flight per pass.
     __shared__ float red[4];
-    __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
-    __shared__ float sl[16];
+    __shared__ __attribute__((aligned(16))) float4 sacc[128];
+    __shared__ float sl;
+    __builtin_amdgcn_s_setprio(3);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = blockIdx.y, c0 = blockIdx.x * 64, bag = blockIdx.z;
+    const int p = blockIdx.y, c0 = blockIdx.x * 512, bag = blockIdx.z;
     pm += (size_t)bag * st.bm;
     pl += (size_t)bag * st.bl;
     pacc += (size_t)bag * st.ba;
-    const int c4 = tid & 15, gs = tid >> 4;
+    const int c4 = tid & 127, gs = tid >> 7;
     const int col = c0 + c4 * 4;
+    const bool incol = col < D;
     constexpr int U = 16;
     float mx = -INFINITY;
     for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * st.sm + p]);
@@ -408,17 +419,17 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restri
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     float lt = 0.f;
-    for (int g0 = gs; g0 < G; g0 += 16 * U) {
+    for (int g0 = gs; g0 < G; g0 += 2 * U) {
         float mg[U], lg[U];
         float4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int gI = g0 + 16 * u;
+            const int gI = g0 + 2 * u;
             const bool ok = gI < G;
             mg[u] = ok ? pm[(size_t)gI * st.sm + p] : -INFINITY;
             lg[u] = ok ? pl[(size_t)gI * st.sl + p] : 0.f;
-            v[u] = ok ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * st.sa + (size_t)p * D + col)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = (ok && incol) ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * st.sa + (size_t)p * D + col)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -427,24 +438,21 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restri
             a.x += v[u].x * f; a.y += v[u].y * f; a.z += v[u].z * f; a.w += v[u].w * f;
         }
     }
-    sacc[gs][c4] = a;
-    if (c4 == 0) sl[gs] = lt;
+    if (gs == 1) {
+        sacc[c4] = a;
+        if (c4 == 0) sl = lt;
+    }
     __syncthreads();
-    if (tid < 16) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        float ls = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float4 v = sacc[k][tid];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            ls += sl[k];
-        }
+    if (gs == 0) {
+        const float4 o = sacc[c4];
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        const float ls = lt + sl;
         if (normalise) {
             const float inv = 1.f / ls;
-            s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+            a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
         }
-        *reinterpret_cast<float4*>(out + (size_t)bag * st.oo + (size_t)p * D + c0 + tid * 4) = s;
-        if (tid == 0 && blockIdx.x == 0) {
+        if (incol) *reinterpret_cast<float4*>(out + (size_t)bag * st.oo + (size_t)p * D + col) = a;
+        if (c4 == 0 && blockIdx.x == 0) {
             m2[(size_t)bag * st.om + p] = mx;
             l[(size_t)bag * st.ol + p] = ls;
         }
@@ -466,6 +474,10 @@ extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
 }
 #endif
 
+// bags streamed concurrently (each by 256 / S workgroups)
+static inline int batch_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
+extern "C" int vlsa_batch_partials_per_bag(int B) { return 256 / batch_groups(B); }
+
 extern "C" int vlsa_batch_max_bags(void) { return bt::kMaxBags; }
 
 extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
@@ -478,7 +490,8 @@ extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype
     if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
     if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
     if (D != 512 || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
-    const int G = 256;
+    const int S = batch_groups(B);
+    const int G = 256 / S;  // partials per bag
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;
@@ -489,8 +502,8 @@ extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype
     }
     const QPrepLayout L(D);
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
-    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(G), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
-                       static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc);
+    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(256), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
+                       static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
@@ -504,14 +517,15 @@ extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype
     const int rc = vlsa_vlfan_partial_batch(bag_desc, B, x_dtype, D, qprep, P, workspace, stream);
     if (rc != VLSA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int G = 256;
+    const int G = 256 / batch_groups(B);
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;
-    unsigned int* counters = reinterpret_cast<unsigned int*>(pacc + (size_t)B * G * P * D);
+    unsigned int* counters = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(workspace) +
+                                                             vlsa_batch_workspace_bytes(B, P, D) - (size_t)B * 64);
     const MergeStrides st{kPStride, kPStride, (int64_t)P * D, (int64_t)G * kPStride, (int64_t)G * kPStride,
                           (int64_t)G * P * D, kPStride, kPStride, (int64_t)P * D};
-    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3(D / 64, P, B), dim3(256), 0, s, pm, pl, pacc, G, P, D, 1, m2, l, out, st);
+    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3((D + 511) / 512, P, B), dim3(256), 0, s, pm, pl, pacc, G, P, D, 1, m2, l, out, st);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     return vlsa_launch_head_batch(out, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, counters, pooled, v, vhat, vnorm,
                                   logits, incidence, s);
@@ -521,12 +535,12 @@ extern "C" int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, 
                                               int normalise, const int64_t* strides9, float* m2, float* l, float* out,
                                               void* stream) {
     if (!pm || !pl || !pacc || !strides9 || !m2 || !l || !out) return VLSA_EINVAL;
-    if (B < 1 || G < 1 || P < 1 || P > VLSA_MAX_P || D < 64 || (D % 64) != 0 || D > VLSA_MAX_D) return VLSA_EINVAL;
+    if (B < 1 || G < 1 || P < 1 || P > VLSA_MAX_P || D < 4 || (D % 4) != 0 || D > VLSA_MAX_D) return VLSA_EINVAL;
     MergeStrides st{strides9[0], strides9[1], strides9[2], strides9[3], strides9[4], strides9[5], strides9[6], strides9[7], strides9[8]};
     if ((st.sa % 4) || (st.ba % 4) || (st.oo % 4) || (reinterpret_cast<uintptr_t>(pacc) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return VLSA_EINVAL;
-    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3(D / 64, P, B), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D, normalise,
-                       m2, l, out, st);
+    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3((D + 511) / 512, P, B), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D,
+                       normalise, m2, l, out, st);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 

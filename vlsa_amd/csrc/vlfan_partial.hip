@@ -23,6 +23,7 @@ namespace vlsa {
 __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict__ Q, int nq, int D, int gated,
                                                           float scale2, unsigned char* __restrict__ qprep) {
     __shared__ float red[4];
+    __builtin_amdgcn_s_setprio(3);
     const QPrepLayout L(D);
     float* qeff = reinterpret_cast<float*>(qprep + L.qeff);
     __bf16* qsplit = reinterpret_cast<__bf16*>(qprep + L.qsplit);

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_attn_normalise(const float* __restrict_
 __global__ __launch_bounds__(256) void k_normalize_rows(const float* __restrict__ in, int D, float* __restrict__ out,
                                                          float* __restrict__ norms) {
     __shared__ float red[4];
+    __builtin_amdgcn_s_setprio(3);
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* x = in + (size_t)r * D;
     float ss = 0.f;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     __shared__ float slog[VLSA_MAX_K];
     __shared__ float red[4];
     __shared__ int s_last;
+    __builtin_amdgcn_s_setprio(3);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {   // batched launch: blockIdx.y selects the bag; every per-bag pointer is advanced here
         const int bag = blockIdx.y;

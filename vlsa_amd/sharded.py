@@ -177,6 +177,7 @@ class ShardedVlfanBatchPlan:
         self._pending = None
         self._i = 0
         self.lib = nat.load()
+        self.G = int(self.lib.vlsa_batch_partials_per_bag(B))
         G, rf = self.G, self.rf
         i64 = ctypes.c_int64 * 9
         self._st_local = i64(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D, rf, rf, rf)
