@@ -188,3 +188,38 @@ def test_backward_full_size_vs_oracle_autograd():
         scale = Q.grad.abs().max().item()
         assert (out.detach().cpu() - ref["out"].detach()).abs().max().item() < 1e-4 * max(1.0, ref["out"].abs().max().item())
         assert (Qd.grad.cpu() - Q.grad).abs().max().item() < GRAD_RTOL * scale
+
+
+def test_interpretation_matches_reference_fixture():
+    """calc_text_img_similarity / prototype SHAP vs the reference's outputs (tests/golden/interpretation.npz)."""
+    from vlsa_amd.inference import calc_text_img_similarity, evaluate_prototype_shap_imp
+    fx = H.load_fixture("interpretation")
+    N, P, K, seed = 512, 8, 8, 401
+    X = cases.make_bag(N, seed, "clustered")
+    params = cases.make_params(P, K, seed + 1000)
+    case = ("interp", N, P, K, "mean", "default", False, "clustered", seed, False)
+    model, _ = build_vlsa(case, params, {})
+    for axis in ("V", "L"):
+        _, A, cottn, probs, probs2, dec_imp, shap = calc_text_img_similarity(model, X[None], axis_softmax=axis)
+        assert np.abs(A.numpy()[:, ::8] - fx[f"{axis}.A"]).max() < 1e-4
+        assert np.abs(cottn.numpy()[:, ::8] - fx[f"{axis}.cottn"]).max() < 1e-4
+        assert np.abs(probs.numpy() - fx[f"{axis}.probs"]).max() < 1e-4
+        assert np.abs(probs2.numpy() - fx[f"{axis}.probs2"]).max() < 1e-4
+        assert np.abs(dec_imp.numpy() - fx[f"{axis}.decoupled_imp"]).max() < 1e-4
+        assert np.abs(shap.numpy() - fx[f"{axis}.shap"]).max() < 2e-4
+    s = evaluate_prototype_shap_imp(fx["shap_in"], 56.31)
+    assert np.abs(s.numpy() - fx["shap_out"]).max() < 1e-5
+
+
+def test_forward_bags_matches_per_bag_forward():
+    (name, N, P, K, pooling, head, gated, kind, seed, grads) = cases.VLFAN_CASES[4]
+    X, params, pool = H.vlfan_case_inputs(cases.VLFAN_CASES[4])
+    model, _ = build_vlsa(cases.VLFAN_CASES[4], params, pool)
+    bags = [cases.make_bag(n, 500 + i).to(torch.bfloat16).cuda() for i, n in enumerate((2798, 100, 5000, 33, 1))]
+    with torch.no_grad():
+        logits, feats, txt = model.forward_bags(bags)
+        for i, xb in enumerate(bags):
+            l1, f1, t1 = model(xb[None])
+            assert (logits[i] - l1[0]).abs().max().item() < 2e-5
+            assert (feats[i] - f1[0]).abs().max().item() < 1e-5
+    assert logits.shape == (5, K)

@@ -95,3 +95,11 @@ def test_query_div_loss_cpu():
             enc.Q.copy_(torch.from_numpy(fx[f"{tag}.Q"]))
         assert abs(enc.query_div_loss(last_div=True).item() - float(fx[f"{tag}.loss_last_div"])) < 1e-6
         assert abs(enc.query_div_loss(last_div=False).item() - float(fx[f"{tag}.loss_all"])) < 1e-6
+
+
+def test_prototype_shap_matches_reference_fixture_cpu():
+    import numpy as np
+    from vlsa_amd.inference import evaluate_prototype_shap_imp
+    fx = dict(np.load(os.path.join(GOLDEN, "interpretation.npz")))
+    s = evaluate_prototype_shap_imp(fx["shap_in"], 56.31)
+    assert np.abs(s.numpy() - fx["shap_out"]).max() < 1e-5

@@ -1,0 +1,75 @@
+"""Interpretation utilities over a trained VLSA model -- counterparts of utils/model_inference.py:23-144.
+
+``calc_text_img_similarity`` decouples the prediction over the P text prototypes.  The reference re-encodes all N
+patches through the visual adapter (an [N,512]x[512,512] GEMM) and contracts with the attention weights
+(utils/model_inference.py:129-132); algebraically  A @ (((X W^T + b)/L) T^^T) = ((out W^T + b * sum_n A)/L) T^^T
+and sum_n A_pn = 1 (softmax over the patches), so the decoupled [P, K] similarities follow from the P aggregated rows
+``out`` the forward pass already produced: no second pass over the bag is needed.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import functional as VF
+from .deepmil import VLFAN
+
+
+def evaluate_prototype_shap_imp(decoupled_similarity, logit_scale, verbose=False):
+    """Exact Shapley values of the P prototypes for the survival risk sum_k (K - k) softmax(ls * mean_p sim)[k];
+    the empty coalition is worth 1 (utils/model_inference.py:23-79).  O(P 2^P) on the host, vectorised."""
+    sim = torch.as_tensor(decoupled_similarity, dtype=torch.float32).cpu()
+    num_p, num_cls = sim.shape
+    n_cases = 2 ** num_p
+    masks = ((torch.arange(n_cases)[:, None] >> torch.arange(num_p)[None, :]) & 1).float()  # [2^P, P]
+    cnt = masks.sum(dim=1)
+    mean_sim = (masks @ sim) / cnt.clamp_min(1)[:, None]
+    prob = F.softmax(float(logit_scale) * mean_sim, dim=1)
+    wts = (num_cls - torch.arange(0, num_cls)).float()
+    V = (prob * wts).sum(dim=1)
+    V[0] = 1.0
+    fac = [math.factorial(i) for i in range(num_p + 1)]
+    Wt = torch.tensor([fac[i] * fac[num_p - i - 1] / fac[num_p] for i in range(num_p)])
+    shap = torch.zeros(num_p)
+    idx = torch.arange(n_cases)
+    for i in range(num_p):
+        without = idx[((idx >> i) & 1) == 0]
+        shap[i] = (Wt[cnt[without].long()] * (V[without + (1 << i)] - V[without])).sum()
+    if verbose:
+        print("[SHAP] base", V[0].item(), "full", V[-1].item(), "sum", shap.sum().item())
+    return shap
+
+
+@torch.no_grad()
+def calc_text_img_similarity(model, X_feats, axis_softmax="V", verbose=False):
+    """Same return tuple as the reference: (None, A_softmax[P,N], cottn_score[P,N], probs[1,K], probs_2[1,K],
+    decoupled_imp[P,K], shap[P]) -- for a VLSA model whose encoder is a VLFAN with mean query pooling and a Linear head."""
+    assert axis_softmax in ["L", "V"]
+    model.eval()
+    enc = model.mil_encoder
+    assert isinstance(enc, VLFAN)
+    X = X_feats if X_feats.dim() == 3 else X_feats[None]
+    X = X.to(next(model.parameters()).device)
+    logit_scale = float(model.get_logit_scale())
+    That = F.normalize(model.forward_text_only(), dim=-1)
+    image_feature, cottn = enc(X, ret_with_attn=True)            # HIP forward with attention weights
+    cottn = cottn[0] if isinstance(cottn, tuple) else cottn
+    cottn = cottn.squeeze(0)                                      # [P, N]
+    if axis_softmax == "V":
+        A = cottn
+    else:  # softmax over the prototypes of the same scaled cosine scores: recover them from the patch-softmax weights
+        qp = VF.prepare_queries(enc.get_query(), enc.gated_query, float(enc.coattn_logit_scale.exp()))
+        _, _, _, scores = VF.vlfan_partial(X, qp, want_scores=True)  # log2-domain scaled scores
+        A = F.softmax(scores / 1.4426950408889634, dim=0)
+    L = image_feature.norm(dim=-1)
+    probs = F.softmax(logit_scale * (image_feature / L) @ That.t(), dim=-1)
+    # decoupled similarities from the aggregated rows (see module docstring)
+    out, _ = VF.vlfan_cross_attention(X, enc.get_query(), gated=enc.gated_query,
+                                      coattn_scale=float(enc.coattn_logit_scale.exp()))
+    dec = (enc.visual_adapter(out) / L) @ That.t()                # [P, K]
+    decoupled_imp = F.softmax(logit_scale * dec, dim=0)
+    probs_2 = F.softmax(logit_scale * dec.mean(dim=0, keepdim=True), dim=-1)
+    shap = evaluate_prototype_shap_imp(dec.cpu(), logit_scale, verbose=verbose)
+    return None, A.cpu(), cottn.cpu(), probs.cpu(), probs_2.cpu(), decoupled_imp.cpu(), shap

@@ -140,6 +140,46 @@ class VLSA(nn.Module):
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
         return logits, image_features, text_features
 
+    @torch.no_grad()
+    def forward_bags(self, bags):
+        """Inference over a list of independent bags (what the reference's eval loop does one bag at a time,
+        runner/vlsa_handler.py:315-345).  bf16 bags with D == 512 and a fusable VLFAN go through the persistent
+        multi-bag kernel, up to 64 bags per launch; anything else falls back to per-bag ``forward``.
+        Returns (logits [B, K], image_features [B, D], text_features [K, D])."""
+        enc = self.mil_encoder
+        spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
+        text_features = self.forward_text_only()
+        flat = [VF._bag2d(x) for x in bags]
+        ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 512
+                                                          and x.shape[0] > 0 for x in flat))
+        if not ok:
+            outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), outs[0][2]
+        mode, pw, W, b = spec
+        Q = enc.get_query().detach().float().contiguous()
+        P = Q.shape[0] - (1 if enc.gated_query else 0)
+        K = text_features.shape[0]
+        T = text_features.detach().float().contiguous()
+        ls = self.logit_scale.detach().float()
+        logits, feats, That = [], [], None
+        step = 32
+        for i in range(0, len(flat), step):
+            chunk = flat[i:i + step]
+            key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None)
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = VF.VlfanBatchPlan(len(chunk), P, K, chunk[0].device, gated=enc.gated_query, pool=mode,
+                                         identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()))
+                self._plans[key] = plan
+            plan.set_bags(chunk)
+            plan.run(Q, T, ls, None if W is None else W.detach().float().contiguous(),
+                     None if b is None else b.detach().float().contiguous(),
+                     None if pw is None else pw.detach().float().reshape(-1).contiguous())
+            logits.append(plan.logits.clone())
+            feats.append(plan.vhat.clone())
+            That = plan.That.clone()
+        return torch.cat(logits), torch.cat(feats), That
+
     def _forward_zeroshot(self, X, text_features):
         """Identity FeatMIL: per-patch cosine logits pooled over the patches (model/vlsa.py:194-196)."""
         from .deepmil import _parse_logit_pooling
