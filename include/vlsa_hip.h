@@ -72,6 +72,9 @@ size_t vlsa_qprep_bytes(int D);
  *          what backward needs).
  */
 int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, float coattn_scale, void* qprep, void* stream);
+/* vlsa_prepare_queries + vlsa_normalize_rows(T -> That, tnorm nullable) in ONE launch (both are bag-independent). */
+int vlsa_prepare_queries_and_text(const float* Q, int nq, int D, int gated, float coattn_scale, void* qprep,
+                                  const float* T, int K, float* That, float* tnorm, void* stream);
 /* Accessors into the opaque block (device pointers; for backward and for tests). */
 const float* vlsa_qprep_qeff(const void* qprep, int D);   /* [16, D] effective queries, rows >= P zero */
 const float* vlsa_qprep_qhat(const void* qprep, int D);   /* [17, D] unit queries */

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "vlsa_qprep_qhat": (c_void_p, [c_void_p, c_int]),
     "vlsa_qprep_qnorm": (c_void_p, [c_void_p, c_int]),
     "vlsa_prepare_queries": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "vlsa_prepare_queries_and_text": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+                                              c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

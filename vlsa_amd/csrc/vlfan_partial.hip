@@ -21,9 +21,22 @@ namespace vlsa {
 // scale * log2(e) * e_p (so MFMA scores come out directly in the log2 domain).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict__ Q, int nq, int D, int gated,
-                                                          float scale2, unsigned char* __restrict__ qprep) {
+                                                          float scale2, unsigned char* __restrict__ qprep,
+                                                          const float* __restrict__ T, float* __restrict__ That,
+                                                          float* __restrict__ tnorm) {
     __shared__ float red[4];
     __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x >= 17) {  // fused text-feature normalisation: F.normalize(text_features) (model/vlsa.py:186)
+        const int r = blockIdx.x - 17, tid = threadIdx.x;
+        const float* x = T + (size_t)r * D;
+        float ss = 0.f;
+        for (int d = tid; d < D; d += 256) ss += x[d] * x[d];
+        ss = block_sum_256(ss, red);
+        const float nrm = fmaxf(sqrtf(ss), kNormEps);
+        for (int d = tid; d < D; d += 256) That[(size_t)r * D + d] = x[d] / nrm;
+        if (tnorm != nullptr && tid == 0) tnorm[r] = nrm;
+        return;
+    }
     const QPrepLayout L(D);
     float* qeff = reinterpret_cast<float*>(qprep + L.qeff);
     __bf16* qsplit = reinterpret_cast<__bf16*>(qprep + L.qsplit);
@@ -439,7 +452,18 @@ extern "C" int vlsa_prepare_queries(const float* Q, int nq, int D, int gated, fl
     const int P = gated ? nq - 1 : nq;
     if (P < 1 || P > VLSA_MAX_P || !(coattn_scale > 0.f)) return VLSA_EINVAL;
     hipLaunchKernelGGL(k_prepare_queries, dim3(17), dim3(256), 0, (hipStream_t)stream, Q, nq, D, gated,
-                       coattn_scale * kLog2e, static_cast<unsigned char*>(qprep));
+                       coattn_scale * kLog2e, static_cast<unsigned char*>(qprep), (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_prepare_queries_and_text(const float* Q, int nq, int D, int gated, float coattn_scale, void* qprep,
+                                             const float* T, int K, float* That, float* tnorm, void* stream) {
+    if (!Q || !qprep || !T || !That || D <= 0 || D > VLSA_MAX_D || (D % 8) != 0 || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    const int P = gated ? nq - 1 : nq;
+    if (P < 1 || P > VLSA_MAX_P || !(coattn_scale > 0.f)) return VLSA_EINVAL;
+    hipLaunchKernelGGL(k_prepare_queries, dim3(17 + K), dim3(256), 0, (hipStream_t)stream, Q, nq, D, gated,
+                       coattn_scale * kLog2e, static_cast<unsigned char*>(qprep), T, That, tnorm);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 

@@ -376,6 +376,8 @@ int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode
     if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_GIVEN) return VLSA_EINVAL;
     if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
     const int NB = W ? (D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock : 1;
+    // one workgroup per (8 rows of W, bag): all bags' latency chains run side by side (a variant that kept W in registers
+    // and walked 8 bags per workgroup measured 2x slower: the per-bag chain, not the W traffic, is the cost)
     hipLaunchKernelGGL(k_head, dim3(NB, B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
                        counters, pooled, v, vhat, vnorm, logits, incidence, NB);
     return launch_status();

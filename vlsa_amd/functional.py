@@ -249,9 +249,8 @@ class VlfanInferencePlan:
         lib, s = self.lib, _stream()
         nq = self.P + 1 if self.gated else self.P
         c = nat.check
-        c(lib.vlsa_prepare_queries(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), s),
-          "prepare_queries")
-        c(lib.vlsa_normalize_rows(_p(T), self.K, self.D, _p(self.That), _p(self.tnorm), s), "normalize_rows")
+        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), _p(T), self.K,
+                                            _p(self.That), _p(self.tnorm), s), "prepare_queries_and_text")
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
         c(lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
                                  self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc), _p(self.scores), s),
@@ -487,8 +486,8 @@ class VlfanBatchPlan:
     def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
         lib, s, c = self.lib, _stream(), nat.check
         nq = self.P + 1 if self.gated else self.P
-        c(lib.vlsa_prepare_queries(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), s), "prepare_queries")
-        c(lib.vlsa_normalize_rows(_p(T), self.K, self.D, _p(self.That), _p(self.tnorm), s), "normalize_rows")
+        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), _p(T), self.K,
+                                            _p(self.That), _p(self.tnorm), s), "prepare_queries_and_text")
         c(lib.vlsa_vlfan_forward_batch(_p(self.desc), self.B, nat.DT_BF16, self.D, _p(self.qprep), self.P, self.pool,
                                        _p(pool_w), None if self.identity_head else _p(W),
                                        None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
