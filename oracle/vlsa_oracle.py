@@ -314,3 +314,43 @@ def vlfan_forward_sharded(X: torch.Tensor, Q: torch.Tensor, bounds: List[int], *
     s = torch.cat([p[3] for p in parts], dim=1)
     A = torch.exp(s - m[:, None]) / l[:, None]
     return dict(out=out, A=A, m=m, l=l)
+
+
+# ----------------------------------------------------------------------------------------------
+# Host-side losses of the training step (used ONLY by the training-step parity tests; the drop-in keeps
+# the reference's own loss code, which is out of scope -- SURVEY.md section 2)
+# ----------------------------------------------------------------------------------------------
+def surv_ifmle(incidence: torch.Tensor, t: torch.Tensor, e: torch.Tensor, alpha: float = 0.0, eps: float = 1e-7):
+    """SurvIFMLE, reduction='mean' (loss/loss_surv.py:144-169). incidence [B,K] softmax-ed, t [B] bins, e [B] events."""
+    B = len(t)
+    t = t.view(B, 1).long()
+    c = 1 - e.view(B, 1).float()
+    cif = torch.cumsum(incidence, dim=1)
+    unc = -(1 - c) * torch.log(torch.gather(incidence, 1, t).clamp(min=eps))
+    cen = -c * torch.log((1 - torch.gather(cif, 1, t)).clamp(min=eps))
+    return ((1.0 - alpha) * (cen + unc) + alpha * unc).mean()
+
+
+def surv_emd(y_hat: torch.Tensor, t: torch.Tensor, e: torch.Tensor, logit_scale, p: int = 2):
+    """SurvEMD, raw_distance=True, reduction='mean' (loss/loss_surv_ext.py:43-109)."""
+    B, K = y_hat.shape
+    ls = logit_scale.detach() if isinstance(logit_scale, torch.Tensor) else logit_scale
+    t = t.view(-1, 1).long()
+    e = e.view(-1, 1).long()
+    target = torch.zeros(B, K, dtype=t.dtype, device=t.device).scatter_(1, t, 1)
+    for i in range(B):  # censored: every later bin is also a valid target (loss_surv_ext.py:51-54)
+        loc = int(t[i, 0]) + 1
+        if loc < K:
+            target[i, loc:] = target[i, loc:] + (1 - e[i, 0])
+    target_dist = torch.softmax((2 * target - 1) * ls, dim=-1)
+    pred = (1 - e) * ((1 - target) * y_hat + target * ls) + e * y_hat
+    pred_dist = torch.softmax(pred, dim=-1)
+    d = torch.cumsum(pred_dist, dim=-1) - torch.cumsum(target_dist, dim=-1)
+    dist = (d ** 2).sum(dim=-1) if p == 2 else d.abs().pow(p).sum(dim=-1)
+    return dist.mean()
+
+
+def vlsa_objective(logits: torch.Tensor, t, e, logit_scale_exp):
+    """calc_objective_loss with loss_type SurvIFMLE-SurvEMD, weights 1/1 (runner/vlsa_handler.py:241-258)."""
+    inc = torch.softmax(logits, dim=-1)
+    return surv_ifmle(inc, t, e) + surv_emd(inc, t, e, logit_scale_exp)

@@ -101,9 +101,9 @@ def pack_big(out: dict, key: str, t: torch.Tensor):
     """Store a tensor in a fixture dict; large 2-D tensors as 4 sampled rows + Frobenius norm + sum."""
     t = t.detach()
     if t.numel() <= BIG or t.dim() != 2:
-        out[key] = t.numpy()
+        out[key] = t.numpy().copy()
     else:
-        out[key + "@rows"] = t[list(SAMPLE_ROWS)].numpy()
+        out[key + "@rows"] = t[list(SAMPLE_ROWS)].numpy().copy()
         out[key + "@fro"] = t.double().norm().numpy()
         out[key + "@sum"] = t.double().sum().numpy()
 
@@ -178,3 +178,12 @@ def bag_for_case(N, kind, seed):
     if kind == "iid_bf16":
         return make_bag(N, seed, "iid", torch.bfloat16)
     return make_bag(N, seed, kind)
+
+
+# ---- training-step case: 4 bags, 3 Adam steps (runner/vlsa_handler.py:260-289; cfg_vlsa_conch.yaml:111-118) ----
+TRAIN = dict(P=12, K=12, sizes=(300, 517, 900, 64), seed=601, lr=2e-4, wd=1e-5, steps=3,
+             t=(0, 3, 11, 5), e=(1, 0, 1, 0))
+
+
+def train_bags():
+    return [make_bag(n, TRAIN["seed"] + 10 + i, "clustered" if i % 2 else "iid") for i, n in enumerate(TRAIN["sizes"])]

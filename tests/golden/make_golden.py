@@ -25,7 +25,7 @@ torch.set_num_threads(4)
 
 
 def _np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 def fake_vlsa(ref, encoder, T, logit_scale, pooling=None, text_requires_grad=False):
@@ -247,6 +247,48 @@ def gen_misc(ref):
         print("ckpt keys", keys)
 
 
+def gen_train_step(ref):
+    """The reference's own training step: VLSA.forward per bag, SurvIFMLE + SurvEMD, Adam with weight decay on the
+    >= 2-D parameters only (runner/vlsa_handler.py:241-289, optim/optim_factory.py:25-37)."""
+    import loss.loss_surv as LS
+    import loss.loss_surv_ext as LE
+    cfg = cases.TRAIN
+    P, K = cfg["P"], cfg["K"]
+    params = cases.make_params(P, K, cfg["seed"] + 1000)
+    enc = build_vlfan(ref, P, "mean", "default", False, params, cfg["seed"])
+    enc.train()
+    model = fake_vlsa(ref, enc, params["T"], cases.LOGIT_SCALE, text_requires_grad=True)
+    bags = cases.train_bags()
+    t = torch.tensor(cfg["t"]).view(-1, 1)
+    e = torch.tensor(cfg["e"]).view(-1, 1).float()
+    decay = [p for n, p in model.named_parameters() if p.requires_grad and not (p.dim() <= 1 or n.endswith(".bias"))]
+    no_decay = [p for n, p in model.named_parameters() if p.requires_grad and (p.dim() <= 1 or n.endswith(".bias"))]
+    opt = torch.optim.Adam([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": cfg["wd"]}], lr=cfg["lr"])
+    ifmle, emd = LS.SurvIFMLE(), LE.SurvEMD(p=2)
+    out = {}
+    for step in range(cfg["steps"]):
+        preds = torch.cat([model(x[None])[0] for x in bags], dim=0)
+        inc = torch.softmax(preds, dim=-1)
+        l1, l2 = ifmle(inc, t, e), emd(inc, t, e, model.get_logit_scale())
+        loss = 1.0 * l1 + 1.0 * l2
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out["grad0.resid"] = _np(enc.Q.residual_features.grad)
+            out["grad0.logit_scale"] = _np(model.logit_scale.grad)
+            out["logits0"] = _np(preds)
+        opt.step()
+        out[f"loss{step}"] = np.array([float(loss), float(l1), float(l2)])
+        if step in (0, cfg["steps"] - 1):
+            out[f"resid@{step}"] = _np(enc.Q.residual_features)
+            out[f"b@{step}"] = _np(enc.visual_adapter.bias)
+            out[f"logit_scale@{step}"] = _np(model.logit_scale)
+            out[f"T@{step}"] = _np(model.text_param)
+            cases.pack_big(out, f"W@{step}", enc.visual_adapter.weight)
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    print("train", [out[f"loss{i}"] for i in range(cfg["steps"])])
+
+
 if __name__ == "__main__":
     ref = _ref_import.import_reference()
     gen_vlfan(ref)
@@ -254,4 +296,5 @@ if __name__ == "__main__":
     gen_deepmil(ref)
     gen_interpretation(ref)
     gen_misc(ref)
+    gen_train_step(ref)
     print("done")
