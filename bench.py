@@ -194,6 +194,15 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                 "avg_us": round(avg_ms * 1e3, 2), "min_us": round(ts[0] * 1e3, 2), "event_pair_us": round(null_ms * 1e3, 2),
                 "bags_per_launch": BPL, "bytes_per_launch": algo_bytes}
+        # HBM traffic of this kernel/configuration from the committed PMC passes (separate `--pmc FETCH_SIZE` /
+        # `--pmc WRITE_SIZE` runs of tools/run_batch.py; FETCH_SIZE x 2 = gfx950 16-B/lane correction, MI355X_MICROARCH.md)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_batch_kernel.json")))
+            if BPL == 32:
+                roof["traffic"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
+                roof["traffic_source"] = "profiles/r01_pmc_batch_kernel.json (rocprofv3 --pmc, 32 x 50k bags per launch)"
+        except Exception:
+            pass
     if dist is not None:
         dist.barrier()
 

@@ -6,12 +6,12 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r01; mkdir -p $O
 (timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --streams 1 > $O/bench_streams1.json 2>/dev/null
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python tools/run_partial.py 50000 bf16 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python tools/run_partial.py 50000 bf16 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_sq -- python tools/run_partial.py 50000 bf16 > /dev/null 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_lds -- python tools/run_partial.py 50000 bf16 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_sq -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_lds -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
 python - <<PY
 import csv, glob, collections, json
 out = {}
@@ -20,12 +20,12 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     if not fs: continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "partial" in r["Kernel_Name"]:
+        if "partial_dma_batch" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         v = v[4:] or v            # skip warm-up launches
         out[k] = sum(v) / len(v)
-json.dump(out, open("$O/pmc_partial_kernel.json", "w"), indent=1)
+json.dump(out, open("$O/pmc_batch_kernel.json", "w"), indent=1)
 print(out)
 PY
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
