@@ -147,7 +147,7 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
 
 /* One bag of a batch (device-resident array of these is passed to vlsa_vlfan_forward_batch). */
 typedef struct vlsa_bag_desc {
-    const void* X;   /* [N, 512] bf16 rows, 16-byte aligned */
+    const void* X;   /* [N, 512] rows (bf16 or fp32: one dtype per batch), 16-byte aligned */
     int64_t N;       /* patches in this bag (>= 0) */
     int64_t ldx;     /* row stride in elements (>= 512, multiple of 8) */
 } vlsa_bag_desc;
@@ -160,7 +160,8 @@ size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE af
  * B independent bags through the whole per-bag forward (model/vlsa.py:181-198 with cached text features, called once
  * per bag by runner/vlsa_handler.py:267-269,322-330) in THREE launches: one persistent streaming kernel that walks all
  * bags with the LDS-DMA ring running across bag boundaries, a batched merge and a batched incidence head.
- * Queries (qprep) and unit text features (That) are shared by the batch.  bf16 rows, D == 512.
+ * Queries (qprep) and unit text features (That) are shared by the batch.  D == 512; x_dtype VLSA_DT_BF16 (split-bf16
+ * MFMA kernel) or VLSA_DT_F32 (exact f32 MFMA kernel -- the reference's own feature format).
  * Outputs: m2, l [B,16]; out [B,P,D]; pooled, v, vhat [B,D]; vnorm [B]; logits, incidence (nullable) [B,K].
  */
 /* Only the persistent streaming kernel of the batch (partials into `workspace`); vlsa_vlfan_forward_batch = this +

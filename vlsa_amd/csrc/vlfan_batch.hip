@@ -485,11 +485,15 @@ extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
     return ((size_t)B * G * kPStride * 2 + (size_t)B * G * P * D) * sizeof(float) + (size_t)B * 64;
 }
 
+int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
+                                  float* pl, float* pacc, int S, hipStream_t s);  // vlfan_batch_f32.hip
+
 extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                                         void* workspace, void* stream) {
     if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
     if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
-    if (D != 512 || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
+    if (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) return VLSA_EINVAL;
+    if (D != 512) return VLSA_EUNSUPPORTED;
     const int S = batch_groups(B);
     const int G = 256 / S;  // partials per bag
     float* pm = static_cast<float*>(workspace);
@@ -501,6 +505,11 @@ extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype
         attr_set = true;
     }
     const QPrepLayout L(D);
+    if (x_dtype == VLSA_DT_F32) {
+        const unsigned char* qp = static_cast<const unsigned char*>(qprep);
+        return vlsa_launch_partial_f32_batch(bag_desc, B, reinterpret_cast<const float*>(qp + L.qeff),
+                                             reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, S, (hipStream_t)stream);
+    }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
     hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(256), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
                        static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S);

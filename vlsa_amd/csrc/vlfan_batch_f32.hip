@@ -1,0 +1,359 @@
+// fp32 bags (the reference's own storage format: dataset/PatchWSI.py:205-215 returns float32 features) through the
+// persistent multi-bag streaming kernel, EXACTLY in fp32: both contractions run on v_mfma_f32_16x16x4_f32 (f32 in /
+// f32 accumulate, bit-equal to an fmaf chain, 157 TFLOP/s peak -- MI355X_MICROARCH.md), so there is no split-bf16
+// approximation of X at all.  Structure = k_vlfan_partial_dma_batch (vlfan_batch.hip); what differs:
+//   * tile = 16 rows x 128 fp32 columns per wave (8 KiB slot, same ring); a lock-step iteration covers 32 rows;
+//   * LDS-DMA piece = 2 rows x 512 B; the swizzle XORs the 16-byte chunk index with (row & 7) on the SOURCE address;
+//   * fragments are single floats: A[i][k] -> lane (i = l & 15, k = l >> 4); ds_read_b32 (2-way conflict on the score
+//     reads, conflict-free on the weighted-sum reads);
+//   * weighted sum: MFMA k-slot k of step rs is mapped to tile row 4k + rs, so the softmax weight the lane already holds
+//     in register rs IS the A operand -- weights stay fp32, no conversion;
+//   * row norms on the VALU from the score fragments (32 FMAs + 2 cross-quad adds per tile).
+// Arithmetic intensity at HBM rate: 2048 B / patch -> 64 fp32 MFMAs per 16-row tile per wave = 63 % of the f32 MFMA pipe.
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef f32x4 __attribute__((may_alias)) f32x4_ma;
+typedef float __attribute__((may_alias)) float_ma;
+typedef int __attribute__((may_alias)) int_ma;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct BagDesc {
+    const void* X;
+    int64_t N;
+    int64_t ldx;
+};
+
+namespace bf {
+constexpr int kTile = 16;                        // rows per tile
+constexpr int kSlot = kTile * 512;               // 8 KiB: 16 rows x 128 fp32 columns
+constexpr int kWaveRing = 2 * kSlot;
+constexpr int kRingBytes = 8 * kWaveRing;        // 128 KiB
+constexpr int kExchWave = 1024 + 64;             // S partials (one f32x4 per lane) + 16 row sums of squares
+constexpr int kExchGroup = 4 * kExchWave;
+constexpr int kTabOff = kRingBytes + 2 * kExchGroup;
+constexpr int kMaxBags = 64;
+constexpr int kMlOff = kTabOff + kMaxBags * 32;
+constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;
+constexpr float kThr = 16.0f;
+}  // namespace bf
+
+// element (row, col) of a wave's fp32 slice image lives at row * 512 + (((col >> 2) ^ (row & 7)) << 4) + (col & 3) * 4
+__device__ __forceinline__ int fswz(int row, int col) { return row * 512 + ((((col >> 2) ^ (row & 7))) << 4) + ((col & 3) << 2); }
+
+#define VLSA_FBAR()                                          \
+    do {                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        __builtin_amdgcn_s_barrier();                        \
+        asm volatile("" ::: "memory");                       \
+    } while (0)
+
+// S = number of workgroup groups: bag t is streamed by the Gb = G / S workgroups of group t % S only, so S bags are in
+// flight at once, every workgroup sees S times more rows per bag (fewer bag epilogues, better tile quantisation) and a
+// bag leaves Gb instead of G partials behind.
+__global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDesc* __restrict__ bags, int B,
+                                                                     const float* __restrict__ qeff, const float* __restrict__ qmeta, int P,
+                                                                     float* __restrict__ pm, float* __restrict__ pl,
+                                                                     float* __restrict__ pacc, int S) {
+    using namespace bf;
+    constexpr int D = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = w >> 2, cw = w & 3;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int Gb = gridDim.x / S;            // workgroups (and partials) per bag
+    const int grp = blockIdx.x / Gb, b = blockIdx.x % Gb, G = Gb;
+
+    unsigned char* ring = smem + w * kWaveRing;
+    unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
+    int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
+
+    // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
+    if (tid < B) {
+        const BagDesc d = bags[tid];
+        // 32-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
+        // unit rotates with the bag index so that the extra iterations even out over the batch
+        const unsigned long long units = (unsigned long long)((d.N + 31) >> 5);
+        const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
+        const unsigned int vb = (unsigned int)((b + (tid / S) * 37) % G);  // virtual workgroup index for this bag
+        const bool mine = (tid % S) == grp;
+        const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
+        const long long rbeg = (long long)(ubeg << 5);
+        long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 5);
+        if (rend > d.N) rend = d.N;
+        const int nrows = (mine && rend > rbeg) ? (int)(rend - rbeg) : 0;
+        const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 4ull;
+        int_ma* e = tab + tid * 8;
+        e[0] = (int)(unsigned int)addr;
+        e[1] = (int)((addr >> 32) & 0xffffu);
+        e[2] = nrows > 0 ? (int)(((long long)(nrows - 1) * d.ldx + D) * 4) : 0;  // descriptor span in bytes
+        e[3] = (int)(d.ldx * 4);                                                    // row pitch in bytes
+        e[4] = nrows;
+        e[5] = (nrows + kTile - 1) / kTile;
+        e[6] = (int)vb;  // partial slot of this workgroup for this bag
+        e[7] = mine ? 1 : 0;
+    }
+    // query B-fragments, fp32, scale * log2(e) applied here: lane holds e_p[p = i16][128 cw + 4 kk + g], kk = 0..31
+    float qf[32];
+    {
+        const float sc = qmeta[31];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) qf[kk] = qeff[(size_t)i16 * D + cw * 128 + 4 * kk + g] * sc;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) asm volatile("" : "+v"(qf[kk]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * 8 + k]); };
+
+    const unsigned int ring_lds = (unsigned int)(uintptr_t)(lds_void_ptr)ring;
+    const int lr = lane >> 5, lc = lane & 31;
+    // LDS-DMA of one 32-row tile of `bag` into ring slot `slot` (see k_vlfan_partial_dma for the layout)
+    // descriptor of the bag the DMA currently streams from, cached in SGPRs (reloaded from the table on a bag change)
+    int ib = -1, ildb = 0;
+    int voff[4] = {0, 0, 0, 0};  // row & 7 of piece i is 2 (i & 3) + lr
+    i32x4 rsrc = {0, 0, 0, 0x00020000};
+    auto issue_tile = [&](int bag, int tile, int slot) {
+        if (bag != ib) {
+            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * 32);
+            rsrc[0] = __builtin_amdgcn_readfirstlane(e.x);
+            rsrc[1] = __builtin_amdgcn_readfirstlane(e.y);
+            rsrc[2] = __builtin_amdgcn_readfirstlane(e.z);
+            ildb = __builtin_amdgcn_readfirstlane(e.w);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) voff[q] = lr * ildb + cw * 512 + ((lc ^ (2 * q + lr)) << 4);
+            ib = bag;
+        }
+        const int ldb = ildb;
+        const int sbase = tile * kTile * ldb;
+        const unsigned int dst = ring_lds + slot * kSlot;
+        unsigned int keep;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst + i * 1024), "v"(voff[i & 3]), "s"(rsrc), "s"(sbase + i * 2 * ldb)
+                : "memory");
+        }
+    };
+    // this row group's next own tile after (bag, tile): same bag if it has one, else the first of a later bag
+    auto next_of = [&](int bag, int tile, int ntiles_bag, int& nb, int& nt) {
+        if (tile + 2 < ntiles_bag) {
+            nb = bag;
+            nt = tile + 2;
+            return;
+        }
+        nb = bag + 1;
+        while (nb < B && tab_get(nb, 5) <= rg) ++nb;
+        nt = rg;
+    };
+
+    int kown = 0;      // own tiles consumed so far by this wave; own tile k lives in ring slot k & 1
+    int k0 = 0, k1 = 0;  // tiles consumed so far by row group 0 / 1 (for the epilogue's free-slot bookkeeping)
+    {
+        int fb = 0;  // first own tile of the whole batch
+        while (fb < B && tab_get(fb, 5) <= rg) ++fb;
+        if (fb < B) issue_tile(fb, rg, 0);
+    }
+
+    
+    for (int bag = 0; bag < B; ++bag) {
+        if (tab_get(bag, 7) == 0) continue;  // another group's bag (workgroup-uniform)
+        const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
+        const int niter = (ntiles + 1) >> 1;
+        f32x4 acc[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float M = -INFINITY, lsum = 0.f;
+
+        for (int it = 0; it < niter; ++it) {
+            const int tile = 2 * it + rg;
+            const bool have = tile < ntiles;  // wave-uniform
+            const int slot = kown & 1;
+            const unsigned char* xs = ring + slot * kSlot;
+            const int row0 = tile * kTile;
+            f32x4 S = {0.f, 0.f, 0.f, 0.f};
+            float ss = 0.f;
+            if (have) {
+                int nb, nt;
+                next_of(bag, tile, ntiles, nb, nt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
+                if (nb < B) {
+                    issue_tile(nb, nt, slot ^ 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this tile landed; the next 8 pieces stay in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // contraction 1 on the f32 matrix pipe: S[n][p] += X[n][c] e_p[c]; A fragment = one float per lane
+                float xa[32];
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) xa[kk] = *reinterpret_cast<const float_ma*>(xs + fswz(i16, 4 * kk + g));
+                f32x4 Sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 2) {
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], qf[kk], S, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 1], qf[kk + 1], Sb, 0, 0, 0);
+                }
+                S += Sb;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 2) {
+                    s0 = fmaf(xa[kk], xa[kk], s0);
+                    s1 = fmaf(xa[kk + 1], xa[kk + 1], s1);
+                }
+                ss = quad_rows_sum(s0 + s1);  // lanes with the same i16 hold the wave-partial |x_n|^2, n = i16
+            }
+
+            VLSA_FBAR();  // readers of the previous exchange are done
+            {
+                unsigned char* mine = exch + cw * kExchWave;
+                *reinterpret_cast<f32x4_ma*>(mine + lane * 16) = S;
+                if (g == 0) reinterpret_cast<float_ma*>(mine + 1024)[i16] = ss;
+            }
+            VLSA_FBAR();
+            if (have) {
+                f32x4 T, R2;
+                {
+                    f32x4 tv[4], rv[4];
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const unsigned char* o = exch + ww * kExchWave;
+                        tv[ww] = *reinterpret_cast<const f32x4_ma*>(o + lane * 16);
+                        rv[ww] = *reinterpret_cast<const f32x4_ma*>(o + 1024 + 16 * g);
+                    }
+                    T = (tv[0] + tv[1]) + (tv[2] + tv[3]);
+                    R2 = (rv[0] + rv[1]) + (rv[2] + rv[3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[r] *= fminf(__builtin_amdgcn_rsqf(R2[r]), 1e12f);
+                if (row0 + kTile > nrows) {  // ragged last tile of this workgroup's range
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row0 + 4 * g + r >= nrows) T[r] = -INFINITY;
+                }
+                const float tmax = fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3]));
+                if (__builtin_amdgcn_ballot_w64(tmax > M + kThr) != 0) {
+                    const float newM = fmaxf(M, quad_rows_max(tmax));
+                    const float f = (M == -INFINITY) ? 0.f : fast_exp2(M - newM);
+                    lsum *= f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float fr = __shfl(f, 4 * g + r);
+#pragma unroll
+                        for (int ct = 0; ct < 8; ++ct) acc[ct][r] *= fr;
+                    }
+                    M = newM;
+                }
+                float wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    wv[r] = fast_exp2(T[r] - M);
+                    lsum += wv[r];
+                }
+                // contraction 2 on the f32 matrix pipe: acc[p][c] += W[p][n] X[n][c]; k-slot k of step rs <-> tile row 4k + rs,
+                // so A = wv[rs] (this lane: p = i16, row 4g + rs) and B = X[4g + rs][16 ct + i16]
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    float xb[4];
+#pragma unroll
+                    for (int rs = 0; rs < 4; ++rs) xb[rs] = *reinterpret_cast<const float_ma*>(xs + fswz(4 * g + rs, 16 * ct + i16));
+#pragma unroll
+                    for (int rs = 0; rs < 4; ++rs) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rs], xb[rs], acc[ct], 0, 0, 0);
+                }
+                ++kown;
+            }
+            
+        }
+        k0 += (ntiles + 1) >> 1;
+        k1 += ntiles >> 1;
+
+        // ---- bag epilogue.  Waves (0, cw) and (1, cw) each park the half of their accumulators the partner merges in
+        // their just-consumed ring slot (the other slot holds the next bag's first tile, already in flight); after ONE
+        // barrier wave (rg, cw) merges column tiles [4 rg, 4 rg + 4) of quarter cw from both, transposes them through
+        // the other half of its own slot and stores 16-byte row pieces.  A second barrier frees the slots for the ring.
+        lsum = quad_rows_sum(lsum);
+        const int kmine = rg == 0 ? k0 : k1, kother = rg == 0 ? k1 : k0;
+        unsigned char* myslot = ring + (((kmine - 1) & 1) * kSlot);
+        const unsigned char* otherslot = smem + ((rg ^ 1) * 4 + cw) * kWaveRing + (((kother - 1) & 1) * kSlot);
+        float_ma* mlw = reinterpret_cast<float_ma*>(smem + kMlOff);  // [8 waves][2][16]: (M, l) of every wave
+        // first 4 KiB of my free slot: the 4 column tiles the partner wave merges; last 4 KiB: my transpose tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_ma*>(myslot + (j * 64 + lane) * 16) = rg == 0 ? acc[4 + j] : acc[j];
+        if (g == 0) {
+            mlw[w * 32 + i16] = M;
+            mlw[w * 32 + 16 + i16] = lsum;
+        }
+        VLSA_FBAR();
+        {
+            const int wo = (rg ^ 1) * 4 + cw;
+            // one round of LDS reads: both waves' reference maxima for the 4 queries of my accumulator rows, the
+            // partner's normaliser, and the partner's 4 parked column tiles
+            const f32x4 Mm4 = *reinterpret_cast<const f32x4_ma*>(&mlw[w * 32 + 4 * g]);
+            const f32x4 Mo4 = *reinterpret_cast<const f32x4_ma*>(&mlw[wo * 32 + 4 * g]);
+            const float Mo = mlw[wo * 32 + i16], lo = mlw[wo * 32 + 16 + i16];
+            f32x4 oth[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oth[j] = *reinterpret_cast<const f32x4_ma*>(otherslot + (j * 64 + lane) * 16);
+            float am[4], ao[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mn = fmaxf(Mm4[r], Mo4[r]);
+                am[r] = (Mm4[r] == -INFINITY) ? 0.f : fast_exp2(Mm4[r] - mn);
+                ao[r] = (Mo4[r] == -INFINITY) ? 0.f : fast_exp2(Mo4[r] - mn);
+            }
+            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
+            if (w == 0 && g == 0 && i16 < P) {
+                const float Mn = fmaxf(M, Mo);
+                const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
+                const float fo = (Mo == -INFINITY) ? 0.f : fast_exp2(Mo - Mn);
+                pm[slotg * kPStride + i16] = Mn;
+                pl[slotg * kPStride + i16] = lsum * fm + lo * fo;
+            }
+            float_ma* tp = reinterpret_cast<float_ma*>(myslot + 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 mine = rg == 0 ? acc[j] : acc[4 + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[(4 * g + r) * 64 + j * 16 + i16] = mine[r] * am[r] + oth[j][r] * ao[r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float* dstp = pacc + slotg * P * D + cw * 128 + rg * 64 + (lane & 15) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = 4 * k + (lane >> 4);
+                const f32x4 v = *reinterpret_cast<const f32x4_ma*>(reinterpret_cast<unsigned char*>(tp) + (p * 64 + (lane & 15) * 4) * 4);
+                if (p < P) *reinterpret_cast<f32x4*>(dstp + (size_t)p * D) = v;
+            }
+        }
+        VLSA_FBAR();  // lent slots and the transpose area are free again
+        
+    }
+}
+#ifdef VLSA_TIMING
+extern "C" __global__ void k_dummy_batch_dbg() {}
+#endif
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
+                                  float* pl, float* pacc, int S, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_vlfan_partial_f32_batch, dim3(256), dim3(512), bf::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
+                       qeff, qmeta, P, pm, pl, pacc, S);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}

@@ -465,22 +465,25 @@ class VlfanBatchPlan:
         self.pooled, self.v, self.vhat, self.vnorm = f(B, D), f(B, D), f(B, D), f(B)
         self.logits, self.incidence = f(B, K), f(B, K)
         self._bags = None
+        self.dt = nat.DT_BF16
 
     def set_bags(self, bags):
-        """bags: list of B device tensors [N_i, 512] bf16 (unit inner stride, 16-byte aligned rows). Kept alive by the plan."""
+        """bags: list of B device tensors [N_i, 512], all bf16 or all fp32 (unit inner stride, 16-byte aligned rows).
+        Kept alive by the plan."""
         if len(bags) != self.B:
             raise ValueError(f"expected {self.B} bags, got {len(bags)}")
         keep = []
         for i, x in enumerate(bags):
             _need_gpu(x)
             x = _bag2d(x)
-            if x.dtype != torch.bfloat16 or x.shape[1] != self.D:
-                raise VlsaNativeError("the batched path takes bf16 bags with D == 512")
+            if x.shape[1] != self.D or (i > 0 and x.dtype != keep[0].dtype):
+                raise VlsaNativeError("the batched path takes bags with D == 512 and one dtype (bf16 or fp32) per batch")
             keep.append(x)
             self.desc_host[i, 0] = x.data_ptr()
             self.desc_host[i, 1] = x.shape[0]
             self.desc_host[i, 2] = x.stride(0) if x.shape[0] > 0 else self.D
         self._bags = keep
+        self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
         self.desc.copy_(self.desc_host, non_blocking=True)
 
     def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
@@ -488,7 +491,7 @@ class VlfanBatchPlan:
         nq = self.P + 1 if self.gated else self.P
         c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), _p(T), self.K,
                                             _p(self.That), _p(self.tnorm), s), "prepare_queries_and_text")
-        c(lib.vlsa_vlfan_forward_batch(_p(self.desc), self.B, nat.DT_BF16, self.D, _p(self.qprep), self.P, self.pool,
+        c(lib.vlsa_vlfan_forward_batch(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P, self.pool,
                                        _p(pool_w), None if self.identity_head else _p(W),
                                        None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
                                        _p(self.ws), _p(self.m2), _p(self.l), _p(self.out), _p(self.pooled), _p(self.v),
@@ -498,5 +501,5 @@ class VlfanBatchPlan:
 
     def run_partial_only(self):
         """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
-        nat.check(self.lib.vlsa_vlfan_partial_batch(_p(self.desc), self.B, nat.DT_BF16, self.D, _p(self.qprep), self.P,
+        nat.check(self.lib.vlsa_vlfan_partial_batch(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
                                                     _p(self.ws), _stream()), "vlfan_partial_batch")

@@ -190,7 +190,7 @@ class ShardedVlfanBatchPlan:
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         nq = self.P + 1 if pl_.gated else self.P
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
-        c(lib.vlsa_vlfan_partial_batch(p(pl_.desc), self.B, nat.DT_BF16, self.D, p(pl_.qprep), self.P, p(pl_.ws), s),
+        c(lib.vlsa_vlfan_partial_batch(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws), s),
           "vlfan_partial_batch")
         base = pl_.ws.data_ptr()
         n_ml = self.B * self.G * nat.P_STRIDE * 4

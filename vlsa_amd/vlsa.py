@@ -143,14 +143,14 @@ class VLSA(nn.Module):
     @torch.no_grad()
     def forward_bags(self, bags):
         """Inference over a list of independent bags (what the reference's eval loop does one bag at a time,
-        runner/vlsa_handler.py:315-345).  bf16 bags with D == 512 and a fusable VLFAN go through the persistent
+        runner/vlsa_handler.py:315-345).  bf16 or fp32 bags with D == 512 and a fusable VLFAN go through the persistent
         multi-bag kernel, up to 64 bags per launch; anything else falls back to per-bag ``forward``.
         Returns (logits [B, K], image_features [B, D], text_features [K, D])."""
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         text_features = self.forward_text_only()
         flat = [VF._bag2d(x) for x in bags]
-        ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == torch.bfloat16 and x.shape[1] == 512
+        ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512
                                                           and x.shape[0] > 0 for x in flat))
         if not ok:
             outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
