@@ -174,6 +174,19 @@ int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, co
                              float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
 
 /*
+ * Backward of the aggregation for a BATCH of bags w.r.t. the (shared) effective queries -- one training step of the
+ * reference back-propagates 32 bags through the same queries (runner/vlsa_handler.py:260-289, model/deepmil.py:187-200).
+ * dout, out: [B, P, D]; m2, l: [B, 16] (the batched forward's outputs).  ONE persistent launch streams all bags and writes
+ * 256 partial sums of  sum_bags de  into pm (= 0), pl (= 1) [256, 16] and pacc [256, P, D]; reduce them with
+ * vlsa_vlfan_merge(..., G = 256, normalise = 0).  bwd_prep: scratch of vlsa_bwd_batch_prep_bytes(B, D).
+ * bf16 bags, D == 512 and P <= 12 (VLSA_EUNSUPPORTED otherwise: loop vlsa_vlfan_backward over the bags instead).
+ */
+size_t vlsa_bwd_batch_prep_bytes(int B, int D);
+int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                              float coattn_scale, const float* dout, const float* out, const float* m2, const float* l,
+                              void* bwd_prep, float* pm, float* pl, float* pacc, void* stream);
+
+/*
  * Batched log-sum-exp merge with explicit strides (in floats): strides9 (HOST array) = {partial stride of pm, pl, pacc;
  * bag stride of pm, pl, pacc; bag stride of the outputs m2, l, out}.  Used by the multi-GPU batch path to fold the
  * workgroup partials of B bags into B compact records and, after the all-gather, the per-rank records into the result.

@@ -18,3 +18,20 @@ for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (10000, torch.flo
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / 50 * 1e6
     print(f"N={n} {str(dt)[6:]}: fwd+bwd {us:8.1f} us/bag (eager, python included)")
+
+# 32 bags per optimizer step through the persistent batch kernels (forward + backward)
+for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (10000, torch.float32)):
+    base = torch.randn(32 * n + 4096, 512, device=dev).to(dt)
+    bags = [base[i * n:(i + 1) * n] for i in range(32)]
+    Q = torch.randn(12, 512, device=dev, requires_grad=True)
+    G = torch.randn(32, 12, 512, device=dev)
+    def bstep():
+        out = F.vlfan_cross_attention_bags(bags, Q)
+        (out * G).sum().backward()
+    for i in range(3): bstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20): bstep()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / 20 / 32 * 1e6
+    print(f"N={n} {str(dt)[6:]} x32 bags: batched fwd+bwd {us:8.2f} us/bag")

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "vlsa_vlfan_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_bwd_batch_prep_bytes": (c_size_t, [c_int, c_int]),
+    "vlsa_vlfan_backward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge_batch_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_head_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

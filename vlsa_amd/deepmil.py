@@ -158,6 +158,21 @@ class VLFAN(nn.Module):
             return visual_features, attn
         return visual_features
 
+    def forward_bags(self, bags):
+        """Differentiable forward over a list of bags (each [1, N_i, C] or [N_i, C]) sharing this encoder: the cross
+        attention of all bags runs in the persistent multi-bag kernels (forward and backward), the P x C tail as batched
+        torch ops.  Equals ``torch.cat([self(x) for x in bags])``; one training step of the reference
+        (runner/vlsa_handler.py:260-289) is 32 such bags.  Returns visual features [B, C]."""
+        if self.feat_proj is not None:
+            return torch.cat([self.forward(x if x.dim() == 3 else x[None]) for x in bags])
+        Q = self.get_query()
+        scale = float(self.coattn_logit_scale.exp())
+        outs = []
+        for i in range(0, len(bags), 64):
+            outs.append(VF.vlfan_cross_attention_bags(bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale))
+        pooled_out, _ = self.forward_query_pooling(torch.cat(outs))
+        return self.visual_adapter(pooled_out)
+
 
 class DeepMIL(nn.Module):
     """ABMIL-style encoder (model/deepmil.py:222-292): optional Feat_Projecter, mean / max / (gated-)attention pooling

@@ -329,6 +329,110 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
     return out, (A if want_attn else None)
 
 
+class _BagTable:
+    """Device-side descriptor table (pointer, N, row stride) of up to 64 bags for the batched kernels."""
+
+    def __init__(self, bags, D=512):
+        lib = nat.load()
+        B = len(bags)
+        if not (1 <= B <= lib.vlsa_batch_max_bags()):
+            raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_max_bags()}]")
+        host = torch.zeros(B, 3, dtype=torch.int64)
+        keep = []
+        for i, x in enumerate(bags):
+            _need_gpu(x)
+            x = _bag2d(x)
+            if x.shape[1] != D or (i > 0 and x.dtype != keep[0].dtype):
+                raise VlsaNativeError("the batched path takes bags with D == 512 and one dtype (bf16 or fp32) per batch")
+            keep.append(x)
+            host[i, 0], host[i, 1], host[i, 2] = x.data_ptr(), x.shape[0], (x.stride(0) if x.shape[0] > 0 else D)
+        self.bags, self.B, self.D = keep, B, D
+        self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
+        self.desc = host.to(keep[0].device, non_blocking=False)
+
+
+class _VlfanBatchAggregateFn(torch.autograd.Function):
+    """out[B, P, D] for B bags sharing the queries Q; differentiable w.r.t. Q (the bags carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, Q, gated, coattn_scale, table):
+        lib, s = nat.load(), _stream()
+        B, D = table.B, table.D
+        dev = table.desc.device
+        qp = prepare_queries(Q, gated, coattn_scale)
+        P = qp.P
+        ws = torch.empty(lib.vlsa_batch_workspace_bytes(B, P, D), dtype=torch.uint8, device=dev)
+        nat.check(lib.vlsa_vlfan_partial_batch(_p(table.desc), B, table.dt, D, _p(qp.buf), P, _p(ws), s),
+                  "vlsa_vlfan_partial_batch")
+        G = int(lib.vlsa_batch_partials_per_bag(B))
+        wf = ws.view(torch.float32)
+        pm, pl, pacc = wf, wf[B * G * nat.P_STRIDE:], wf[2 * B * G * nat.P_STRIDE:]
+        m2 = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        l = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        out = torch.empty(B, P, D, dtype=torch.float32, device=dev)
+        st = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D,
+                                  nat.P_STRIDE, nat.P_STRIDE, P * D)
+        nat.check(lib.vlsa_vlfan_merge_batch_strided(_p(pm), _p(pl), _p(pacc), B, G, P, D, 1, st, _p(m2), _p(l), _p(out), s),
+                  "vlsa_vlfan_merge_batch_strided")
+        ctx.save_for_backward(out, m2, l, qp.buf)
+        ctx.table = table
+        ctx.meta = (qp.nq, P, D, bool(gated), float(coattn_scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, m2, l, qbuf = ctx.saved_tensors
+        table = ctx.table
+        nq, P, D, gated, scale = ctx.meta
+        lib, s = nat.load(), _stream()
+        B, dev = table.B, out.device
+        dout = _f32c(dout)
+        if table.dt == nat.DT_BF16 and P <= 12:
+            G = 256
+            pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pacc = torch.empty(G, P, D, dtype=torch.float32, device=dev)
+            prep = torch.empty(lib.vlsa_bwd_batch_prep_bytes(B, D), dtype=torch.uint8, device=dev)
+            nat.check(lib.vlsa_vlfan_backward_batch(_p(table.desc), B, table.dt, D, _p(qbuf), P, scale, _p(dout), _p(out),
+                                                    _p(m2), _p(l), _p(prep), _p(pm), _p(pl), _p(pacc), s),
+                      "vlsa_vlfan_backward_batch")
+            _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
+        else:  # fp32 bags or P > 12: the per-bag kernel, partial sums of all bags reduced together
+            Gs = [num_partials(x.shape[0]) for x in table.bags]
+            Gt = sum(Gs)
+            pm = torch.empty(Gt, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pl = torch.empty(Gt, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pacc = torch.empty(Gt, P, D, dtype=torch.float32, device=dev)
+            prep = torch.empty(B, lib.vlsa_bwd_prep_bytes(D), dtype=torch.uint8, device=dev)
+            g0 = 0
+            for i, x in enumerate(table.bags):
+                if x.shape[0] == 0:
+                    continue
+                nat.check(lib.vlsa_vlfan_backward(_p(x), table.dt, x.shape[0], x.stride(0), D, _p(qbuf), P, scale,
+                                                  _p(dout[i]), _p(out[i]), _p(m2[i]), _p(l[i]), _p(prep[i]),
+                                                  _p(pm[g0:]), _p(pl[g0:]), _p(pacc[g0:]), s), "vlsa_vlfan_backward")
+                g0 += Gs[i]
+            if g0 == 0:
+                dE = torch.zeros(P, D, dtype=torch.float32, device=dev)
+            else:
+                _, _, dE = vlfan_merge(pm[:g0], pl[:g0], pacc[:g0], normalise=False)
+        qp = PreparedQueries(qbuf, nq, P, D, gated)
+        qhat, qnorm = qp.qhat, qp.qnorm
+        dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
+        dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
+        return dQ, None, None, None
+
+
+def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE):
+    """out[B, P, D]: ``vlfan_cross_attention`` for a list of up to 64 bags that share the queries, through the
+    persistent multi-bag kernels (forward and backward); what one optimizer step of the reference does bag by bag
+    (runner/vlsa_handler.py:260-289).  Bags: [N_i, 512] device tensors, N_i >= 1, one dtype per batch."""
+    table = _BagTable(bags)
+    if any(x.shape[0] == 0 for x in table.bags):
+        raise VlsaNativeError("empty bag in a batch")
+    return _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table)
+
+
 # ------------------------------------------------------------------------------------------------------
 # FeatMIL / DeepMIL / zero-shot pieces (model/deepmil.py:16-67,222-292; model/layers.py:85-153)
 # ------------------------------------------------------------------------------------------------------

@@ -140,15 +140,28 @@ class VLSA(nn.Module):
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
         return logits, image_features, text_features
 
-    @torch.no_grad()
     def forward_bags(self, bags):
-        """Inference over a list of independent bags (what the reference's eval loop does one bag at a time,
-        runner/vlsa_handler.py:315-345).  bf16 or fp32 bags with D == 512 and a fusable VLFAN go through the persistent
-        multi-bag kernel, up to 64 bags per launch; anything else falls back to per-bag ``forward``.
+        """A list of independent bags in one call (the reference loops bag by bag: eval runner/vlsa_handler.py:315-345,
+        training 260-289).  bf16 or fp32 bags with D == 512 and a VLFAN encoder go through the persistent multi-bag
+        kernels, up to 64 bags per launch: fully fused when no gradient is needed, HIP aggregation forward + backward with
+        a batched torch tail otherwise; anything else falls back to per-bag ``forward``.
         Returns (logits [B, K], image_features [B, D], text_features [K, D])."""
         enc = self.mil_encoder
-        spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         text_features = self.forward_text_only()
+        if self._needs_grad(text_features):
+            if (isinstance(enc, VLFAN) and len(bags) > 0 and all(x.is_cuda and x.shape[-1] == 512 and x.shape[-2] > 0 for x in bags)
+                    and all(x.dtype == bags[0].dtype for x in bags)):
+                text_n = F.normalize(text_features, dim=-1)
+                image_features = F.normalize(enc.forward_bags(bags), dim=-1)
+                return self.logit_scale.exp() * image_features @ text_n.t(), image_features, text_n
+            outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), outs[0][2]
+        with torch.no_grad():
+            return self._forward_bags_fused(bags, text_features)
+
+    def _forward_bags_fused(self, bags, text_features):
+        enc = self.mil_encoder
+        spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         flat = [VF._bag2d(x) for x in bags]
         ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512
                                                           and x.shape[0] > 0 for x in flat))
