@@ -234,6 +234,14 @@ int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const
  */
 int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, float* out, void* stream);
 
+/*
+ * Bag ingest (replaces the per-step host concat + blocking H2D of dataset/PatchWSI.py:205-215 / runner/vlsa_handler.py:205):
+ * pack N freshly uploaded rows (fp32 -> bf16 round-to-nearest-even, or bf16 copy) into a resident bf16 arena.
+ * src [N, lds], dst [N, ldd] device pointers, 16-byte aligned rows, D % 8 == 0.
+ */
+int vlsa_pack_rows_bf16(const void* src, int src_dtype, int64_t N, int64_t lds, int D, void* dst, int64_t ldd,
+                        void* stream);
+
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
 

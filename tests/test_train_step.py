@@ -68,13 +68,16 @@ def test_oracle_training_step_matches_reference():
             grads0 = dict(resid=leaves["resid"].grad.numpy().copy(), logit_scale=float(leaves["logit_scale"].grad))
             logits0 = preds.detach().numpy().copy()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         snap[step] = {k: (v.detach().numpy().copy() if v.dim() else float(v)) for k, v in leaves.items()}
     _check(fx, losses, grads0, logits0, snap)
 
 
 @pytest.mark.gpu
-def test_gpu_training_step_matches_reference():
+@pytest.mark.parametrize("batched", [False, True])
+def test_gpu_training_step_matches_reference(batched):
+    """batched=False: bag-by-bag forward as the reference loops; True: all bags of the step through forward_bags (the
+    persistent multi-bag forward + backward kernels).  Both must follow the reference's Adam trajectory."""
     from vlsa_amd.prompt_adapter import PromptAdapter
     from vlsa_amd.vlsa import VLSA
     fx = H.load_fixture("train_step")
@@ -104,7 +107,7 @@ def test_gpu_training_step_matches_reference():
     t, e = torch.tensor(CFG["t"]).cuda(), torch.tensor(CFG["e"]).float().cuda()
     losses, snap, grads0, logits0 = [], {}, None, None
     for step in range(CFG["steps"]):
-        preds = torch.cat([model(x[None])[0] for x in bags], dim=0)
+        preds = model.forward_bags(bags)[0] if batched else torch.cat([model(x[None])[0] for x in bags], dim=0)
         loss = O.vlsa_objective(preds, t, e, model.get_logit_scale())   # host-side loss: plain torch ops on [4, K]
         opt.zero_grad()
         loss.backward()
@@ -112,6 +115,6 @@ def test_gpu_training_step_matches_reference():
             grads0 = dict(resid=enc.Q.residual_features.grad.cpu().numpy().copy(), logit_scale=float(model.logit_scale.grad))
             logits0 = preds.detach().cpu().numpy().copy()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         snap[step] = {k: (v.detach().cpu().numpy().copy() if v.dim() else float(v)) for k, v in named}
     _check(fx, losses, grads0, logits0, snap)

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "vlsa_head_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "vlsa_pack_rows_bf16": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "vlsa_pool_num_partials": (c_int, [c_int64]),
     "vlsa_scored_pool_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
