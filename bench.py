@@ -82,8 +82,8 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=640)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=12800)
+    ap.add_argument("--warmup", type=int, default=2560)
     ap.add_argument("--bags-per-launch", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,7 +170,7 @@ def main():
     if rank == 0:
         base = plans[BPL][0].local if hasattr(plans[BPL][0], "local") else plans[BPL][0]
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-        for _ in range(3):
+        for _ in range(24):  # the event set-up above idled the GPU: let the clocks ramp back up (takes a few ms)
             base.run_partial_only()
         torch.cuda.synchronize()
         for e0, e1 in ev:

@@ -194,6 +194,18 @@ int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, c
 int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
                                    int normalise, const int64_t* strides9, float* m2, float* l, float* out, void* stream);
 
+/*
+ * Final merge + head of a batch in three ticket-free launches: log-sum-exp merge of G partial records per bag fused with the
+ * query pooling (model/deepmil.py:133-150,203), v = W pooled + b for all bags (W rows kept in registers across 8 bags,
+ * model/deepmil.py:204), then normalise + cosine logits + incidence per bag (model/vlsa.py:188-192).  strides9 as in
+ * vlsa_vlfan_merge_batch_strided.  pool_mode MEAN / MAX / WEIGHT.  Outputs [B, ...].
+ */
+int vlsa_vlfan_merge_head_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
+                                        const int64_t* strides9, int pool_mode, const float* pool_w, const float* W,
+                                        const float* b, const float* That, int K, const float* logit_scale, float* m2,
+                                        float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
+                                        float* logits, float* incidence, void* stream);
+
 /* vlsa_head_forward for B bags in one launch: rows [B,P,D]; counters: B zeroed uint32; outputs [B, ...]. */
 int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
                             const float* b, const float* That, int K, const float* logit_scale, void* counters,

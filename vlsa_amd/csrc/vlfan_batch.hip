@@ -392,7 +392,7 @@ struct MergeStrides {
     int64_t om, ol, oo;  // between bags, outputs
 };
 
-__global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restrict__ pm, const float* __restrict__ pl,
+__global__ __launch_bounds__(256, 5) void k_vlfan_merge_batch(const float* __restrict__ pm, const float* __restrict__ pl,
                                                             const float* __restrict__ pacc, int G, int P, int D,
                                                             int normalise, float* __restrict__ m2, float* __restrict__ l,
                                                             float* __restrict__ out, MergeStrides st) {
@@ -407,10 +407,10 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restri
     pm += (size_t)bag * st.bm;
     pl += (size_t)bag * st.bl;
     pacc += (size_t)bag * st.ba;
-    const int c4 = tid & 127, gs = tid >> 7;
+    const int c4 = tid & 127, gs = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: partial indices stay scalar
     const int col = c0 + c4 * 4;
     const bool incol = col < D;
-    constexpr int U = 16;
+    constexpr int U = 16;  // <= 96 VGPRs so the kernel can co-reside with a persistent streaming kernel (2 x 208 of 512 VGPRs per SIMD taken)
     float mx = -INFINITY;
     for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * st.sm + p]);
     mx = wave_max(mx);
@@ -459,6 +459,109 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_batch(const float* __restri
     }
 }
 
+// Merge + query pooling in one pass (the batched forward's tail): workgroup (cc, bag) owns 64 columns of ALL P queries of
+// a bag -- thread (gs = tid >> 8, p = (tid >> 4) & 15, c4 = tid & 15) folds every second partial piece of query p, float4
+// column c4 -- so the pooled vector (mean / max / softmax(weight) over the queries, model/deepmil.py:133-150) is formed
+// right here from LDS instead of every head workgroup re-reading the P x D rows.  The p order of the pooling sum is fixed.
+// <= 96 VGPRs: may co-reside with a persistent streaming kernel of another stream.
+__global__ __launch_bounds__(512, 4) void k_vlfan_merge_pool_batch(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                    const float* __restrict__ pacc, int G, int P, int D,
+                                                                    float* __restrict__ m2, float* __restrict__ l,
+                                                                    float* __restrict__ out, MergeStrides st, int pool_mode,
+                                                                    const float* __restrict__ pool_w,
+                                                                    float* __restrict__ pooled) {
+    __shared__ __attribute__((aligned(16))) float4 sacc[VLSA_MAX_P][16];
+    __shared__ float slt[VLSA_MAX_P][16];
+    __shared__ float spw[VLSA_MAX_P];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int gs = tid >> 8, p = (tid >> 4) & 15, c4 = tid & 15, bag = blockIdx.y;
+    const int col = blockIdx.x * 64 + c4 * 4;
+    const bool live = p < P && col < D;
+    pm += (size_t)bag * st.bm + p;
+    pl += (size_t)bag * st.bl + p;
+    pacc += (size_t)bag * st.ba + (size_t)p * D + col;
+    if (pool_mode == VLSA_POOL_WEIGHT && tid == 0) {
+        float mx = -INFINITY, sum = 0.f;
+        for (int q = 0; q < P; ++q) mx = fmaxf(mx, pool_w[q]);
+        for (int q = 0; q < P; ++q) { spw[q] = expf(pool_w[q] - mx); sum += spw[q]; }
+        for (int q = 0; q < P; ++q) spw[q] /= sum;
+    }
+    constexpr int U = 8;
+    float mx = -INFINITY;
+    if (p < P)
+        for (int g = 0; g < G; ++g) mx = fmaxf(mx, pm[(size_t)g * st.sm]);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = 0.f;
+    for (int g0 = gs; g0 < G; g0 += 2 * U) {
+        float mg[U], lg[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int g = g0 + 2 * u;
+            const bool ok = live && g < G;
+            mg[u] = ok ? pm[(size_t)g * st.sm] : -INFINITY;
+            lg[u] = ok ? pl[(size_t)g * st.sl] : 0.f;
+            v[u] = ok ? *reinterpret_cast<const float4*>(pacc + (size_t)g * st.sa) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float f = (mg[u] == -INFINITY) ? 0.f : fast_exp2(mg[u] - mx);
+            lt += lg[u] * f;
+            a.x += v[u].x * f; a.y += v[u].y * f; a.z += v[u].z * f; a.w += v[u].w * f;
+        }
+    }
+    if (gs == 1) {
+        sacc[p][c4] = a;
+        slt[p][c4] = lt;
+    }
+    __syncthreads();
+    if (gs == 0) {
+        const float4 o = sacc[p][c4];
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        lt += slt[p][c4];
+        if (live) {
+            const float inv = 1.f / lt;
+            a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+            *reinterpret_cast<float4*>(out + (size_t)bag * st.oo + (size_t)p * D + col) = a;
+            if (blockIdx.x == 0 && c4 == 0) {
+                m2[(size_t)bag * st.om + p] = mx;
+                l[(size_t)bag * st.ol + p] = lt;
+            }
+        }
+    }
+    if (pooled == nullptr) return;
+    __syncthreads();
+    if (gs == 0) sacc[p][c4] = a;
+    __syncthreads();
+    if (tid < 16 && col < D) {
+        float4 r;
+        if (pool_mode == VLSA_POOL_MAX) {
+            r = sacc[0][tid];
+            for (int q = 1; q < P; ++q) {
+                const float4 o = sacc[q][tid];
+                r.x = fmaxf(r.x, o.x); r.y = fmaxf(r.y, o.y); r.z = fmaxf(r.z, o.z); r.w = fmaxf(r.w, o.w);
+            }
+        } else if (pool_mode == VLSA_POOL_WEIGHT) {
+            r = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < P; ++q) {
+                const float4 o = sacc[q][tid];
+                const float wq = spw[q];
+                r.x += wq * o.x; r.y += wq * o.y; r.z += wq * o.z; r.w += wq * o.w;
+            }
+        } else {  // mean: left-to-right sum, then / P (as pooled_col in vlfan_tail.hip)
+            r = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < P; ++q) {
+                const float4 o = sacc[q][tid];
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            const float fp = (float)P;
+            r.x /= fp; r.y /= fp; r.z /= fp; r.w /= fp;
+        }
+        *reinterpret_cast<float4*>(pooled + (size_t)bag * D + col) = r;
+    }
+}
+
 }  // namespace vlsa
 
 using namespace vlsa;
@@ -467,6 +570,9 @@ int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode
                            const float* b, const float* That, int K, const float* logit_scale, unsigned int* counters,
                            float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
                            hipStream_t s);  // vlfan_tail.hip
+int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float* W, const float* b, const float* That, int K,
+                                  const float* logit_scale, float* v, float* vhat, float* vnorm, float* logits,
+                                  float* incidence, hipStream_t s);  // vlfan_tail.hip
 
 #ifdef VLSA_TIMING
 extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
@@ -534,10 +640,14 @@ extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype
                                                              vlsa_batch_workspace_bytes(B, P, D) - (size_t)B * 64);
     const MergeStrides st{kPStride, kPStride, (int64_t)P * D, (int64_t)G * kPStride, (int64_t)G * kPStride,
                           (int64_t)G * P * D, kPStride, kPStride, (int64_t)P * D};
-    hipLaunchKernelGGL(k_vlfan_merge_batch, dim3((D + 511) / 512, P, B), dim3(256), 0, s, pm, pl, pacc, G, P, D, 1, m2, l, out, st);
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    // merge + pooling in one kernel; the head then starts from the pooled vectors (2 KB instead of P x 2 KB per workgroup)
+    hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
+                       pool_mode, pool_w, pooled);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-    return vlsa_launch_head_batch(out, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, counters, pooled, v, vhat, vnorm,
-                                  logits, incidence, s);
+    (void)counters;
+    return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
 }
 
 extern "C" int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
@@ -551,6 +661,25 @@ extern "C" int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, 
     hipLaunchKernelGGL(k_vlfan_merge_batch, dim3((D + 511) / 512, P, B), dim3(256), 0, (hipStream_t)stream, pm, pl, pacc, G, P, D,
                        normalise, m2, l, out, st);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_vlfan_merge_head_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,
+                                                   const int64_t* strides9, int pool_mode, const float* pool_w, const float* W,
+                                                   const float* b, const float* That, int K, const float* logit_scale, float* m2,
+                                                   float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
+                                                   float* logits, float* incidence, void* stream) {
+    if (!pm || !pl || !pacc || !strides9 || !m2 || !l || !out || !pooled || !v || !vhat || !vnorm || !logits || !That || !logit_scale)
+        return VLSA_EINVAL;
+    if (B < 1 || G < 1 || P < 1 || P > VLSA_MAX_P || D < 4 || (D % 4) != 0 || D > VLSA_MAX_D || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT || (pool_mode == VLSA_POOL_WEIGHT && !pool_w)) return VLSA_EINVAL;
+    MergeStrides st{strides9[0], strides9[1], strides9[2], strides9[3], strides9[4], strides9[5], strides9[6], strides9[7], strides9[8]};
+    if ((st.sa % 4) || (st.ba % 4) || (st.oo % 4) || (reinterpret_cast<uintptr_t>(pacc) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
+                       pool_mode, pool_w, pooled);
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
 }
 
 extern "C" int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,

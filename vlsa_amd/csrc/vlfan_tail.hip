@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
                                                const float* __restrict__ pool_w, const float* __restrict__ W,
                                                const float* __restrict__ bias, const float* __restrict__ That, int K,
                                                const float* __restrict__ logit_scale, unsigned int* counter,
-                                               float* __restrict__ pooled, float* v, float* __restrict__ vhat,
+                                               float* pooled, float* v, float* __restrict__ vhat,
                                                float* __restrict__ vnorm, float* __restrict__ logits,
                                                float* __restrict__ incidence, int NB) {
     __shared__ float sp[VLSA_MAX_D];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     for (int c = tid; c < D; c += 256) {
         const float pc = pooled_col(rows, P, D, c, pool_mode, spw);
         sp[c] = pc;
-        if (blockIdx.x == 0) pooled[c] = pc;
+        if (blockIdx.x == 0 && pooled != rows) pooled[c] = pc;  // rows == pooled: already pooled by the merge kernel
     }
     __syncthreads();
 
@@ -258,6 +258,103 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
         for (int k = 0; k < K; ++k) incidence[k] = expf(slog[k] - mx) / s;
     }
     if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ticket back to zero
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched head in two ticket-free kernels (the batch path has the pooled vectors from the merge kernel):
+//   k_head_linear: v[bag] = W pooled[bag] + b.  grid (D/8, ceil(B/8)): a workgroup keeps 8 rows of W in registers
+//                  (2 per wave) and walks 8 bags, whose pooled vectors are all loaded up front (one L2 round trip).
+//   k_head_finish: one workgroup per bag: v^ = v / max(|v|, eps); logits = exp(ls) v^ . T^_k; incidence = softmax.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kHeadBagsPerBlock = 8;
+
+__global__ __launch_bounds__(256) void k_head_linear(const float* __restrict__ pooled, int B, int D,
+                                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                                      float* __restrict__ v) {
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bag0 = blockIdx.y * kHeadBagsPerBlock;
+    float4 wq[2][VLSA_MAX_D / 256];
+    float bj[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int j = blockIdx.x * kHeadRowsPerBlock + wv * 2 + rr;
+#pragma unroll
+        for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+            const int c = lane * 4 + 256 * i;
+            wq[rr][i] = (j < D && c < D) ? *reinterpret_cast<const float4*>(W + (size_t)j * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (j < D && bias != nullptr) bj[rr] = bias[j];
+    }
+    float4 x[kHeadBagsPerBlock][VLSA_MAX_D / 256];
+#pragma unroll
+    for (int t = 0; t < kHeadBagsPerBlock; ++t)
+#pragma unroll
+        for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+            const int c = lane * 4 + 256 * i;
+            x[t][i] = (bag0 + t < B && c < D) ? *reinterpret_cast<const float4*>(pooled + (size_t)(bag0 + t) * D + c)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int t = 0; t < kHeadBagsPerBlock; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VLSA_MAX_D / 256; ++i)
+                s += wq[rr][i].x * x[t][i].x + wq[rr][i].y * x[t][i].y + wq[rr][i].z * x[t][i].z + wq[rr][i].w * x[t][i].w;
+            s = wave_sum(s);
+            const int j = blockIdx.x * kHeadRowsPerBlock + wv * 2 + rr;
+            if (lane == 0 && j < D && bag0 + t < B) v[(size_t)(bag0 + t) * D + j] = s + bj[rr];
+        }
+}
+
+__global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v, int D, const float* __restrict__ That, int K,
+                                                      const float* __restrict__ logit_scale, float* __restrict__ vhat,
+                                                      float* __restrict__ vnorm, float* __restrict__ logits,
+                                                      float* __restrict__ incidence) {
+    __shared__ float sp[VLSA_MAX_D];
+    __shared__ float slog[VLSA_MAX_K];
+    __shared__ float red[4];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, bag = blockIdx.x;
+    v += (size_t)bag * D;
+    vhat += (size_t)bag * D;
+    logits += (size_t)bag * K;
+    float ss = 0.f;
+    for (int c = tid; c < D; c += 256) {
+        const float x = v[c];
+        sp[c] = x;
+        ss += x * x;
+    }
+    ss = block_sum_256(ss, red);
+    const float nrm = fmaxf(sqrtf(ss), kNormEps);
+    for (int c = tid; c < D; c += 256) {
+        const float u = sp[c] / nrm;
+        sp[c] = u;
+        vhat[c] = u;
+    }
+    if (tid == 0) vnorm[bag] = nrm;
+    __syncthreads();
+    const float ls = expf(logit_scale[0]);
+    for (int k = wv; k < K; k += 4) {
+        const float* tk = That + (size_t)k * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += sp[c] * tk[c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float lg = ls * s;
+            logits[k] = lg;
+            slog[k] = lg;
+        }
+    }
+    __syncthreads();
+    if (incidence != nullptr && tid == 0) {
+        float mx = -INFINITY, s = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, slog[k]);
+        for (int k = 0; k < K; ++k) s += expf(slog[k] - mx);
+        for (int k = 0; k < K; ++k) incidence[(size_t)bag * K + k] = expf(slog[k] - mx) / s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -380,6 +477,22 @@ int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode
     // and walked 8 bags per workgroup measured 2x slower: the per-bag chain, not the W traffic, is the cost)
     hipLaunchKernelGGL(k_head, dim3(NB, B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, W, b, That, K, logit_scale,
                        counters, pooled, v, vhat, vnorm, logits, incidence, NB);
+    return launch_status();
+}
+
+// Batched head from already pooled vectors (pooled: [B, D]); v = pooled when W == nullptr (Identity head).
+int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float* W, const float* b, const float* That, int K,
+                                  const float* logit_scale, float* v, float* vhat, float* vnorm, float* logits,
+                                  float* incidence, hipStream_t s) {
+    const float* vin = pooled;
+    if (W != nullptr) {
+        hipLaunchKernelGGL(k_head_linear, dim3((D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock, (B + kHeadBagsPerBlock - 1) / kHeadBagsPerBlock),
+                           dim3(256), 0, s, pooled, B, D, W, b, v);
+        vin = v;
+    } else {
+        if (hipMemcpyAsync(v, pooled, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VLSA_ELAUNCH;
+    }
+    hipLaunchKernelGGL(k_head_finish, dim3(B), dim3(256), 0, s, vin, D, That, K, logit_scale, vhat, vnorm, logits, incidence);
     return launch_status();
 }
 

@@ -203,15 +203,14 @@ class ShardedVlfanBatchPlan:
     def _tail(self, slot, T, ls, W, b, pool_w):
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         g = self.gathered[slot].data_ptr()
-        c(lib.vlsa_vlfan_merge_batch_strided(ctypes.c_void_p(g), ctypes.c_void_p(g + 4 * nat.P_STRIDE),
-                                             ctypes.c_void_p(g + 4 * REC_HDR), self.B, self.world, self.P, self.D, 1,
-                                             self._st_global, p(pl_.m2), p(pl_.l), p(pl_.out), s), "merge_batch(global)")
         c(lib.vlsa_normalize_rows(p(T), self.K, self.D, p(pl_.That), p(pl_.tnorm), s), "normalize_rows")
-        counters = ctypes.c_void_p(pl_.ws.data_ptr() + pl_.ws.numel() - self.B * 64)
-        c(lib.vlsa_head_forward_batch(p(pl_.out), self.B, self.P, self.D, pl_.pool, p(pool_w),
-                                      None if pl_.identity_head else p(W), None if pl_.identity_head else p(b),
-                                      p(pl_.That), self.K, p(ls), counters, p(pl_.pooled), p(pl_.v), p(pl_.vhat),
-                                      p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s), "head_forward_batch")
+        c(lib.vlsa_vlfan_merge_head_batch_strided(ctypes.c_void_p(g), ctypes.c_void_p(g + 4 * nat.P_STRIDE),
+                                                  ctypes.c_void_p(g + 4 * REC_HDR), self.B, self.world, self.P, self.D,
+                                                  self._st_global, pl_.pool, p(pool_w),
+                                                  None if pl_.identity_head else p(W), None if pl_.identity_head else p(b),
+                                                  p(pl_.That), self.K, p(ls), p(pl_.m2), p(pl_.l), p(pl_.out), p(pl_.pooled),
+                                                  p(pl_.v), p(pl_.vhat), p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s),
+          "merge_head_batch(global)")
 
     def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
         slot = self._i & 1
