@@ -23,10 +23,16 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
         if "partial_dma_batch" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        v = v[4:] or v            # skip warm-up launches
+        v = v[8:] or v            # skip warm-up launches
         out[k] = sum(v) / len(v)
 json.dump(out, open("$O/pmc_batch_kernel.json", "w"), indent=1)
 print(out)
 PY
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python tools/prof_train.py > /dev/null 2>&1
+cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv
+python tools/bench_train.py > $O/bench_train.txt 2>&1
+python tools/bench_ingest.py > $O/bench_ingest.txt 2>&1
+python tools/kbench_batch_f32.py > $O/kbench_batch_f32.txt 2>&1
+VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2>/dev/null
+rm -rf $O/train $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
 cat $O/pytest_gpu.txt; cat $O/bench.json | cut -c1-600

@@ -12,6 +12,6 @@ W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls
 plan = F.VlfanBatchPlan(B, 12, 4, dev)
 plan.set_bags(bags)
 plan.run(Q, T, ls, W, b)
-for _ in range(8):
+for _ in range(40):
     plan.run_partial_only()
 torch.cuda.synchronize()
