@@ -254,6 +254,18 @@ int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, flo
 int vlsa_pack_rows_bf16(const void* src, int src_dtype, int64_t N, int64_t lds, int D, void* dst, int64_t ldd,
                         void* stream);
 
+/*
+ * Loss tail of the training step on [B, K] bag predictions, value and gradient in one launch:
+ * SurvIFMLE (loss/loss_surv.py:144-169: alpha, eps) and SurvEMD (loss/loss_surv_ext.py:43-109: p in {1, 2}, raw_distance;
+ * logit_scale_exp = device pointer to exp(logit_scale), treated as a constant as the reference detaches it).
+ * x: raw logits (from_logits = 1: the softmax converter of runner/vlsa_handler.py:245 is fused in) or incidences.
+ * t: int64 bin per sample, e: 1 = event, 0 = censored.  out_ifmle / out_emd: per-sample losses [B] (either may be NULL);
+ * grad [B, K] = d (w_ifmle * ifmle_i + w_emd * emd_i) / d x[i, :]  (NULL to skip).  K <= 64.
+ */
+int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, int B, int K, int from_logits,
+                   const float* logit_scale_exp, float alpha, float eps, int p, int raw_distance, float w_ifmle,
+                   float w_emd, float* out_ifmle, float* out_emd, float* grad, void* stream);
+
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
 

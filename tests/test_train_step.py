@@ -74,10 +74,13 @@ def test_oracle_training_step_matches_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batched", [False, True])
-def test_gpu_training_step_matches_reference(batched):
+@pytest.mark.parametrize("batched,fused_loss", [(False, False), (True, False), (True, True)])
+def test_gpu_training_step_matches_reference(batched, fused_loss):
     """batched=False: bag-by-bag forward as the reference loops; True: all bags of the step through forward_bags (the
-    persistent multi-bag forward + backward kernels).  Both must follow the reference's Adam trajectory."""
+    persistent multi-bag forward + backward kernels).  fused_loss: the IF-MLE + EMD loss tail from vlsa_amd.losses (one
+    kernel for value + gradient) instead of torch ops.  All must follow the reference's Adam trajectory."""
+    from vlsa_amd.losses import SurvObjective
+    objective = SurvObjective()
     from vlsa_amd.prompt_adapter import PromptAdapter
     from vlsa_amd.vlsa import VLSA
     fx = H.load_fixture("train_step")
@@ -108,7 +111,8 @@ def test_gpu_training_step_matches_reference(batched):
     losses, snap, grads0, logits0 = [], {}, None, None
     for step in range(CFG["steps"]):
         preds = model.forward_bags(bags)[0] if batched else torch.cat([model(x[None])[0] for x in bags], dim=0)
-        loss = O.vlsa_objective(preds, t, e, model.get_logit_scale())   # host-side loss: plain torch ops on [4, K]
+        loss = (objective(preds, t, e, model.get_logit_scale()) if fused_loss else
+                O.vlsa_objective(preds, t, e, model.get_logit_scale()))   # host-side loss: plain torch ops on [4, K]
         opt.zero_grad()
         loss.backward()
         if step == 0:

@@ -71,6 +71,8 @@ _SIGNATURES = {
                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
     "vlsa_pack_rows_bf16": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "vlsa_surv_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_int, c_int,
+                               c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_pool_num_partials": (c_int, [c_int64]),
     "vlsa_scored_pool_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),

@@ -1,0 +1,122 @@
+// On-device loss tail of the training step: SurvIFMLE (loss/loss_surv.py:127-169) and SurvEMD
+// (loss/loss_surv_ext.py:43-109, cdf_loss 13-38) on the [B, K] bag predictions, forward AND gradient in one launch, from
+// the raw logits (the handler's softmax converter, runner/vlsa_handler.py:241-258, fused in) or from incidences.
+// The reference spends ~40 elementwise launches and a Python loop over the batch (convert_survival_label) on this.
+// One thread per sample; K <= 64 values live in registers / scratch -- the work is a few hundred flops per sample.
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+__global__ __launch_bounds__(64) void k_surv_loss(const float* __restrict__ x, const int64_t* __restrict__ t_,
+                                                   const float* __restrict__ e_, int B, int K, int from_logits,
+                                                   const float* __restrict__ logit_scale_exp, float alpha, float eps, int p,
+                                                   int raw_distance, float w_ifmle, float w_emd,
+                                                   float* __restrict__ out_ifmle, float* __restrict__ out_emd,
+                                                   float* __restrict__ grad) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= B) return;
+    float inc[VLSA_MAX_K], g[VLSA_MAX_K];
+    const float* xi = x + (size_t)i * K;
+    int t = (int)t_[i];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    const float e = e_[i];
+    // ---- incidence: softmax over the K bins (utils/func.py:43-44) or the given values
+    if (from_logits) {
+        float mx = -INFINITY, s = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, xi[k]);
+        for (int k = 0; k < K; ++k) { inc[k] = expf(xi[k] - mx); s += inc[k]; }
+        for (int k = 0; k < K; ++k) inc[k] /= s;
+    } else {
+        for (int k = 0; k < K; ++k) inc[k] = xi[k];
+    }
+    for (int k = 0; k < K; ++k) g[k] = 0.f;
+
+    // ---- SurvIFMLE: (1 - alpha) (censored + uncensored) + alpha uncensored, per sample
+    float l_ifmle = 0.f;
+    {
+        const float c = 1.f - e;
+        float cif = 0.f;
+        for (int k = 0; k <= t; ++k) cif += inc[k];
+        const float a = inc[t], sv = 1.f - cif;
+        const float unc = -(1.f - c) * logf(fmaxf(a, eps));
+        const float cen = -c * logf(fmaxf(sv, eps));
+        l_ifmle = (1.f - alpha) * (cen + unc) + alpha * unc;
+        if (w_ifmle != 0.f) {
+            if (a >= eps) g[t] += w_ifmle * (-(1.f - c) / a);          // d unc / d inc[t]; clamp passes the gradient at >= eps
+            if (sv >= eps) {
+                const float gc = w_ifmle * (1.f - alpha) * c / sv;     // d cen / d inc[k], k <= t
+                for (int k = 0; k <= t; ++k) g[k] += gc;
+            }
+        }
+    }
+
+    // ---- SurvEMD on y = incidence
+    float l_emd = 0.f;
+    if (w_emd != 0.f || out_emd != nullptr) {
+        const float ls = logit_scale_exp[0];
+        const int ei = (int)e;  // e.long() of the reference
+        float pd[VLSA_MAX_K], td[VLSA_MAX_K], dp[VLSA_MAX_K];
+        float mp = -INFINITY, mt = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float tg = (k == t ? 1.f : 0.f) + (k > t ? (float)(1 - ei) : 0.f);   // convert_survival_label
+            td[k] = (2.f * tg - 1.f) * ls;
+            pd[k] = (float)(1 - ei) * ((1.f - tg) * inc[k] + tg * ls) + (float)ei * inc[k];
+            dp[k] = (float)(1 - ei) * (1.f - tg) + (float)ei;                               // d pred / d y
+            mp = fmaxf(mp, pd[k]);
+            mt = fmaxf(mt, td[k]);
+        }
+        float sp = 0.f, st = 0.f;
+        for (int k = 0; k < K; ++k) { pd[k] = expf(pd[k] - mp); sp += pd[k]; td[k] = expf(td[k] - mt); st += td[k]; }
+        float cp = 0.f, ct = 0.f, S = 0.f;
+        for (int k = 0; k < K; ++k) {
+            pd[k] /= sp;
+            cp += pd[k];
+            ct += td[k] / st;
+            const float d = cp - ct;
+            td[k] = d;                                   // td now holds the cdf difference
+            S += (p == 1) ? fabsf(d) : d * d;
+        }
+        const bool root = (p == 2 && !raw_distance);
+        l_emd = root ? sqrtf(S) : S;
+        if (w_emd != 0.f) {
+            const float outer = root ? (S > 0.f ? 0.5f / sqrtf(S) : 0.f) : 1.f;
+            // r_j = d dist / d pd_j = suffix sum of d S / d d_k
+            float r = 0.f, dot = 0.f;
+            for (int k = K - 1; k >= 0; --k) {
+                const float d = td[k];
+                r += (p == 1) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d;
+                td[k] = r;
+                dot += pd[k] * r;
+            }
+            for (int k = 0; k < K; ++k) g[k] += w_emd * outer * pd[k] * (td[k] - dot) * dp[k];
+        }
+    }
+
+    if (out_ifmle != nullptr) out_ifmle[i] = l_ifmle;
+    if (out_emd != nullptr) out_emd[i] = l_emd;
+    if (grad != nullptr) {
+        float* gi = grad + (size_t)i * K;
+        if (from_logits) {  // softmax backward to the raw logits
+            float dot = 0.f;
+            for (int k = 0; k < K; ++k) dot += inc[k] * g[k];
+            for (int k = 0; k < K; ++k) gi[k] = inc[k] * (g[k] - dot);
+        } else {
+            for (int k = 0; k < K; ++k) gi[k] = g[k];
+        }
+    }
+}
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+extern "C" int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, int B, int K, int from_logits,
+                              const float* logit_scale_exp, float alpha, float eps, int p, int raw_distance, float w_ifmle,
+                              float w_emd, float* out_ifmle, float* out_emd, float* grad, void* stream) {
+    if (!x || !t || !e || B < 1 || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    if ((w_emd != 0.f || out_emd) && !logit_scale_exp) return VLSA_EINVAL;
+    if (p != 1 && p != 2) return VLSA_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_surv_loss, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, t, e, B, K, from_logits, logit_scale_exp,
+                       alpha, eps, p, raw_distance, w_ifmle, w_emd, out_ifmle, out_emd, grad);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
