@@ -168,10 +168,17 @@ size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE af
  * the batched merge + the batched head. */
 int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, void* workspace,
                              void* stream);
+/* Same, leaving `reserved_cus` compute units (rounded up to a multiple of the bags in flight) without a persistent workgroup,
+ * so that communication kernels of another stream (RCCL all-gather of the multi-GPU path) can run concurrently: next to a
+ * persistent workgroup only kernels with <= 96 VGPRs and <= 8 KiB LDS get scheduled.  Partials per bag change accordingly. */
+int vlsa_batch_partials_per_bag_reserved(int B, int reserved_cus);
+int vlsa_vlfan_partial_batch_reserved(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                      void* workspace, int reserved_cus, void* stream);
 int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, int pool_mode,
                              const float* pool_w, const float* W, const float* b, const float* That, int K,
                              const float* logit_scale, void* workspace, float* m2, float* l, float* out, float* pooled,
-                             float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
+                             float* v, float* vhat, float* vnorm, float* logits, float* incidence, int reserved_cus,
+                             void* stream);
 
 /*
  * Backward of the aggregation for a BATCH of bags w.r.t. the (shared) effective queries -- one training step of the

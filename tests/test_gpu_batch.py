@@ -42,3 +42,36 @@ def test_batch_equals_single_bag_and_oracle(sizes, dtype):
             cpu = O.vlsa_vlfan_forward(bags[i].float().cpu(), Q.cpu(), T.cpu(), ls.cpu(), head_weight=W.cpu(), head_bias=b.cpu())
             assert (plan.logits[i].cpu() - cpu["logits"][0]).abs().max().item() < 1e-4, (i, n)
             assert (plan.incidence[i].cpu() - cpu["incidence"][0]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("reserved", [8, 13, 250, 1000])
+def test_partial_batch_with_reserved_cus(reserved, dtype):
+    """Fewer persistent workgroups (CUs left free for communication kernels): same partial merge result."""
+    import ctypes
+    from vlsa_amd import functional as F, _native as nat
+    dev = torch.device("cuda", 0)
+    P, K = 12, 4
+    sizes = [5000, 64, 3333, 70, 9000, 1, 640, 2798, 100]
+    bags = [cases.make_bag(n, 500 + i).to(dtype).to(dev) for i, n in enumerate(sizes)]
+    params = cases.make_params(P, K, 510)
+    Q = (0.5 * params["resid"] + params["prompt"]).to(dev)
+    plan = F.VlfanBatchPlan(len(sizes), P, K, dev)
+    plan.set_bags(bags)
+    plan.run(Q, params["T"].to(dev), torch.tensor(cases.LOGIT_SCALE, device=dev), params["W"].to(dev), params["b"].to(dev))
+    ref_out = plan.out.clone()
+    lib, B, D = nat.load(), len(sizes), 512
+    G = lib.vlsa_batch_partials_per_bag_reserved(B, reserved)
+    assert 1 <= G <= 32 and G == max(1, (256 - (min(reserved, 248) + 7) // 8 * 8) // 8)
+    plan.ws.zero_()
+    nat.check(lib.vlsa_vlfan_partial_batch_reserved(F._p(plan.desc), B, plan.dt, D, F._p(plan.qprep), P, F._p(plan.ws), reserved,
+                                                    F._stream()), "partial_batch_reserved")
+    wf = plan.ws.view(torch.float32)
+    n_ml = B * G * nat.P_STRIDE
+    st = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D,
+                              nat.P_STRIDE, nat.P_STRIDE, P * D)
+    m2, l, out = torch.empty(B, 16, device=dev), torch.empty(B, 16, device=dev), torch.empty(B, P, D, device=dev)
+    nat.check(lib.vlsa_vlfan_merge_batch_strided(F._p(wf), F._p(wf[n_ml:]), F._p(wf[2 * n_ml:]), B, G, P, D, 1, st, F._p(m2),
+                                                 F._p(l), F._p(out), F._stream()), "merge")
+    torch.cuda.synchronize()
+    assert (out - ref_out).abs().max().item() < 2e-5 * max(1.0, ref_out.abs().max().item())

@@ -75,8 +75,9 @@ def test_sharded_plan_over_one_rank_rccl_group():
                 assert (g - r).abs().max().item() < 1e-5, pipeline
         # batched sharded plan (B bags per launch, one all-gather per batch)
         from vlsa_amd.sharded import ShardedVlfanBatchPlan
-        for pipeline in (False, True):
-            bp = ShardedVlfanBatchPlan(3, P, K, dev, dist, pipeline=pipeline)
+        for pipeline, reserved in ((False, None), (True, None), (True, 8), (True, 100)):
+            # reserved: CUs left without a persistent workgroup (room for RCCL next to the streaming kernel)
+            bp = ShardedVlfanBatchPlan(3, P, K, dev, dist, pipeline=pipeline, reserved_cus=reserved)
             bp.set_bags(bags)
             bp.run(Q, T, ls, W, b)
             bp.run(Q, T, ls, W, b)

@@ -582,7 +582,19 @@ extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
 
 // bags streamed concurrently (each by 256 / S workgroups)
 static inline int batch_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
+// workgroups of the persistent kernels when `reserved_cus` CUs are to stay free for concurrently running communication
+// kernels (RCCL needs CUs; next to a persistent workgroup only kernels with <= 96 VGPRs / 8 KiB LDS get scheduled)
+static inline int batch_workgroups(int B, int reserved_cus) {
+    const int S = batch_groups(B);
+    int r = reserved_cus < 0 ? 0 : reserved_cus;
+    r = (r + S - 1) / S * S;
+    if (r > 256 - S) r = 256 - S;
+    return 256 - r;
+}
 extern "C" int vlsa_batch_partials_per_bag(int B) { return 256 / batch_groups(B); }
+extern "C" int vlsa_batch_partials_per_bag_reserved(int B, int reserved_cus) {
+    return batch_workgroups(B, reserved_cus) / batch_groups(B);
+}
 
 extern "C" int vlsa_batch_max_bags(void) { return bt::kMaxBags; }
 
@@ -592,16 +604,17 @@ extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
 }
 
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
-                                  float* pl, float* pacc, int S, hipStream_t s);  // vlfan_batch_f32.hip
+                                  float* pl, float* pacc, int S, int workgroups, hipStream_t s);  // vlfan_batch_f32.hip
 
-extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
-                                        void* workspace, void* stream) {
+extern "C" int vlsa_vlfan_partial_batch_reserved(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                                 void* workspace, int reserved_cus, void* stream) {
     if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
     if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
     if (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) return VLSA_EINVAL;
     if (D != 512) return VLSA_EUNSUPPORTED;
     const int S = batch_groups(B);
-    const int G = 256 / S;  // partials per bag
+    const int WG = batch_workgroups(B, reserved_cus);
+    const int G = WG / S;  // partials per bag
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;
@@ -614,25 +627,30 @@ extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype
     if (x_dtype == VLSA_DT_F32) {
         const unsigned char* qp = static_cast<const unsigned char*>(qprep);
         return vlsa_launch_partial_f32_batch(bag_desc, B, reinterpret_cast<const float*>(qp + L.qeff),
-                                             reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, S, (hipStream_t)stream);
+                                             reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, S, WG, (hipStream_t)stream);
     }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
-    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(256), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
                        static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                        void* workspace, void* stream) {
+    return vlsa_vlfan_partial_batch_reserved(bag_desc, B, x_dtype, D, qprep, P, workspace, 0, stream);
 }
 
 extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                                         int pool_mode, const float* pool_w, const float* W, const float* b,
                                         const float* That, int K, const float* logit_scale, void* workspace, float* m2,
                                         float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
-                                        float* logits, float* incidence, void* stream) {
+                                        float* logits, float* incidence, int reserved_cus, void* stream) {
     if (!That || !logit_scale || !m2 || !l || !out || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
     if (K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
-    const int rc = vlsa_vlfan_partial_batch(bag_desc, B, x_dtype, D, qprep, P, workspace, stream);
+    const int rc = vlsa_vlfan_partial_batch_reserved(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, stream);
     if (rc != VLSA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int G = 256 / batch_groups(B);
+    const int G = batch_workgroups(B, reserved_cus) / batch_groups(B);
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;

@@ -553,8 +553,12 @@ class VlfanBatchPlan:
     """
 
     def __init__(self, B: int, P: int, K: int, device, D: int = 512, gated: bool = False, pool: str = "mean",
-                 identity_head: bool = False, coattn_scale: float = COATTN_SCALE):
+                 identity_head: bool = False, coattn_scale: float = COATTN_SCALE, reserved_cus: int = 0):
+        """reserved_cus: compute units left without a persistent streaming workgroup.  When batches are pipelined over two
+        streams, 32 (4 per XCD) lets the merge / head / prepare kernels of batch i run on those CUs while batch i+1 streams
+        on the other 224: the HBM-bound streaming kernel loses ~2 %, the step gains ~4 % (0 for a single stream)."""
         lib = nat.load()
+        self.reserved_cus = int(reserved_cus)
         if not (1 <= B <= lib.vlsa_batch_max_bags()):
             raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_max_bags()}]")
         self.lib, self.B, self.D, self.P, self.K = lib, B, D, P, K
@@ -599,11 +603,11 @@ class VlfanBatchPlan:
                                        _p(pool_w), None if self.identity_head else _p(W),
                                        None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
                                        _p(self.ws), _p(self.m2), _p(self.l), _p(self.out), _p(self.pooled), _p(self.v),
-                                       _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence), s),
-          "vlfan_forward_batch")
+                                       _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence),
+                                       self.reserved_cus, s), "vlfan_forward_batch")
         return self.logits
 
     def run_partial_only(self):
         """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
-        nat.check(self.lib.vlsa_vlfan_partial_batch(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
-                                                    _p(self.ws), _stream()), "vlfan_partial_batch")
+        nat.check(self.lib.vlsa_vlfan_partial_batch_reserved(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
+                                                             _p(self.ws), self.reserved_cus, _stream()), "vlfan_partial_batch")

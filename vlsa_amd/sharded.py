@@ -159,7 +159,11 @@ class ShardedVlfanBatchPlan:
     G = 256
 
     def __init__(self, B: int, P: int, K: int, device, dist_module=None, group=None, D: int = 512, gated: bool = False,
-                 pool: str = "mean", identity_head: bool = False, pipeline: bool = True):
+                 pool: str = "mean", identity_head: bool = False, pipeline: bool = True, reserved_cus: Optional[int] = None):
+        """reserved_cus: compute units the persistent streaming kernel leaves free so that the RCCL all-gather of the
+        previous batch and the tail kernels can run next to it (default: 32 = four per XCD when pipelined, else 0;
+        env ``VLSA_RESERVED_CUS`` overrides)."""
+        import os
         import torch.distributed as dist
         self.dist = dist_module or dist
         self.group = group
@@ -177,7 +181,10 @@ class ShardedVlfanBatchPlan:
         self._pending = None
         self._i = 0
         self.lib = nat.load()
-        self.G = int(self.lib.vlsa_batch_partials_per_bag(B))
+        if reserved_cus is None:
+            reserved_cus = 32 if pipeline else 0
+        self.reserved_cus = int(os.environ.get("VLSA_RESERVED_CUS", reserved_cus))
+        self.G = int(self.lib.vlsa_batch_partials_per_bag_reserved(B, self.reserved_cus))
         G, rf = self.G, self.rf
         i64 = ctypes.c_int64 * 9
         self._st_local = i64(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D, rf, rf, rf)
@@ -190,8 +197,8 @@ class ShardedVlfanBatchPlan:
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         nq = self.P + 1 if pl_.gated else self.P
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
-        c(lib.vlsa_vlfan_partial_batch(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws), s),
-          "vlfan_partial_batch")
+        c(lib.vlsa_vlfan_partial_batch_reserved(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
+                                                self.reserved_cus, s), "vlfan_partial_batch")
         base = pl_.ws.data_ptr()
         n_ml = self.B * self.G * nat.P_STRIDE * 4
         rec = self.rec[slot].data_ptr()
