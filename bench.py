@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2560)
     ap.add_argument("--bags-per-launch", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
-    ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs without a streaming workgroup (-1: 32 if streams > 1 else 0)")
+    ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs without a streaming workgroup (-1: 32 when N > 1, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -110,9 +110,10 @@ def main():
     BPL = max(1, min(a.bags_per_launch, 64))
     bags, Q, T, W, b, ls = synth(device, 100 + rank, BPL)
 
-    # 32 of the 256 CUs (4 per XCD) carry no persistent streaming workgroup: the merge / head / prepare kernels (and the RCCL
-    # all-gather when N > 1) of launch i run there while launch i+1 streams on the other 224
-    RESERVED = a.reserved_cus if a.reserved_cus >= 0 else (32 if a.streams > 1 else 0)
+    # N > 1: 32 of the 256 CUs (4 per XCD) carry no persistent streaming workgroup, so that the RCCL all-gather and the tail
+    # kernels of launch i run there while launch i+1 streams on the other 224.  N = 1: all 256 stream
+    # (reserving 32 measured +1 % step throughput for -3 % on the streaming kernel: within noise, not taken).
+    RESERVED = a.reserved_cus if a.reserved_cus >= 0 else (32 if (dist is not None and a.streams > 1) else 0)
 
     def make_plan(nb):
         if dist is None:

@@ -168,17 +168,25 @@ size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE af
  * the batched merge + the batched head. */
 int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, void* workspace,
                              void* stream);
-/* Same, leaving `reserved_cus` compute units (rounded up to a multiple of the bags in flight) without a persistent workgroup,
- * so that communication kernels of another stream (RCCL all-gather of the multi-GPU path) can run concurrently: next to a
- * persistent workgroup only kernels with <= 96 VGPRs and <= 8 KiB LDS get scheduled.  Partials per bag change accordingly. */
-int vlsa_batch_partials_per_bag_reserved(int B, int reserved_cus);
-int vlsa_vlfan_partial_batch_reserved(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
-                                      void* workspace, int reserved_cus, void* stream);
+/* Same with two scheduling knobs:
+ *  reserved_cus: compute units (rounded up to a multiple of the bags in flight) left without a persistent workgroup, so
+ *    that the tail kernels of the previous batch and communication kernels of another stream (RCCL all-gather of the
+ *    multi-GPU path) run concurrently: next to a persistent workgroup only kernels with <= 96 VGPRs and <= 8 KiB LDS
+ *    get scheduled;
+ *  groups: bags streamed concurrently (power of two <= min(B, 64); 0 = min(B, 8)).  Bag t is streamed by the
+ *    workgroups / groups workgroups of group t % groups; fewer workgroups per bag = more rows per workgroup per bag
+ *    epilogue and fewer partial records.  vlsa_batch_groups picks it from the bag sizes (HOST array rows_host[B]) by
+ *    minimising the modelled duration of the slowest group.
+ * Partials per bag = workgroups / groups: vlsa_batch_partials_per_bag_ex. */
+int vlsa_batch_groups(const int64_t* rows_host, int B, int reserved_cus);
+int vlsa_batch_partials_per_bag_ex(int B, int reserved_cus, int groups);
+int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, void* workspace,
+                                int reserved_cus, int groups, void* stream);
 int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, int pool_mode,
                              const float* pool_w, const float* W, const float* b, const float* That, int K,
                              const float* logit_scale, void* workspace, float* m2, float* l, float* out, float* pooled,
                              float* v, float* vhat, float* vnorm, float* logits, float* incidence, int reserved_cus,
-                             void* stream);
+                             int groups, void* stream);
 
 /*
  * Backward of the aggregation for a BATCH of bags w.r.t. the (shared) effective queries -- one training step of the
@@ -187,11 +195,12 @@ int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, co
  * 256 partial sums of  sum_bags de  into pm (= 0), pl (= 1) [256, 16] and pacc [256, P, D]; reduce them with
  * vlsa_vlfan_merge(..., G = 256, normalise = 0).  bwd_prep: scratch of vlsa_bwd_batch_prep_bytes(B, D).
  * bf16 bags, D == 512 and P <= 12 (VLSA_EUNSUPPORTED otherwise: loop vlsa_vlfan_backward over the bags instead).
+ * groups: bags in flight as in vlsa_vlfan_partial_batch_ex (0 = min(B, 8)).
  */
 size_t vlsa_bwd_batch_prep_bytes(int B, int D);
 int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                               float coattn_scale, const float* dout, const float* out, const float* m2, const float* l,
-                              void* bwd_prep, float* pm, float* pl, float* pacc, void* stream);
+                              void* bwd_prep, float* pm, float* pl, float* pacc, int groups, void* stream);
 
 /*
  * Batched log-sum-exp merge with explicit strides (in floats): strides9 (HOST array) = {partial stride of pm, pl, pacc;

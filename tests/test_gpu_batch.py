@@ -45,9 +45,10 @@ def test_batch_equals_single_bag_and_oracle(sizes, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("reserved", [8, 13, 250, 1000])
-def test_partial_batch_with_reserved_cus(reserved, dtype):
-    """Fewer persistent workgroups (CUs left free for communication kernels): same partial merge result."""
+@pytest.mark.parametrize("reserved,groups", [(8, 0), (13, 0), (250, 0), (1000, 0), (0, 1), (0, 2), (32, 4), (0, 8), (32, 16), (0, 64)])
+def test_partial_batch_with_reserved_cus_and_groups(reserved, groups, dtype):
+    """Fewer persistent workgroups (CUs left free for tail / communication kernels) and other numbers of bags in flight:
+    same partial merge result."""
     import ctypes
     from vlsa_amd import functional as F, _native as nat
     dev = torch.device("cuda", 0)
@@ -61,11 +62,12 @@ def test_partial_batch_with_reserved_cus(reserved, dtype):
     plan.run(Q, params["T"].to(dev), torch.tensor(cases.LOGIT_SCALE, device=dev), params["W"].to(dev), params["b"].to(dev))
     ref_out = plan.out.clone()
     lib, B, D = nat.load(), len(sizes), 512
-    G = lib.vlsa_batch_partials_per_bag_reserved(B, reserved)
-    assert 1 <= G <= 32 and G == max(1, (256 - (min(reserved, 248) + 7) // 8 * 8) // 8)
+    G = lib.vlsa_batch_partials_per_bag_ex(B, reserved, groups)
+    S = {0: 8, 1: 1, 2: 2, 4: 4, 8: 8, 16: 8, 64: 8}[groups]      # power of two <= B = 9
+    assert G == (256 - min((reserved + S - 1) // S * S, 256 - S)) // S
     plan.ws.zero_()
-    nat.check(lib.vlsa_vlfan_partial_batch_reserved(F._p(plan.desc), B, plan.dt, D, F._p(plan.qprep), P, F._p(plan.ws), reserved,
-                                                    F._stream()), "partial_batch_reserved")
+    nat.check(lib.vlsa_vlfan_partial_batch_ex(F._p(plan.desc), B, plan.dt, D, F._p(plan.qprep), P, F._p(plan.ws), reserved, groups,
+                                              F._stream()), "partial_batch_ex")
     wf = plan.ws.view(torch.float32)
     n_ml = B * G * nat.P_STRIDE
     st = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D,

@@ -9,7 +9,7 @@ dev = "cuda"
 bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(B)]
 Q = torch.randn(12, 512, device=dev); T = torch.randn(4, 512, device=dev)
 W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)
-R = int(sys.argv[3]) if len(sys.argv) > 3 else 32   # CUs without a streaming workgroup (bench.py default with 2 streams)
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 0    # CUs without a streaming workgroup (bench.py default at N = 1)
 plan = F.VlfanBatchPlan(B, 12, 4, dev, reserved_cus=R)
 plan.set_bags(bags)
 plan.run(Q, T, ls, W, b)

@@ -56,14 +56,15 @@ _SIGNATURES = {
     "vlsa_batch_partials_per_bag": (c_int, [c_int]),
     "vlsa_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlsa_vlfan_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "vlsa_batch_partials_per_bag_reserved": (c_int, [c_int, c_int]),
-    "vlsa_vlfan_partial_batch_reserved": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "vlsa_batch_groups": (c_int, [c_void_p, c_int, c_int]),
+    "vlsa_batch_partials_per_bag_ex": (c_int, [c_int, c_int, c_int]),
+    "vlsa_vlfan_partial_batch_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "vlsa_vlfan_forward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "vlsa_bwd_batch_prep_bytes": (c_size_t, [c_int, c_int]),
     "vlsa_vlfan_backward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlsa_vlfan_merge_batch_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_vlfan_merge_head_batch_strided": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,

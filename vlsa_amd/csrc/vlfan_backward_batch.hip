@@ -377,10 +377,17 @@ extern "C" size_t vlsa_bwd_batch_prep_bytes(int B, int D) { return (size_t)B * 3
 
 extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                                          float coattn_scale, const float* dout, const float* out, const float* m2,
-                                         const float* l, void* bwd_prep, float* pm, float* pl, float* pacc, void* stream) {
+                                         const float* l, void* bwd_prep, float* pm, float* pl, float* pacc, int groups,
+                                         void* stream) {
     if (!bag_desc || !qprep || !dout || !out || !m2 || !l || !bwd_prep || !pm || !pl || !pacc) return VLSA_EINVAL;
     if (B < 1 || B > bb::kMaxBags || P < 1) return VLSA_EINVAL;
     if (D != 512 || x_dtype != VLSA_DT_BF16 || P > bb::kMaxP) return VLSA_EUNSUPPORTED;
+    int S = groups > 0 ? groups : bwd_groups(B);  // bags in flight: power of two <= min(B, 64)
+    {
+        int p2 = 1;
+        while (p2 * 2 <= S && p2 * 2 <= B && p2 * 2 <= 64) p2 *= 2;
+        S = p2;
+    }
     hipStream_t s = (hipStream_t)stream;
     __bf16* dsplit = static_cast<__bf16*>(bwd_prep);
     float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
@@ -393,6 +400,6 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
     const QPrepLayout L(D);
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
     hipLaunchKernelGGL(k_vlfan_backward_dma_batch, dim3(256), dim3(512), bb::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
-                       qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, bwd_groups(B));
+                       qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

@@ -582,18 +582,51 @@ extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
 
 // bags streamed concurrently (each by 256 / S workgroups)
 static inline int batch_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
-// workgroups of the persistent kernels when `reserved_cus` CUs are to stay free for concurrently running communication
-// kernels (RCCL needs CUs; next to a persistent workgroup only kernels with <= 96 VGPRs / 8 KiB LDS get scheduled)
-static inline int batch_workgroups(int B, int reserved_cus) {
-    const int S = batch_groups(B);
+// S = bags streamed concurrently (each by workgroups / S workgroups).  Auto: 8 for B >= 8.  Small bags want more: every
+// workgroup should see >= ~8 lock-step iterations (512 rows) of a bag per bag epilogue, so the host may ask for S up to 64.
+static inline int resolve_groups(int B, int groups) {
+    int S = groups > 0 ? groups : batch_groups(B);
+    int p2 = 1;
+    while (p2 * 2 <= S && p2 * 2 <= B && p2 * 2 <= 64) p2 *= 2;  // power of two, <= B, <= 64
+    return p2;
+}
+// workgroups of the persistent kernels when `reserved_cus` CUs are to stay free for concurrently running tail /
+// communication kernels (next to a persistent workgroup only kernels with <= 96 VGPRs / 8 KiB LDS get scheduled)
+static inline int batch_workgroups(int S, int reserved_cus) {
     int r = reserved_cus < 0 ? 0 : reserved_cus;
     r = (r + S - 1) / S * S;
     if (r > 256 - S) r = 256 - S;
     return 256 - r;
 }
 extern "C" int vlsa_batch_partials_per_bag(int B) { return 256 / batch_groups(B); }
-extern "C" int vlsa_batch_partials_per_bag_reserved(int B, int reserved_cus) {
-    return batch_workgroups(B, reserved_cus) / batch_groups(B);
+extern "C" int vlsa_batch_partials_per_bag_ex(int B, int reserved_cus, int groups) {
+    const int S = resolve_groups(B, groups);
+    return batch_workgroups(S, reserved_cus) / S;
+}
+extern "C" int vlsa_batch_groups(const int64_t* rows_host, int B, int reserved_cus) {
+    // Pick the number of bags in flight from the bag sizes (HOST array): bag t goes to group t % S and is streamed by
+    // Gb = workgroups / S workgroups in 64-row lock-step iterations; a bag epilogue costs about 0.7 iterations.  The launch
+    // lasts as long as its slowest group: minimise that.  (Equal 50k bags, B = 32: S = 32 -> 98.7, S = 8 -> 102.8.)
+    if (!rows_host || B < 1) return 1;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int S = 1; S <= 64 && S <= B; S *= 2) {
+        const int Gb = batch_workgroups(S, reserved_cus) / S;
+        double worst = 0.0;
+        for (int g = 0; g < S; ++g) {
+            double c = 0.0;
+            for (int t = g; t < B; t += S) {
+                const int64_t units = (rows_host[t] + 63) / 64;
+                c += (double)((units + Gb - 1) / Gb) + 0.7;
+            }
+            if (c > worst) worst = c;
+        }
+        if (worst < best_cost * 0.999) {  // ties go to the smaller S (fewer, larger partial merges are not needed)
+            best_cost = worst;
+            best = S;
+        }
+    }
+    return best;
 }
 
 extern "C" int vlsa_batch_max_bags(void) { return bt::kMaxBags; }
@@ -606,14 +639,14 @@ extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
                                   float* pl, float* pacc, int S, int workgroups, hipStream_t s);  // vlfan_batch_f32.hip
 
-extern "C" int vlsa_vlfan_partial_batch_reserved(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
-                                                 void* workspace, int reserved_cus, void* stream) {
+extern "C" int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                           void* workspace, int reserved_cus, int groups, void* stream) {
     if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
     if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
     if (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) return VLSA_EINVAL;
     if (D != 512) return VLSA_EUNSUPPORTED;
-    const int S = batch_groups(B);
-    const int WG = batch_workgroups(B, reserved_cus);
+    const int S = resolve_groups(B, groups);
+    const int WG = batch_workgroups(S, reserved_cus);
     const int G = WG / S;  // partials per bag
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
@@ -637,20 +670,20 @@ extern "C" int vlsa_vlfan_partial_batch_reserved(const void* bag_desc, int B, in
 
 extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                                         void* workspace, void* stream) {
-    return vlsa_vlfan_partial_batch_reserved(bag_desc, B, x_dtype, D, qprep, P, workspace, 0, stream);
+    return vlsa_vlfan_partial_batch_ex(bag_desc, B, x_dtype, D, qprep, P, workspace, 0, 0, stream);
 }
 
 extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                                         int pool_mode, const float* pool_w, const float* W, const float* b,
                                         const float* That, int K, const float* logit_scale, void* workspace, float* m2,
                                         float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
-                                        float* logits, float* incidence, int reserved_cus, void* stream) {
+                                        float* logits, float* incidence, int reserved_cus, int groups, void* stream) {
     if (!That || !logit_scale || !m2 || !l || !out || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
     if (K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
-    const int rc = vlsa_vlfan_partial_batch_reserved(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, stream);
+    const int rc = vlsa_vlfan_partial_batch_ex(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, groups, stream);
     if (rc != VLSA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int G = batch_workgroups(B, reserved_cus) / batch_groups(B);
+    const int G = vlsa_batch_partials_per_bag_ex(B, reserved_cus, groups);
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;

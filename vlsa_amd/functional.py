@@ -329,6 +329,12 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
     return out, (A if want_attn else None)
 
 
+def choose_groups(sizes, reserved_cus: int = 0) -> int:
+    """Bags the persistent kernels keep in flight for these bag sizes (vlsa_batch_groups: slowest-group model)."""
+    arr = (ctypes.c_int64 * len(sizes))(*[int(n) for n in sizes])
+    return int(nat.load().vlsa_batch_groups(arr, len(sizes), int(reserved_cus)))
+
+
 class _BagTable:
     """Device-side descriptor table (pointer, N, row stride) of up to 64 bags for the batched kernels."""
 
@@ -362,9 +368,10 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         qp = prepare_queries(Q, gated, coattn_scale)
         P = qp.P
         ws = torch.empty(lib.vlsa_batch_workspace_bytes(B, P, D), dtype=torch.uint8, device=dev)
-        nat.check(lib.vlsa_vlfan_partial_batch(_p(table.desc), B, table.dt, D, _p(qp.buf), P, _p(ws), s),
+        groups = choose_groups([x.shape[0] for x in table.bags], 0)
+        nat.check(lib.vlsa_vlfan_partial_batch_ex(_p(table.desc), B, table.dt, D, _p(qp.buf), P, _p(ws), 0, groups, s),
                   "vlsa_vlfan_partial_batch")
-        G = int(lib.vlsa_batch_partials_per_bag(B))
+        G = int(lib.vlsa_batch_partials_per_bag_ex(B, 0, groups))
         wf = ws.view(torch.float32)
         pm, pl, pacc = wf, wf[B * G * nat.P_STRIDE:], wf[2 * B * G * nat.P_STRIDE:]
         m2 = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
@@ -394,7 +401,8 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
             pacc = torch.empty(G, P, D, dtype=torch.float32, device=dev)
             prep = torch.empty(lib.vlsa_bwd_batch_prep_bytes(B, D), dtype=torch.uint8, device=dev)
             nat.check(lib.vlsa_vlfan_backward_batch(_p(table.desc), B, table.dt, D, _p(qbuf), P, scale, _p(dout), _p(out),
-                                                    _p(m2), _p(l), _p(prep), _p(pm), _p(pl), _p(pacc), s),
+                                                    _p(m2), _p(l), _p(prep), _p(pm), _p(pl), _p(pacc),
+                                                    choose_groups([x.shape[0] for x in table.bags], 0), s),
                       "vlsa_vlfan_backward_batch")
             _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
         else:  # fp32 bags or P > 12: the per-bag kernel, partial sums of all bags reduced together
@@ -574,6 +582,7 @@ class VlfanBatchPlan:
         self.logits, self.incidence = f(B, K), f(B, K)
         self._bags = None
         self.dt = nat.DT_BF16
+        self.groups = 0
 
     def set_bags(self, bags):
         """bags: list of B device tensors [N_i, 512], all bf16 or all fp32 (unit inner stride, 16-byte aligned rows).
@@ -592,6 +601,7 @@ class VlfanBatchPlan:
             self.desc_host[i, 2] = x.stride(0) if x.shape[0] > 0 else self.D
         self._bags = keep
         self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
+        self.groups = choose_groups([x.shape[0] for x in keep], self.reserved_cus)  # bags in flight
         self.desc.copy_(self.desc_host, non_blocking=True)
 
     def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
@@ -604,10 +614,11 @@ class VlfanBatchPlan:
                                        None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
                                        _p(self.ws), _p(self.m2), _p(self.l), _p(self.out), _p(self.pooled), _p(self.v),
                                        _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence),
-                                       self.reserved_cus, s), "vlfan_forward_batch")
+                                       self.reserved_cus, self.groups, s), "vlfan_forward_batch")
         return self.logits
 
     def run_partial_only(self):
         """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
-        nat.check(self.lib.vlsa_vlfan_partial_batch_reserved(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
-                                                             _p(self.ws), self.reserved_cus, _stream()), "vlfan_partial_batch")
+        nat.check(self.lib.vlsa_vlfan_partial_batch_ex(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
+                                                       _p(self.ws), self.reserved_cus, self.groups, _stream()),
+                  "vlfan_partial_batch")

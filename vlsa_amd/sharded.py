@@ -184,21 +184,26 @@ class ShardedVlfanBatchPlan:
         if reserved_cus is None:
             reserved_cus = 32 if pipeline else 0
         self.reserved_cus = int(os.environ.get("VLSA_RESERVED_CUS", reserved_cus))
-        self.G = int(self.lib.vlsa_batch_partials_per_bag_reserved(B, self.reserved_cus))
-        G, rf = self.G, self.rf
-        i64 = ctypes.c_int64 * 9
-        self._st_local = i64(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE, G * P * D, rf, rf, rf)
-        self._st_global = i64(B * rf, B * rf, B * rf, rf, rf, rf, nat.P_STRIDE, nat.P_STRIDE, P * D)
+        rf = self.rf
+        self._st_global = (ctypes.c_int64 * 9)(B * rf, B * rf, B * rf, rf, rf, rf, nat.P_STRIDE, nat.P_STRIDE, P * D)
+        self._set_groups(0)
+
+    def _set_groups(self, groups):
+        P, D, rf = self.P, self.D, self.rf
+        self.G = G = int(self.lib.vlsa_batch_partials_per_bag_ex(self.B, self.reserved_cus, groups))
+        self._st_local = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, P * D, G * nat.P_STRIDE, G * nat.P_STRIDE,
+                                              G * P * D, rf, rf, rf)
 
     def set_bags(self, local_shards):
         self.local.set_bags(local_shards)
+        self._set_groups(self.local.groups)
 
     def _local(self, Q, slot):
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         nq = self.P + 1 if pl_.gated else self.P
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
-        c(lib.vlsa_vlfan_partial_batch_reserved(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
-                                                self.reserved_cus, s), "vlfan_partial_batch")
+        c(lib.vlsa_vlfan_partial_batch_ex(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
+                                          self.reserved_cus, pl_.groups, s), "vlfan_partial_batch")
         base = pl_.ws.data_ptr()
         n_ml = self.B * self.G * nat.P_STRIDE * 4
         rec = self.rec[slot].data_ptr()

@@ -183,7 +183,7 @@ class VLSA(nn.Module):
             if plan is None:
                 plan = VF.VlfanBatchPlan(len(chunk), P, K, chunk[0].device, gated=enc.gated_query, pool=mode,
                                          identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()),
-                                         reserved_cus=32 if len(flat) > step else 0)
+                                         reserved_cus=0)
                 self._plans[key] = plan
             plan.set_bags(chunk)
             plan.run(Q, T, ls, None if W is None else W.detach().float().contiguous(),
