@@ -263,6 +263,21 @@ int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const
 int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, float* out, void* stream);
 
 /*
+ * Raw attention scores of the ABMIL-style pooling modules over all N patches of a bag, fused (model/layers.py:85-153):
+ *   gated:  a[n] = w2 . (tanh(Wa x_n + ba) * sigmoid(Wg x_n + bg)) + c        Wa, Wg: [dim_hid, dim_in] fp32
+ *   plain:  a[n] = w2 .  tanh(Wa x_n + ba)                          + c        (Wg = bg = NULL, gated = 0)
+ * vlsa_prepare_gated_weights packs the weights once (bf16 hi + lo split, MFMA-fragment order) into `prep`
+ * (vlsa_gated_prep_bytes); vlsa_gated_scores streams the bag once: the [N, dim_hid] hidden activations stay in registers.
+ * Feed a[] to vlsa_scored_pool_partial for softmax_N(a) @ X.  bf16 bags, dim_in == 512, dim_hid == 256
+ * (VLSA_EUNSUPPORTED otherwise: the host then uses library GEMMs + vlsa_attn_scores).
+ */
+size_t vlsa_gated_prep_bytes(int gated);
+int vlsa_prepare_gated_weights(const float* Wa, const float* ba, const float* Wg, const float* bg, const float* w2,
+                               const float* c, int dim_in, int dim_hid, int gated, void* prep, void* stream);
+int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                      void* stream);
+
+/*
  * Bag ingest (replaces the per-step host concat + blocking H2D of dataset/PatchWSI.py:205-215 / runner/vlsa_handler.py:205):
  * pack N freshly uploaded rows (fp32 -> bf16 round-to-nearest-even, or bf16 copy) into a resident bf16 arena.
  * src [N, lds], dst [N, ldd] device pointers, 16-byte aligned rows, D % 8 == 0.

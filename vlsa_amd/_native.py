@@ -76,6 +76,10 @@ _SIGNATURES = {
     "vlsa_pack_rows_bf16": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "vlsa_surv_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_int, c_int,
                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_gated_prep_bytes": (c_size_t, [c_int]),
+    "vlsa_prepare_gated_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_void_p, c_void_p]),
+    "vlsa_gated_scores": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vlsa_pool_num_partials": (c_int, [c_int64]),
     "vlsa_scored_pool_partial": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),

@@ -77,6 +77,98 @@ __global__ __launch_bounds__(256) void k_scored_pool_partial(const XT* __restric
         pacc[(size_t)b * D + d] = sacc[d] * f[0] + sacc[DW + d] * f[1] + sacc[2 * DW + d] * f[2] + sacc[3 * DW + d] * f[3];
 }
 
+// Fast path of the scored pooling (rows 16-byte aligned, D a multiple of the vector width): a lane owns NC chunks of 16
+// bytes of a row (chunk c covers elements [(64 c + lane) VEC, +VEC)), so a wave reads a row with NC fully coalesced
+// 16-byte loads; 4 rows per wave are in flight before the (sequential) online-softmax update.  Same outputs as above.
+template <typename XT, int NC>
+__global__ __launch_bounds__(256) void k_scored_pool_partial_vec(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                                  const float* __restrict__ scores, float* __restrict__ pm,
+                                                                  float* __restrict__ pl, float* __restrict__ pacc, int G) {
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    constexpr int U = 4;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    int64_t rbeg, rend;
+    rows_of_block(N, b, G, rbeg, rend);
+    float acc[NC * VEC], M = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC * VEC; ++i) acc[i] = 0.f;
+    bool live[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) live[c] = (64 * c + lane) * VEC < D;
+    for (int64_t r0 = rbeg + U * w; r0 < rend; r0 += 4 * U) {
+        u4 raw[U][NC];
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u;
+            const bool ok = r < rend;
+            t[u] = ok ? (scores != nullptr ? scores[r] * kLog2e : 0.f) : -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                raw[u][c] = (ok && live[c]) ? *reinterpret_cast<const u4*>(X + r * ldx + (64 * c + lane) * VEC) : u4{0u, 0u, 0u, 0u};
+        }
+        float tm = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+        if (tm > M) {
+            const float f = fast_exp2(M - tm);
+            l *= f;
+#pragma unroll
+            for (int i = 0; i < NC * VEC; ++i) acc[i] *= f;
+            M = tm;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float wgt = (t[u] == -INFINITY) ? 0.f : fast_exp2(t[u] - M);
+            l += wgt;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int bits = raw[u][c][e];
+                        acc[c * VEC + 2 * e] += wgt * __uint_as_float(bits << 16);
+                        acc[c * VEC + 2 * e + 1] += wgt * __uint_as_float(bits & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int bits = raw[u][c][e];
+                        acc[c * VEC + e] += wgt * __uint_as_float(bits);
+                    }
+                }
+            }
+        }
+    }
+    float* sm = reinterpret_cast<float*>(smem);  // [4] M, [4] l, then [4][NC * 64 * VEC] acc
+    float* sl = sm + 4;
+    float* sacc = sm + 8;
+    constexpr int DW = NC * 64 * VEC;
+    if (lane == 0) {
+        sm[w] = M;
+        sl[w] = l;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sacc[w * DW + (64 * c + lane) * VEC + e] = acc[c * VEC + e];
+    __syncthreads();
+    const float mm = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float f[4], lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (sm[k] == -INFINITY) ? 0.f : fast_exp2(sm[k] - mm);
+        lt += sl[k] * f[k];
+    }
+    if (tid == 0) {
+        pm[(size_t)b * kPStride] = mm;
+        pl[(size_t)b * kPStride] = lt;
+    }
+    for (int d = tid; d < D; d += 256)
+        pacc[(size_t)b * D + d] = sacc[d] * f[0] + sacc[DW + d] * f[1] + sacc[2 * DW + d] * f[2] + sacc[3 * DW + d] * f[3];
+}
+
 // ---- column max: per-workgroup partial [G, D], then a tiny reduce
 template <typename XT, int DPL>
 __global__ __launch_bounds__(256) void k_colmax_partial(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
@@ -224,6 +316,18 @@ static int launch_scored(const XT* X, int64_t N, int64_t ldx, int D, const float
     {                                                                                                               \
         const size_t lds = (8 + (size_t)4 * DPL * 64) * sizeof(float);                                              \
         hipLaunchKernelGGL((k_scored_pool_partial<XT, DPL>), dim3(G), dim3(256), lds, s, X, N, ldx, D, scores, pm, pl, pacc, G); \
+    }
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    if ((D % VEC) == 0 && ((ldx * sizeof(XT)) % 16) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        const int NC = (D + 64 * VEC - 1) / (64 * VEC);
+#define VLSA_SPV(NCV)                                                                                                   \
+    {                                                                                                                   \
+        const size_t lds = (8 + (size_t)4 * NCV * 64 * VEC) * sizeof(float);                                            \
+        hipLaunchKernelGGL((k_scored_pool_partial_vec<XT, NCV>), dim3(G), dim3(256), lds, s, X, N, ldx, D, scores, pm, pl, pacc, G); \
+    }
+        if (NC == 1) VLSA_SPV(1) else if (NC == 2) VLSA_SPV(2) else if (NC == 3) VLSA_SPV(3) else VLSA_SPV(4)
+#undef VLSA_SPV
+        return st();
     }
     if (D <= 256) VLSA_SP(4) else if (D <= 512) VLSA_SP(8) else if (D <= 768) VLSA_SP(12) else VLSA_SP(16)
 #undef VLSA_SP

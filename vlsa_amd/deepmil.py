@@ -202,8 +202,19 @@ class DeepMIL(nn.Module):
         """raw scores a[N] of the pooling module on all patches: hidden projections by rocBLAS, the rest in HIP when
         no autograd graph is needed (else torch elementwise ops so the pooling parameters get gradients)."""
         sg = self.sigma
-        Xf = X2 if X2.dtype == torch.float32 else X2.float()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in sg.parameters())
+        gated = isinstance(sg, Gated_Attention_Pooling)
+        lin_a = sg.fc1[0] if gated else sg.attention[0]
+        if (not need_grad and not (gated and sg.training and sg.fc1[2].p > 0)
+                and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
+            # bf16 bag, 512 -> 256 hidden: the fused MFMA kernel (hidden activations stay in registers)
+            if not hasattr(self, "_fused_scores"):
+                self._fused_scores = VF.FusedAttnScores()
+            if gated:
+                return self._fused_scores(X2, lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias,
+                                          sg.fc2.weight, sg.fc2.bias)
+            return self._fused_scores(X2, lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias)
+        Xf = X2 if X2.dtype == torch.float32 else X2.float()
         if isinstance(sg, Attention_Pooling):
             lin1, lin2 = sg.attention[0], sg.attention[2]
             H = Xf @ lin1.weight.t()
@@ -230,8 +241,8 @@ class DeepMIL(nn.Module):
             X2 = VF._bag2d(X)
             a = self._attention_scores(X2)
             out_feat = VF.scored_pool(X2, a)[None, :]
-            # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
-            raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
+            if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
+                raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
         if self.pred_head == "Adapter":
             logit = self.keep_ratio * out_feat + (1 - self.keep_ratio) * self.visual_adapter(out_feat)
         else:

@@ -528,6 +528,37 @@ def attn_scores(H: torch.Tensor, Hg: Optional[torch.Tensor], b1, bg, w2, b2) -> 
     return a
 
 
+class FusedAttnScores:
+    """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 bag in ONE MFMA kernel
+    (vlsa_gated_scores; model/layers.py:85-153): the [N, 256] hidden activations never reach memory.  Holds the weights
+    packed in MFMA-fragment order (bf16 hi + lo split) and re-packs them when a parameter changes."""
+
+    def __init__(self):
+        self._key, self._prep = None, None
+
+    @staticmethod
+    def supported(X2: torch.Tensor, dim_in: int, dim_hid: int) -> bool:
+        return X2.is_cuda and X2.dtype == torch.bfloat16 and dim_in == 512 and dim_hid == 256 and X2.shape[0] > 0
+
+    def __call__(self, X2, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
+        lib = nat.load()
+        gated = Wg is not None
+        params = [t for t in (Wa, ba, Wg, bg, w2, c) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        if key != self._key:
+            prep = torch.empty(lib.vlsa_gated_prep_bytes(int(gated)), dtype=torch.uint8, device=X2.device)
+            f = lambda t: None if t is None else _f32c(t).reshape(-1)  # noqa: E731
+            keep = [f(t) for t in (Wa, ba, Wg, bg, w2, c)]
+            nat.check(lib.vlsa_prepare_gated_weights(*[_p(t) for t in keep], Wa.shape[1], Wa.shape[0], int(gated), _p(prep),
+                                                     _stream()), "vlsa_prepare_gated_weights")
+            self._key, self._prep = key, prep
+        N = X2.shape[0]
+        a = torch.empty(N, dtype=torch.float32, device=X2.device)
+        nat.check(lib.vlsa_gated_scores(_p(X2), nat.DT_BF16, N, X2.stride(0), X2.shape[1], _p(self._prep), int(gated), _p(a),
+                                        _stream()), "vlsa_gated_scores")
+        return a
+
+
 def topk_mean(S: torch.Tensor, k: int, out_scale: float = 1.0) -> torch.Tensor:
     """Per-class mean of the k largest entries of S[C, N] (k >= N: plain mean), times out_scale."""
     _need_gpu(S)
