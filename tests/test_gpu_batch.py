@@ -77,3 +77,30 @@ def test_partial_batch_with_reserved_cus_and_groups(reserved, groups, dtype):
                                                  F._p(l), F._p(out), F._stream()), "merge")
     torch.cuda.synchronize()
     assert (out - ref_out).abs().max().item() < 2e-5 * max(1.0, ref_out.abs().max().item())
+
+
+def test_batch_plan_hipgraph_replay():
+    """One captured run of a batch (hipGraph): replays reproduce the eager result and follow in-place parameter updates."""
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    P, K = 12, 4
+    sizes = [2798, 64, 1000, 5000, 333, 17, 2048, 4097]
+    bags = [cases.make_bag(n, 700 + i).to(torch.bfloat16).to(dev) for i, n in enumerate(sizes)]
+    params = cases.make_params(P, K, 710)
+    Q = (0.5 * params["resid"] + params["prompt"]).to(dev)
+    T, W, b = params["T"].to(dev), params["W"].to(dev), params["b"].to(dev)
+    ls = torch.tensor(cases.LOGIT_SCALE, device=dev)
+    plan = F.VlfanBatchPlan(len(sizes), P, K, dev)
+    plan.set_bags(bags)
+    eager = plan.run(Q, T, ls, W, b).clone()
+    g = plan.capture(Q, T, ls, W, b)
+    plan.logits.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.logits, eager)
+    Q.mul_(-1.0)                                  # in-place update: the graph reads Q by address
+    g.replay()
+    torch.cuda.synchronize()
+    ref = plan.logits.clone()
+    assert (ref - eager).abs().max().item() > 1e-3
+    assert torch.equal(plan.run(Q, T, ls, W, b), ref)

@@ -90,3 +90,46 @@ def test_sharded_plan_over_one_rank_rccl_group():
         assert (out - ref_out).abs().max().item() < 1e-5 and (A - ref_A).abs().max().item() < 1e-6
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bag_parallel_training_under_ddp():
+    """Training data parallelism has BAGS as the unit: the model wrapped in torch DDP over RCCL, each rank's
+    bags through the batched HIP forward + backward, gradients all-reduced by DDP.  One rank here (the multi-rank reduction
+    is DDP's own); checks that the custom autograd functions and the list-of-bags forward work under the wrapper."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from vlsa_amd.vlsa import VLSA
+    from vlsa_amd.losses import SurvObjective
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29713", RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    try:
+        P, K = 12, 4
+        params = cases.make_params(P, K, 5000)
+        bags = [cases.make_bag(n, 5010 + i).to(torch.bfloat16).to(dev) for i, n in enumerate([900, 64, 2798, 333])]
+        t, e = torch.tensor([0, 3, 1, 2], device=dev), torch.tensor([1.0, 0.0, 1.0, 0.0], device=dev)
+
+        def build():
+            cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=P, query_pooling="mean")
+            m = VLSA(cfg, pretrained_text_features=params["T"].clone()).to(dev)
+            with torch.no_grad():
+                m.mil_encoder.Q.copy_((0.5 * params["resid"] + params["prompt"]).to(dev))
+                m.mil_encoder.visual_adapter.weight.copy_(params["W"].to(dev))
+                m.mil_encoder.visual_adapter.bias.copy_(params["b"].to(dev))
+            return m.train()
+
+        plain, wrapped = build(), DDP(build(), device_ids=[0])
+        objective = SurvObjective()
+        for model in (plain, wrapped):
+            logits = model(bags)[0]
+            net = model.module if isinstance(model, DDP) else model
+            objective(logits, t, e, net.get_logit_scale()).backward()
+        torch.cuda.synchronize()
+        for (na, pa), (nb, pb) in zip(plain.named_parameters(), wrapped.module.named_parameters()):
+            assert na == nb and (pa.grad is None) == (pb.grad is None)
+            if pa.grad is not None:
+                assert (pa.grad - pb.grad).abs().max().item() <= 1e-6 * max(1.0, pa.grad.abs().max().item()), na
+    finally:
+        dist.destroy_process_group()

@@ -648,6 +648,22 @@ class VlfanBatchPlan:
                                        self.reserved_cus, self.groups, s), "vlfan_forward_batch")
         return self.logits
 
+    def capture(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
+        """Record one ``run`` of the current bags into a hipGraph (``torch.cuda.CUDAGraph``) and return it: ``g.replay()``
+        re-issues the 5 kernels with one host call.  Everything the kernels read is referenced by address (the bag table,
+        Q, T, W, b, logit_scale), so in-place updates of those tensors are seen by later replays; the outputs land in the
+        plan's buffers.  For many small bags per launch the eager launch sequence, not the GPU, is the limit."""
+        side = torch.cuda.Stream(device=self.desc.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.run(Q, T, logit_scale, W, b, pool_w)      # warm-up outside the capture (module load, attribute set-up)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run(Q, T, logit_scale, W, b, pool_w)
+        self._graph_keep = (Q, T, logit_scale, W, b, pool_w)
+        return g
+
     def run_partial_only(self):
         """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
         nat.check(self.lib.vlsa_vlfan_partial_batch_ex(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,

@@ -124,7 +124,11 @@ class VLSA(nn.Module):
         return plan.logits.clone()[None, :], plan.vhat.clone()[None, :], plan.That.clone()
 
     def forward(self, X):
-        """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm))."""
+        """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm)).
+        A list / tuple of bags is routed to ``forward_bags`` (so that wrappers which only hook ``forward`` --
+        ``DistributedDataParallel`` with bags as the data-parallel unit -- see the batched path too)."""
+        if isinstance(X, (list, tuple)):
+            return self.forward_bags(list(X))
         text_features = self.forward_text_only()
         if not self._needs_grad(text_features):
             fused = self._fused_vlfan(X, text_features)
