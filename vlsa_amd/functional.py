@@ -240,32 +240,40 @@ class VlfanInferencePlan:
         self.logits, self.incidence = f(K), f(K)
         self.scores = f(P, N) if want_attn else None
         self.A = f(P, N) if want_attn else None
+        self._c = {k: _p(getattr(self, k)) for k in ("qprep", "pm", "pl", "pacc", "m2", "l", "out", "That", "tnorm", "ws",
+                                                     "pooled", "v", "vhat", "vnorm", "logits", "incidence", "scores", "A")}
 
     def run(self, X: torch.Tensor, Q: torch.Tensor, T: torch.Tensor, logit_scale: torch.Tensor,
             W: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
-            pool_w: Optional[torch.Tensor] = None):
+            pool_w: Optional[torch.Tensor] = None, outs: Optional[dict] = None):
         """X [N, D] (fp32/bf16, unit inner stride), Q [nq, D] fp32, T [K, D] fp32 raw text features,
-        logit_scale 0-dim fp32 -- all contiguous device tensors (not checked here: hot path)."""
-        lib, s = self.lib, _stream()
+        logit_scale 0-dim fp32 -- all contiguous device tensors (not checked here: hot path).
+        outs: optional {'logits': [K], 'vhat': [D], 'That': [K, D]} fp32 tensors the kernels write INSTEAD of the plan's own
+        buffers (a caller that must hand out fresh tensors per bag saves three copy kernels)."""
+        lib, s, k = self.lib, _stream(), self._c
+        if outs:
+            k = dict(k)
+            for name, t in outs.items():
+                k[name] = _p(t)
         nq = self.P + 1 if self.gated else self.P
         c = nat.check
-        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), _p(T), self.K,
-                                            _p(self.That), _p(self.tnorm), s), "prepare_queries_and_text")
+        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, k["qprep"], _p(T), self.K,
+                                            k["That"], k["tnorm"], s), "prepare_queries_and_text")
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
-        c(lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
-                                 self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc), _p(self.scores), s),
+        c(lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, k["qprep"], self.P,
+                                 self.kernel, k["pm"], k["pl"], k["pacc"], k["scores"], s),
           "vlfan_partial")
-        c(lib.vlsa_vlfan_merge(_p(self.pm), _p(self.pl), _p(self.pacc), self.G, self.P, self.D, 1, _p(self.m2),
-                               _p(self.l), _p(self.out), s), "vlfan_merge")
+        c(lib.vlsa_vlfan_merge(k["pm"], k["pl"], k["pacc"], self.G, self.P, self.D, 1, k["m2"],
+                               k["l"], k["out"], s), "vlfan_merge")
         if self.scores is not None:
-            c(lib.vlsa_attn_normalise(_p(self.scores), self.P, self.N, _p(self.m2), _p(self.l), _p(self.A), s),
+            c(lib.vlsa_attn_normalise(k["scores"], self.P, self.N, k["m2"], k["l"], k["A"], s),
               "attn_normalise")
-        c(lib.vlsa_head_forward(_p(self.out), self.P, self.D, self.pool, _p(pool_w),
+        c(lib.vlsa_head_forward(k["out"], self.P, self.D, self.pool, _p(pool_w),
                                 None if self.identity_head else _p(W), None if self.identity_head else _p(b),
-                                _p(self.That), self.K, _p(logit_scale), _p(self.ws), _p(self.pooled), _p(self.v),
-                                _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence), s),
+                                k["That"], self.K, _p(logit_scale), k["ws"], k["pooled"], k["v"],
+                                k["vhat"], k["vnorm"], k["logits"], k["incidence"], s),
           "head_forward")
-        return self.logits
+        return outs["logits"] if outs and "logits" in outs else self.logits
 
     def run_partial_only(self, X: torch.Tensor):
         """Just the streaming kernel (for roofline timing); queries must have been prepared by a run()."""
@@ -329,10 +337,20 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
     return out, (A if want_attn else None)
 
 
+_GROUPS_CACHE: dict = {}
+
+
 def choose_groups(sizes, reserved_cus: int = 0) -> int:
     """Bags the persistent kernels keep in flight for these bag sizes (vlsa_batch_groups: slowest-group model)."""
-    arr = (ctypes.c_int64 * len(sizes))(*[int(n) for n in sizes])
-    return int(nat.load().vlsa_batch_groups(arr, len(sizes), int(reserved_cus)))
+    key = (tuple(sizes), int(reserved_cus))
+    g = _GROUPS_CACHE.get(key)
+    if g is None:
+        arr = (ctypes.c_int64 * len(sizes))(*[int(n) for n in sizes])
+        g = int(nat.load().vlsa_batch_groups(arr, len(sizes), int(reserved_cus)))
+        if len(_GROUPS_CACHE) > 4096:
+            _GROUPS_CACHE.clear()
+        _GROUPS_CACHE[key] = g
+    return g
 
 
 class _BagTable:
@@ -614,39 +632,55 @@ class VlfanBatchPlan:
         self._bags = None
         self.dt = nat.DT_BF16
         self.groups = 0
+        self._desc_np = self.desc_host.numpy()     # same (pinned) memory, cheap element writes
+        self._desc_ev = None                       # recorded after the table's H2D copy: guards the pinned staging buffer
+        # ctypes pointers of the plan-owned buffers, built once (the per-call cost of the eager path is host-side)
+        self._c = {k: _p(getattr(self, k)) for k in ("desc", "ws", "qprep", "That", "tnorm", "m2", "l", "out", "pooled", "v",
+                                                     "vhat", "vnorm", "logits", "incidence")}
 
-    def set_bags(self, bags):
+    def set_bags(self, bags, validated: bool = False):
         """bags: list of B device tensors [N_i, 512], all bf16 or all fp32 (unit inner stride, 16-byte aligned rows).
-        Kept alive by the plan."""
+        Kept alive by the plan.  validated: the caller already passed every bag through ``_bag2d`` and checked device,
+        dtype and D (skips the per-bag checks: the eager path is host-bound for small bags)."""
         if len(bags) != self.B:
             raise ValueError(f"expected {self.B} bags, got {len(bags)}")
-        keep = []
+        keep, rows = [], []
         for i, x in enumerate(bags):
-            _need_gpu(x)
-            x = _bag2d(x)
-            if x.shape[1] != self.D or (i > 0 and x.dtype != keep[0].dtype):
-                raise VlsaNativeError("the batched path takes bags with D == 512 and one dtype (bf16 or fp32) per batch")
+            if not validated:
+                _need_gpu(x)
+                x = _bag2d(x)
+                if x.shape[1] != self.D or (i > 0 and x.dtype != keep[0].dtype):
+                    raise VlsaNativeError("the batched path takes bags with D == 512 and one dtype (bf16 or fp32) per batch")
             keep.append(x)
-            self.desc_host[i, 0] = x.data_ptr()
-            self.desc_host[i, 1] = x.shape[0]
-            self.desc_host[i, 2] = x.stride(0) if x.shape[0] > 0 else self.D
+            n = x.shape[0]
+            rows.append((x.data_ptr(), n, x.stride(0) if n > 0 else self.D))
+        if self._desc_ev is not None:
+            self._desc_ev.synchronize()            # the previous table's async copy has read the staging buffer
+        self._desc_np[:] = rows
         self._bags = keep
         self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
-        self.groups = choose_groups([x.shape[0] for x in keep], self.reserved_cus)  # bags in flight
+        self.groups = choose_groups([r[1] for r in rows], self.reserved_cus)  # bags in flight
         self.desc.copy_(self.desc_host, non_blocking=True)
+        if self.desc_host.is_pinned():
+            self._desc_ev = torch.cuda.Event()
+            self._desc_ev.record()
 
-    def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
-        lib, s, c = self.lib, _stream(), nat.check
+    def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None, outs: Optional[dict] = None):
+        """outs: optional {'logits': [B, K], 'vhat': [B, D], 'That': [K, D]} tensors written instead of the plan's buffers."""
+        lib, s, c, k = self.lib, _stream(), nat.check, self._c
+        if outs:
+            k = dict(k)
+            for name, t in outs.items():
+                k[name] = _p(t)
         nq = self.P + 1 if self.gated else self.P
-        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, _p(self.qprep), _p(T), self.K,
-                                            _p(self.That), _p(self.tnorm), s), "prepare_queries_and_text")
-        c(lib.vlsa_vlfan_forward_batch(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P, self.pool,
+        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, k["qprep"], _p(T), self.K,
+                                            k["That"], k["tnorm"], s), "prepare_queries_and_text")
+        c(lib.vlsa_vlfan_forward_batch(k["desc"], self.B, self.dt, self.D, k["qprep"], self.P, self.pool,
                                        _p(pool_w), None if self.identity_head else _p(W),
-                                       None if self.identity_head else _p(b), _p(self.That), self.K, _p(logit_scale),
-                                       _p(self.ws), _p(self.m2), _p(self.l), _p(self.out), _p(self.pooled), _p(self.v),
-                                       _p(self.vhat), _p(self.vnorm), _p(self.logits), _p(self.incidence),
-                                       self.reserved_cus, self.groups, s), "vlfan_forward_batch")
-        return self.logits
+                                       None if self.identity_head else _p(b), k["That"], self.K, _p(logit_scale),
+                                       k["ws"], k["m2"], k["l"], k["out"], k["pooled"], k["v"], k["vhat"], k["vnorm"],
+                                       k["logits"], k["incidence"], self.reserved_cus, self.groups, s), "vlfan_forward_batch")
+        return outs["logits"] if outs and "logits" in outs else self.logits
 
     def capture(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
         """Record one ``run`` of the current bags into a hipGraph (``torch.cuda.CUDAGraph``) and return it: ``g.replay()``

@@ -85,6 +85,12 @@ class VLSA(nn.Module):
             self._text_cache, self._text_cache_key = self.text_provider(), key
         return self._text_cache
 
+    def _text_features(self):
+        """forward_text_only without the defensive clone of the cached-features branch (nothing here writes to it)."""
+        if hasattr(self, "pretrained_text_features"):
+            return self.pretrained_text_features
+        return self.forward_text_only()
+
     def encode_instances(self, X):
         return self.mil_encoder(X)
 
@@ -118,10 +124,12 @@ class VLSA(nn.Module):
             plan = VF.VlfanInferencePlan(N, D, P, K, X2.device, gated=enc.gated_query, pool=mode, identity_head=W is None,
                                          coattn_scale=float(enc.coattn_logit_scale.exp()))
             self._plans[key] = plan
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=X2.device)  # noqa: E731
+        outs = {"logits": f(1, K), "vhat": f(1, D), "That": f(K, D)}   # fresh tensors, written by the kernels directly
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
-                 None if pw is None else pw.detach().float().reshape(-1).contiguous())
-        return plan.logits.clone()[None, :], plan.vhat.clone()[None, :], plan.That.clone()
+                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs)
+        return outs["logits"], outs["vhat"], outs["That"]
 
     def forward(self, X):
         """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm)).
@@ -129,7 +137,7 @@ class VLSA(nn.Module):
         ``DistributedDataParallel`` with bags as the data-parallel unit -- see the batched path too)."""
         if isinstance(X, (list, tuple)):
             return self.forward_bags(list(X))
-        text_features = self.forward_text_only()
+        text_features = self._text_features()
         if not self._needs_grad(text_features):
             fused = self._fused_vlfan(X, text_features)
             if fused is not None:
@@ -151,7 +159,7 @@ class VLSA(nn.Module):
         a batched torch tail otherwise; anything else falls back to per-bag ``forward``.
         Returns (logits [B, K], image_features [B, D], text_features [K, D])."""
         enc = self.mil_encoder
-        text_features = self.forward_text_only()
+        text_features = self._text_features()
         if self._needs_grad(text_features):
             if (isinstance(enc, VLFAN) and len(bags) > 0 and all(x.is_cuda and x.shape[-1] == 512 and x.shape[-2] > 0 for x in bags)
                     and all(x.dtype == bags[0].dtype for x in bags)):
@@ -179,6 +187,9 @@ class VLSA(nn.Module):
         T = text_features.detach().float().contiguous()
         ls = self.logit_scale.detach().float()
         logits, feats, That = [], [], None
+        Wc = None if W is None else W.detach().float().contiguous()
+        bc = None if b is None else b.detach().float().contiguous()
+        pwc = None if pw is None else pw.detach().float().reshape(-1).contiguous()
         step = 32
         for i in range(0, len(flat), step):
             chunk = flat[i:i + step]
@@ -189,13 +200,16 @@ class VLSA(nn.Module):
                                          identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()),
                                          reserved_cus=0)
                 self._plans[key] = plan
-            plan.set_bags(chunk)
-            plan.run(Q, T, ls, None if W is None else W.detach().float().contiguous(),
-                     None if b is None else b.detach().float().contiguous(),
-                     None if pw is None else pw.detach().float().reshape(-1).contiguous())
-            logits.append(plan.logits.clone())
-            feats.append(plan.vhat.clone())
-            That = plan.That.clone()
+            plan.set_bags(chunk, validated=True)
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=chunk[0].device)  # noqa: E731
+            outs = {"logits": f(len(chunk), K), "vhat": f(len(chunk), 512)}
+            if That is None:
+                outs["That"] = That = f(K, 512)
+            plan.run(Q, T, ls, Wc, bc, pwc, outs=outs)
+            logits.append(outs["logits"])
+            feats.append(outs["vhat"])
+        if len(logits) == 1:
+            return logits[0], feats[0], That
         return torch.cat(logits), torch.cat(feats), That
 
     def _forward_zeroshot(self, X, text_features):
