@@ -80,6 +80,17 @@ def test_arena_upload_equals_host_concat(convert, tmp_path):
 
 
 @pytest.mark.gpu
+def test_fp32_arena_keeps_features_bit_exact():
+    from vlsa_amd.ingest import DeviceBagArena
+    dev = torch.device("cuda", 0)
+    arena = DeviceBagArena(8192, dev, chunk_rows=512, dtype=torch.float32)
+    slides = [cases.make_bag(700, 1200), cases.make_bag(1300, 1201).to(torch.float16), cases.make_bag(5, 1202).to(torch.bfloat16)]
+    got = arena.add("p", slides)
+    arena.wait()
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), torch.cat([s.to(torch.float) for s in slides]))
+
+
+@pytest.mark.gpu
 def test_arena_feeds_forward_bags():
     from vlsa_amd.ingest import DeviceBagArena
     from vlsa_amd.vlsa import VLSA

@@ -81,11 +81,19 @@ def read_patch_data(path: str) -> torch.Tensor:
 
 class DeviceBagArena:
     def __init__(self, capacity_rows: int, device, D: int = 512, chunk_rows: int = 16384, convert: str = "host",
-                 host_threads: int = 8):
+                 host_threads: int = 8, dtype: torch.dtype = torch.bfloat16):
         """convert='host': slides are cast to bf16 while being copied into the pinned staging buffer, so only 1 KB/patch
         crosses PCIe (measured 1.3 ms per 50k-patch bag); 'device': fp32 crosses PCIe and ``vlsa_pack_rows_bf16`` casts
         in HBM (2.3 ms; for hosts short on cores).  ``host_threads`` caps torch's intra-op threads during the staging
-        copies: with one thread per core of a 256-core host the 16 MB copies were 10x slower and erratic."""
+        copies: with one thread per core of a 256-core host the 16 MB copies were 10x slower and erratic.
+        dtype=torch.float32 keeps the reference's fp32 features bit for bit (2 KB per patch: the exact-fp32 kernels then
+        run at ~4.6 TB/s instead of the bf16 kernels' 6.4, and results match the reference to 1e-5 instead of the
+        ~1e-2 logit shift of rounding the features to bf16 once)."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("arena dtype must be torch.bfloat16 or torch.float32")
+        self.dtype = dtype
+        if dtype == torch.float32:
+            convert = "host"          # nothing to convert: slides are copied as they are
         if convert not in ("device", "host"):
             raise ValueError("convert must be 'device' (fp32 over PCIe, bf16 cast in HBM) or 'host' (bf16 over PCIe)")
         self.device = torch.device(device)
@@ -95,8 +103,8 @@ class DeviceBagArena:
         self.D, self.chunk, self.convert = D, int(chunk_rows), convert
         self.host_threads = int(host_threads)
         self.layout = ArenaLayout(capacity_rows)
-        self.data = torch.empty(capacity_rows, D, dtype=torch.bfloat16, device=self.device)
-        sdt = torch.float32 if convert == "device" else torch.bfloat16
+        self.data = torch.empty(capacity_rows, D, dtype=dtype, device=self.device)
+        sdt = torch.float32 if (convert == "device" or dtype == torch.float32) else torch.bfloat16
         self._pinned = [torch.empty(self.chunk, D, dtype=sdt).pin_memory() for _ in range(2)]
         self._dev_stage = ([torch.empty(self.chunk, D, dtype=torch.float32, device=self.device) for _ in range(2)]
                            if convert == "device" else None)
