@@ -6,7 +6,8 @@ from vlsa_amd import functional as F
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 dev = "cuda"
-bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(B)]
+DT = torch.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else torch.bfloat16
+bags = [torch.randn(n, 512, device=dev).to(DT) for _ in range(B)]
 Q = torch.randn(12, 512, device=dev); T = torch.randn(4, 512, device=dev)
 W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 0    # CUs without a streaming workgroup (bench.py default at N = 1)

@@ -40,8 +40,10 @@ constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;
 constexpr float kThr = 16.0f;
 }  // namespace bf
 
-// element (row, col) of a wave's fp32 slice image lives at row * 512 + (((col >> 2) ^ (row & 7)) << 4) + (col & 3) * 4
-__device__ __forceinline__ int fswz(int row, int col) { return row * 512 + ((((col >> 2) ^ (row & 7))) << 4) + ((col & 3) << 2); }
+// element (row, col) of a wave's fp32 slice image (16 rows x 128 columns) lives at
+// row * 512 + (((col >> 2) ^ row) << 4) + (col & 3) * 4: the 16-B chunk index is XORed with the 4-bit row, so that both the
+// score reads (16 rows x one chunk per quarter wave) and the weighted-sum reads (4 rows x 16 words) hit 64 distinct banks
+__device__ __forceinline__ int fswz(int row, int col) { return row * 512 + ((((col >> 2) ^ (row & 15))) << 4) + ((col & 3) << 2); }
 
 #define VLSA_FBAR()                                          \
     do {                                                     \
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     {
         const float sc = qmeta[31];
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) qf[kk] = qeff[(size_t)i16 * D + cw * 128 + 4 * kk + g] * sc;
+        for (int kk = 0; kk < 32; ++kk)  // MFMA step kk = 4 j + r contracts column 16 j + 4 g + r (k-slot g): see the score reads
+            qf[kk] = qeff[(size_t)i16 * D + cw * 128 + 16 * (kk >> 2) + 4 * g + (kk & 3)] * sc;
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) asm volatile("" : "+v"(qf[kk]));
     }
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     // LDS-DMA of one 32-row tile of `bag` into ring slot `slot` (see k_vlfan_partial_dma for the layout)
     // descriptor of the bag the DMA currently streams from, cached in SGPRs (reloaded from the table on a bag change)
     int ib = -1, ildb = 0;
-    int voff[4] = {0, 0, 0, 0};  // row & 7 of piece i is 2 (i & 3) + lr
+    int voff[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // row of piece i within the tile is 2 i + lr
     i32x4 rsrc = {0, 0, 0, 0x00020000};
     auto issue_tile = [&](int bag, int tile, int slot) {
         if (bag != ib) {
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
             rsrc[2] = __builtin_amdgcn_readfirstlane(e.z);
             ildb = __builtin_amdgcn_readfirstlane(e.w);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) voff[q] = lr * ildb + cw * 512 + ((lc ^ (2 * q + lr)) << 4);
+            for (int q = 0; q < 8; ++q) voff[q] = lr * ildb + cw * 512 + ((lc ^ (2 * q + lr)) << 4);
             ib = bag;
         }
         const int ldb = ildb;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                 "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
-                : "s"(dst + i * 1024), "v"(voff[i & 3]), "s"(rsrc), "s"(sbase + i * 2 * ldb)
+                : "s"(dst + i * 1024), "v"(voff[i]), "s"(rsrc), "s"(sbase + i * 2 * ldb)
                 : "memory");
         }
     };
@@ -194,9 +197,17 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 // contraction 1 on the f32 matrix pipe: S[n][p] += X[n][c] e_p[c]; A fragment = one float per lane
+                // lane (row i16, k-slot g) reads 4 consecutive columns 16 j + 4 g .. + 3 with ONE ds_read_b128 and feeds them to
+                // the 4 MFMA steps 4 j .. 4 j + 3 (the query fragments use the same column permutation)
                 float xa[32];
 #pragma unroll
-                for (int kk = 0; kk < 32; ++kk) xa[kk] = *reinterpret_cast<const float_ma*>(xs + fswz(i16, 4 * kk + g));
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4_ma*>(xs + fswz(i16, 16 * j + 4 * g));
+                    xa[4 * j] = v[0];
+                    xa[4 * j + 1] = v[1];
+                    xa[4 * j + 2] = v[2];
+                    xa[4 * j + 3] = v[3];
+                }
                 f32x4 Sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 2) {
@@ -261,14 +272,16 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                 }
                 // contraction 2 on the f32 matrix pipe: acc[p][c] += W[p][n] X[n][c]; k-slot k of step rs <-> tile row 4k + rs,
                 // so A = wv[rs] (this lane: p = i16, row 4g + rs) and B = X[4g + rs][16 ct + i16]
+                // rs outermost: 8 independent accumulators between two MFMAs on the same one (dependent latency 40 > issue 32 cycles)
+                float xb[4][8];
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    float xb[4];
+                for (int rs = 0; rs < 4; ++rs)
 #pragma unroll
-                    for (int rs = 0; rs < 4; ++rs) xb[rs] = *reinterpret_cast<const float_ma*>(xs + fswz(4 * g + rs, 16 * ct + i16));
+                    for (int ct = 0; ct < 8; ++ct) xb[rs][ct] = *reinterpret_cast<const float_ma*>(xs + fswz(4 * g + rs, 16 * ct + i16));
 #pragma unroll
-                    for (int rs = 0; rs < 4; ++rs) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rs], xb[rs], acc[ct], 0, 0, 0);
-                }
+                for (int rs = 0; rs < 4; ++rs)
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rs], xb[rs][ct], acc[ct], 0, 0, 0);
                 ++kown;
             }
             
