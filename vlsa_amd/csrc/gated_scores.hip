@@ -235,11 +235,10 @@ extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t 
     if (!X || !prep || !a || N < 1 || ldx < D) return VLSA_EINVAL;
     if (D != gs::kD || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * 2) % 16) || ldx * 2 * gs::kRows >= (1ll << 31)) return VLSA_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)k_gated_scores<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
         (void)hipFuncSetAttribute((const void*)k_gated_scores<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
-        attr_set = true;
     }
     const unsigned int tiles = (unsigned int)((N + gs::kRows - 1) / gs::kRows);
     if (gated)

@@ -247,15 +247,15 @@ extern "C" int vlsa_vlfan_backward(const void* X, int x_dtype, int64_t N, int64_
     if (x_dtype == VLSA_DT_F32) {
         auto kern = k_vlfan_backward_mfma<float>;
         constexpr int lds = bwd_lds_bytes<true>();
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, (const float*)X, N, ldx, qsplit, dsplit, P, m2, l, delta,
                            coattn_scale, pm, pl, pacc, G);
     } else {
         auto kern = k_vlfan_backward_mfma<__bf16>;
         constexpr int lds = bwd_lds_bytes<false>();
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, (const __bf16*)X, N, ldx, qsplit, dsplit, P, m2, l, delta,
                            coattn_scale, pm, pl, pacc, G);
     }

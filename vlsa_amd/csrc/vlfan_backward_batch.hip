@@ -391,10 +391,9 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
     __bf16* dsplit = static_cast<__bf16*>(bwd_prep);
     float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
     hipLaunchKernelGGL(k_prepare_backward_batch, dim3(16, B), dim3(256), 0, s, dout, out, P, D, dsplit, delta);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)k_vlfan_backward_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bb::kLdsBytes);
-        attr_set = true;
     }
     const QPrepLayout L(D);
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);

@@ -651,10 +651,9 @@ extern "C" int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dt
     float* pm = static_cast<float*>(workspace);
     float* pl = pm + (size_t)B * G * kPStride;
     float* pacc = pl + (size_t)B * G * kPStride;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bt::kLdsBytes);
-        attr_set = true;
     }
     const QPrepLayout L(D);
     if (x_dtype == VLSA_DT_F32) {

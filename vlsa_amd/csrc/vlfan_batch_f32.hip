@@ -361,10 +361,9 @@ using namespace vlsa;
 
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
                                   float* pl, float* pacc, int S, int workgroups, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_vlfan_partial_f32_batch, dim3(workgroups), dim3(512), bf::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
                        qeff, qmeta, P, pm, pl, pacc, S);

@@ -492,10 +492,9 @@ static int launch_mfma(const XT* X, int64_t N, int64_t ldx, const __bf16* qsplit
     constexpr bool F32 = sizeof(XT) == 4;
     constexpr int lds = mfma_lds_bytes<F32>();
     auto kern = k_vlfan_partial_mfma<XT>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    static DeviceOnce attr_once;
+    if (lds > 64 * 1024 && attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, X, N, ldx, qsplit, P, pm, pl, pacc, scores, G);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;

@@ -374,13 +374,12 @@ extern "C" int vlsa_debug_read_cycles(long long* host_out) {
 // Called from vlsa_vlfan_partial (vlfan_partial.hip).
 int vlsa_launch_partial_dma(const __bf16* X, int64_t N, int64_t ldx, const __bf16* qsplit_scaled, int P, float* pm,
                             float* pl, float* pacc, float* scores, int G, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   dma::kLdsBytes);
         (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   dma::kLdsBytes);
-        attr_set = true;
     }
     const int64_t units = (N + 15) >> 4;
     const int uq = (int)(units / G), ur = (int)(units % G);

@@ -53,6 +53,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember for which devices of this process it was done
+// (normally one process drives one GPU, but a host may also walk over several).
+struct DeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 // Opaque prepared-query block layout (see vlsa_prepare_queries).
 struct QPrepLayout {
     size_t qeff, qsplit, qhat, qnorm, total;

@@ -184,6 +184,7 @@ class ShardedVlfanBatchPlan:
         if reserved_cus is None:
             reserved_cus = 32 if pipeline else 0
         self.reserved_cus = int(os.environ.get("VLSA_RESERVED_CUS", reserved_cus))
+        self.local.reserved_cus = self.reserved_cus   # the local plan picks the bags in flight for the same workgroup count
         rf = self.rf
         self._st_global = (ctypes.c_int64 * 9)(B * rf, B * rf, B * rf, rf, rf, rf, nat.P_STRIDE, nat.P_STRIDE, P * D)
         self._set_groups(0)
