@@ -261,6 +261,14 @@ int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const
  * k <= 32 unless k >= N (VLSA_EUNSUPPORTED otherwise).
  */
 int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, float* out, void* stream);
+/* Same in two stages for long rows (N / 4096 chunks per class in parallel, then a merge of the chunk winners): what the
+ * zero-shot path uses.  workspace: vlsa_topk_workspace_bytes(C, N, k), no initialisation needed. */
+size_t vlsa_topk_workspace_bytes(int C, int64_t N, int k);
+int vlsa_topk_mean_ws(const float* S, int C, int64_t N, int k, float out_scale, void* workspace, float* out, void* stream);
+
+/* out[n, :] = X[n, :] / max(|X[n, :]|, 1e-12) for ALL N patch rows, fp32 out [N, D] (the image_features the reference's
+ * zero-shot forward returns, model/vlsa.py:188-189); bf16 or fp32 rows, 16-byte aligned, D % 8 == 0 (bf16) / % 4 (fp32). */
+int vlsa_normalize_many(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float* out, void* stream);
 
 /*
  * Raw attention scores of the ABMIL-style pooling modules over all N patches of a bag, fused (model/layers.py:85-153):

@@ -87,6 +87,9 @@ _SIGNATURES = {
     "vlsa_attn_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "vlsa_rowdot": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "vlsa_topk_mean_ws": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vlsa_normalize_many": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "vlsa_topk_mean": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vlsa_debug_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
 }

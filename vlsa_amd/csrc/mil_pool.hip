@@ -298,6 +298,122 @@ __global__ __launch_bounds__(256) void k_topk_mean(const float* __restrict__ S, 
     if (tid == 0) out[cls] = sum / (float)k * scale_log2e_inv;
 }
 
+// Stage 1 of the two-stage top-k for long rows: workgroup (chunk b, class) keeps the k largest of ITS contiguous chunk of
+// the class's scores (same per-thread sorted insertion + k arg-max rounds) and writes them, descending, to
+// part[(cls * G + b) * k ..]; k_topk_mean over the [C, G * k] candidates then finishes.  k >= N: partial sums instead.
+__global__ __launch_bounds__(256) void k_topk_partial(const float* __restrict__ S, int64_t N, int k, int G,
+                                                       float* __restrict__ part) {
+    __shared__ float sval[256];
+    __shared__ int sidx[256];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, b = blockIdx.x, cls = blockIdx.y;
+    const float* s = S + (size_t)cls * N;
+    int64_t n0, n1;
+    rows_of_block(N, b, G, n0, n1);
+    if ((int64_t)k >= N) {
+        float a = 0.f;
+        for (int64_t n = n0 + tid; n < n1; n += 256) a += s[n];
+        a = block_sum_256(a, red);
+        if (tid == 0) part[(size_t)cls * G + b] = a;
+        return;
+    }
+    float top[kTopKMax];
+#pragma unroll
+    for (int i = 0; i < kTopKMax; ++i) top[i] = -INFINITY;
+    for (int64_t n = n0 + tid; n < n1; n += 256) {
+        float v = s[n];
+#pragma unroll
+        for (int i = 0; i < kTopKMax; ++i) {
+            if (i < k) {
+                const float hi = fmaxf(top[i], v);
+                v = fminf(top[i], v);
+                top[i] = hi;
+            }
+        }
+    }
+    int head = 0;
+    for (int round = 0; round < k; ++round) {
+        float mine = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kTopKMax; ++i)
+            if (i == head) mine = top[i];
+        sval[tid] = mine;
+        sidx[tid] = tid;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off && sval[tid + off] > sval[tid]) {
+                sval[tid] = sval[tid + off];
+                sidx[tid] = sidx[tid + off];
+            }
+            __syncthreads();
+        }
+        const int winner = sidx[0];
+        if (tid == 0) part[((size_t)cls * G + b) * k + round] = sval[0];
+        __syncthreads();
+        if (tid == winner) ++head;
+    }
+}
+
+// sum of G partial sums per class / N (mean over everything, second stage)
+__global__ __launch_bounds__(64) void k_mean_final(const float* __restrict__ part, int G, int64_t N, float scale, float* __restrict__ out) {
+    const int cls = blockIdx.x;
+    float a = 0.f;
+    for (int g = threadIdx.x; g < G; g += 64) a += part[(size_t)cls * G + g];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) out[cls] = a / (float)N * scale;
+}
+
+// F.normalize of MANY rows (the [N, D] patch features the reference's zero-shot forward hands back, model/vlsa.py:188-189):
+// one wave per row, 16-byte loads, fp32 out.  (k_normalize_rows in vlfan_tail.hip is the few-rows, one-workgroup-per-row form.)
+template <typename XT, int NC>
+__global__ __launch_bounds__(256) void k_normalize_many(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                         float* __restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < N; r += nw) {
+        float v[NC * VEC];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e0 = (64 * c + lane) * VEC;
+            u4 raw = {0u, 0u, 0u, 0u};
+            if (e0 < D) raw = *reinterpret_cast<const u4*>(X + r * ldx + e0);
+            if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int bits = raw[e];
+                    v[c * VEC + 2 * e] = __uint_as_float(bits << 16);
+                    v[c * VEC + 2 * e + 1] = __uint_as_float(bits & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int bits = raw[e];
+                    v[c * VEC + e] = __uint_as_float(bits);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ss += v[c * VEC + e] * v[c * VEC + e];
+        }
+        ss = wave_sum(ss);
+        const float nrm = fmaxf(sqrtf(ss), kNormEps);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int e0 = (64 * c + lane) * VEC;
+            if (e0 < D) {
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    f32x4 o = {v[c * VEC + 4 * q] / nrm, v[c * VEC + 4 * q + 1] / nrm, v[c * VEC + 4 * q + 2] / nrm,
+                               v[c * VEC + 4 * q + 3] / nrm};
+                    *reinterpret_cast<f32x4*>(out + r * D + e0 + 4 * q) = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace vlsa
 
 using namespace vlsa;
@@ -385,6 +501,56 @@ extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, i
         hipLaunchKernelGGL(k_rowdot<__bf16>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, N, ldx, D, v, out);
     else
         return VLSA_EINVAL;
+    return st();
+}
+
+extern "C" int vlsa_topk_chunks(int64_t N) {
+    const int64_t g = (N + 4095) / 4096;
+    return (int)(g < 1 ? 1 : (g > 128 ? 128 : g));
+}
+extern "C" size_t vlsa_topk_workspace_bytes(int C, int64_t N, int k) {
+    return (size_t)C * vlsa_topk_chunks(N) * (size_t)(k < 1 ? 1 : (k > kTopKMax ? kTopKMax : k)) * sizeof(float);
+}
+
+extern "C" int vlsa_topk_mean_ws(const float* S, int C, int64_t N, int k, float out_scale, void* workspace, float* out,
+                                 void* stream) {
+    if (!S || !out || !workspace || C < 1 || N < 1 || k < 1) return VLSA_EINVAL;
+    if (k > kTopKMax && (int64_t)k < N) return VLSA_EUNSUPPORTED;
+    const int G = vlsa_topk_chunks(N);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = static_cast<float*>(workspace);
+    if (G == 1 || ((int64_t)k < N && (int64_t)k * 2 > N / G)) {  // short rows: the single-stage kernel
+        hipLaunchKernelGGL(k_topk_mean, dim3(C), dim3(256), 0, s, S, N, k, out_scale, out);
+        return st();
+    }
+    hipLaunchKernelGGL(k_topk_partial, dim3(G, C), dim3(256), 0, s, S, N, k, G, part);
+    if ((int64_t)k >= N)
+        hipLaunchKernelGGL(k_mean_final, dim3(C), dim3(64), 0, s, part, G, N, out_scale, out);
+    else
+        hipLaunchKernelGGL(k_topk_mean, dim3(C), dim3(256), 0, s, part, (int64_t)G * k, k, out_scale, out);
+    return st();
+}
+
+extern "C" int vlsa_normalize_many(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float* out, void* stream) {
+    if (!X || !out || N < 0 || D < 1 || D > VLSA_MAX_D || ldx < D) return VLSA_EINVAL;
+    if (N == 0) return VLSA_OK;
+    const int esz = x_dtype == VLSA_DT_F32 ? 4 : 2;
+    if ((D % (16 / esz)) || ((ldx * esz) % 16) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (D % 4))
+        return VLSA_EUNSUPPORTED;
+    int64_t nb = (N + 3) / 4;
+    if (nb > 256 * 8) nb = 256 * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define VLSA_NM(XT, NCV) hipLaunchKernelGGL((k_normalize_many<XT, NCV>), dim3((unsigned)nb), dim3(256), 0, s, static_cast<const XT*>(X), N, ldx, D, out)
+    if (x_dtype == VLSA_DT_BF16) {
+        const int NC = (D + 511) / 512;
+        if (NC == 1) VLSA_NM(__bf16, 1); else VLSA_NM(__bf16, 2);
+    } else if (x_dtype == VLSA_DT_F32) {
+        const int NC = (D + 255) / 256;
+        if (NC == 1) VLSA_NM(float, 1); else if (NC == 2) VLSA_NM(float, 2); else if (NC == 3) VLSA_NM(float, 3); else VLSA_NM(float, 4);
+    } else {
+        return VLSA_EINVAL;
+    }
+#undef VLSA_NM
     return st();
 }
 

@@ -584,7 +584,19 @@ def topk_mean(S: torch.Tensor, k: int, out_scale: float = 1.0) -> torch.Tensor:
     S = _f32c(S)
     C, N = S.shape
     out = torch.empty(C, dtype=torch.float32, device=S.device)
-    nat.check(lib.vlsa_topk_mean(_p(S), C, N, int(k), float(out_scale), _p(out), _stream()), "vlsa_topk_mean")
+    ws = torch.empty(max(4, lib.vlsa_topk_workspace_bytes(C, N, int(k))), dtype=torch.uint8, device=S.device)
+    nat.check(lib.vlsa_topk_mean_ws(_p(S), C, N, int(k), float(out_scale), _p(ws), _p(out), _stream()), "vlsa_topk_mean_ws")
+    return out
+
+
+def normalize_many(X: torch.Tensor) -> torch.Tensor:
+    """F.normalize(X.float(), dim=-1) for all N patch rows of a bag in one pass (bf16 or fp32 in, fp32 out)."""
+    _need_gpu(X)
+    lib = nat.load()
+    X2 = _bag2d(X)
+    N, D = X2.shape
+    out = torch.empty(N, D, dtype=torch.float32, device=X2.device)
+    nat.check(lib.vlsa_normalize_many(_p(X2), _dt(X2), N, X2.stride(0), D, _p(out), _stream()), "vlsa_normalize_many")
     return out
 
 

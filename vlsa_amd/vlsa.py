@@ -223,5 +223,7 @@ class VLSA(nn.Module):
         pooled = VF.topk_mean(cosines, N if topk is None else min(topk, N))      # [K]
         logits = (self.logit_scale.exp() * pooled)[None, :]
         That, _ = VF.normalize_rows(text_features.detach())
-        image_features, _ = VF.normalize_rows(X2 if X2.dtype == torch.float32 else X2.float())
+        # the reference hands back the unit-norm patch features [N, D] here (identity encoder); 4 * N * D bytes per call that
+        # its handler never reads -- ``return_patch_features = False`` skips them (None is returned in their place)
+        image_features = VF.normalize_many(X2) if getattr(self, "return_patch_features", True) else None
         return logits, image_features, That
