@@ -57,3 +57,26 @@ def test_zeroshot_full_size_matches_oracle_and_can_skip_features():
             net.return_patch_features = False
             logits2, none_feats, _ = net(X[None].to(dev))
             assert none_feats is None and torch.equal(logits2, logits)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,D", [(1, 512), (3, 512), (2798, 512), (50_000, 512), (5000, 1024), (700, 264), (700, 504)])
+def test_streaming_reductions_vs_torch(N, D, dtype):
+    """colmax / rowdot / scored pooling: the 16-byte-load kernels (D % 8 == 0 is the library's contract; 264 and 504 have a
+    partly filled last chunk)."""
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    g = cases.gen(6300 + N % 89 + D)
+    X = torch.randn(N, D, generator=g).to(dtype)
+    Xd = X.to(dev)
+    Xf = X.float()
+    assert torch.equal(F.colmax(Xd).cpu(), Xf.max(dim=0).values)
+    v = torch.randn(D, generator=g)
+    rd = F.rowdot(Xd, v.to(dev)).cpu()
+    assert (rd - Xf @ v).abs().max().item() < 2e-5 * max(1.0, (Xf @ v).abs().max().item())
+    a = torch.randn(N, generator=g) * 3
+    sp = F.scored_pool(Xd, a.to(dev)).cpu()
+    ref = torch.softmax(a, dim=0) @ Xf
+    assert (sp - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    mean = F.scored_pool(Xd, None).cpu()
+    assert (mean - Xf.mean(dim=0)).abs().max().item() < 1e-5

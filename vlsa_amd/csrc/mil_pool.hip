@@ -197,12 +197,134 @@ __global__ __launch_bounds__(256) void k_colmax_partial(const XT* __restrict__ X
         part[(size_t)b * D + d] = fmaxf(fmaxf(s[d], s[DW + d]), fmaxf(s[2 * DW + d], s[3 * DW + d]));
 }
 
+// workgroup = 64 columns x 4 partial subsets, 4 independent running maxima per thread (the first version walked all G
+// partials in one dependent chain per column: ~50 us at G = 512)
 __global__ __launch_bounds__(256) void k_colmax_merge(const float* __restrict__ part, int G, int D, float* __restrict__ out) {
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
-    float m = -INFINITY;
-    for (int g = 0; g < G; ++g) m = fmaxf(m, part[(size_t)g * D + d]);
-    out[d] = m;
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + c;
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    if (d < D) {
+        int g = q;
+        for (; g + 12 < G; g += 16) {
+            m0 = fmaxf(m0, part[(size_t)g * D + d]);
+            m1 = fmaxf(m1, part[(size_t)(g + 4) * D + d]);
+            m2 = fmaxf(m2, part[(size_t)(g + 8) * D + d]);
+            m3 = fmaxf(m3, part[(size_t)(g + 12) * D + d]);
+        }
+        for (; g < G; g += 4) m0 = fmaxf(m0, part[(size_t)g * D + d]);
+    }
+    sm[q][c] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    __syncthreads();
+    if (q == 0 && d < D) out[d] = fmaxf(fmaxf(sm[0][c], sm[1][c]), fmaxf(sm[2][c], sm[3][c]));
+}
+
+// 16-byte row pieces -> floats (bf16: 8 values, fp32: 4 values)
+typedef unsigned int u32x4_p __attribute__((ext_vector_type(4)));
+template <typename XT>
+__device__ __forceinline__ void unpack16(const u32x4_p raw, float* v) {
+    if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int bits = raw[e];
+            v[2 * e] = __uint_as_float(bits << 16);
+            v[2 * e + 1] = __uint_as_float(bits & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int bits = raw[e];
+            v[e] = __uint_as_float(bits);
+        }
+    }
+}
+
+// Fast paths (rows 16-byte aligned, D a multiple of the vector width): a lane owns NC 16-byte chunks of a row (chunk c =
+// elements [(64 c + lane) VEC, +VEC)), 4 rows per wave in flight.  Same outputs as the scalar kernels above.
+template <typename XT, int NC>
+__global__ __launch_bounds__(256) void k_colmax_partial_vec(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                             float* __restrict__ part, int G) {
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    int64_t rbeg, rend;
+    rows_of_block(N, b, G, rbeg, rend);
+    float mx[NC * VEC];
+#pragma unroll
+    for (int i = 0; i < NC * VEC; ++i) mx[i] = -INFINITY;
+    for (int64_t r0 = rbeg + U * w; r0 < rend; r0 += 4 * U) {
+        u32x4_p raw[U][NC];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = r0 + u < rend;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                raw[u][c] = (ok[u] && (64 * c + lane) * VEC < D) ? *reinterpret_cast<const u32x4_p*>(X + (r0 + u) * ldx + (64 * c + lane) * VEC)
+                                                                 : u32x4_p{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float v[VEC];
+                    unpack16<XT>(raw[u][c], v);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) mx[c * VEC + e] = fmaxf(mx[c * VEC + e], v[e]);
+                }
+            }
+    }
+    float* s = reinterpret_cast<float*>(smem);
+    constexpr int DW = NC * 64 * VEC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[w * DW + (64 * c + lane) * VEC + e] = mx[c * VEC + e];
+    __syncthreads();
+    for (int d = tid; d < D; d += 256)
+        part[(size_t)b * D + d] = fmaxf(fmaxf(s[d], s[DW + d]), fmaxf(s[2 * DW + d], s[3 * DW + d]));
+}
+
+template <typename XT, int NC>
+__global__ __launch_bounds__(256) void k_rowdot_vec(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
+                                                     const float* __restrict__ v, float* __restrict__ out) {
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    float vv[NC * VEC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int d = (64 * c + lane) * VEC + e;
+            vv[c * VEC + e] = d < D ? v[d] : 0.f;
+        }
+    for (int64_t n0 = wave * U; n0 < N; n0 += nw * U) {
+        u32x4_p raw[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                raw[u][c] = (n0 + u < N && (64 * c + lane) * VEC < D) ? *reinterpret_cast<const u32x4_p*>(X + (n0 + u) * ldx + (64 * c + lane) * VEC)
+                                                                      : u32x4_p{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float x[VEC];
+                unpack16<XT>(raw[u][c], x);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s += x[e] * vv[c * VEC + e];
+            }
+            s = wave_sum(s);
+            if (lane == 0 && n0 + u < N) out[n0 + u] = s;
+        }
+    }
 }
 
 // ---- attention scores from the hidden projections: one wave per patch row
@@ -466,9 +588,19 @@ static int launch_colmax(const XT* X, int64_t N, int64_t ldx, int D, float* part
         const size_t lds = (size_t)4 * DPL * 64 * sizeof(float);                                                   \
         hipLaunchKernelGGL((k_colmax_partial<XT, DPL>), dim3(G), dim3(256), lds, s, X, N, ldx, D, part, G);        \
     }
-    if (D <= 256) VLSA_CM(4) else if (D <= 512) VLSA_CM(8) else if (D <= 768) VLSA_CM(12) else VLSA_CM(16)
+    constexpr int VEC = 16 / (int)sizeof(XT);
+    if ((D % VEC) == 0 && ((ldx * sizeof(XT)) % 16) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        const int NC = (D + 64 * VEC - 1) / (64 * VEC);
+#define VLSA_CMV(NCV)                                                                                                  \
+    {                                                                                                                  \
+        const size_t lds = (size_t)4 * NCV * 64 * VEC * sizeof(float);                                                 \
+        hipLaunchKernelGGL((k_colmax_partial_vec<XT, NCV>), dim3(G), dim3(256), lds, s, X, N, ldx, D, part, G);        \
+    }
+        if (NC == 1) VLSA_CMV(1) else if (NC == 2) VLSA_CMV(2) else if (NC == 3) VLSA_CMV(3) else VLSA_CMV(4)
+#undef VLSA_CMV
+    } else if (D <= 256) VLSA_CM(4) else if (D <= 512) VLSA_CM(8) else if (D <= 768) VLSA_CM(12) else VLSA_CM(16)
 #undef VLSA_CM
-    hipLaunchKernelGGL(k_colmax_merge, dim3((D + 255) / 256), dim3(256), 0, s, part, G, D, out);
+    hipLaunchKernelGGL(k_colmax_merge, dim3((D + 63) / 64), dim3(256), 0, s, part, G, D, out);
     return st();
 }
 
@@ -495,12 +627,23 @@ extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, i
     if (!X || !v || !out || N < 1 || D < 1 || ldx < D) return VLSA_EINVAL;
     int64_t nb = (N + 3) / 4;
     if (nb > 2048) nb = 2048;
+    if (x_dtype != VLSA_DT_F32 && x_dtype != VLSA_DT_BF16) return VLSA_EINVAL;
+    const int esz = x_dtype == VLSA_DT_F32 ? 4 : 2, VEC = 16 / esz;
+    hipStream_t s = (hipStream_t)stream;
+    if ((D % VEC) == 0 && ((ldx * esz) % 16) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && D <= VLSA_MAX_D) {
+        const int NC = (D + 64 * VEC - 1) / (64 * VEC);
+        int64_t nbv = (N + 15) / 16;
+        if (nbv > 2048) nbv = 2048;
+#define VLSA_RD(XT, NCV) hipLaunchKernelGGL((k_rowdot_vec<XT, NCV>), dim3((unsigned)nbv), dim3(256), 0, s, (const XT*)X, N, ldx, D, v, out)
+        if (x_dtype == VLSA_DT_BF16) { if (NC == 1) VLSA_RD(__bf16, 1); else VLSA_RD(__bf16, 2); }
+        else { if (NC == 1) VLSA_RD(float, 1); else if (NC == 2) VLSA_RD(float, 2); else if (NC == 3) VLSA_RD(float, 3); else VLSA_RD(float, 4); }
+#undef VLSA_RD
+        return st();
+    }
     if (x_dtype == VLSA_DT_F32)
-        hipLaunchKernelGGL(k_rowdot<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)X, N, ldx, D, v, out);
-    else if (x_dtype == VLSA_DT_BF16)
-        hipLaunchKernelGGL(k_rowdot<__bf16>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, N, ldx, D, v, out);
+        hipLaunchKernelGGL(k_rowdot<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)X, N, ldx, D, v, out);
     else
-        return VLSA_EINVAL;
+        hipLaunchKernelGGL(k_rowdot<__bf16>, dim3((unsigned)nb), dim3(256), 0, s, (const __bf16*)X, N, ldx, D, v, out);
     return st();
 }
 

@@ -145,8 +145,16 @@ class VLSA(nn.Module):
         enc = self.mil_encoder
         if isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max"):
             return self._forward_zeroshot(X, text_features)
+        feats = self.encode_instances(X)
+        if (not self._needs_grad(text_features) and feats.is_cuda and feats.dim() == 2 and feats.shape[0] == 1
+                and feats.shape[1] % 4 == 0 and feats.shape[1] <= 1024 and text_features.shape[0] <= 64):
+            # any encoder, no gradient: normalise + cosine logits of the bag vector in the head kernel (2 launches instead of
+            # ~8 torch ops; these paths are host-bound)
+            That, _ = VF.normalize_rows(text_features.detach())
+            h = VF.head_forward(feats, "given", None, None, None, That, self.logit_scale.detach())
+            return h["logits"][None, :], h["vhat"][None, :], That
         text_features = F.normalize(text_features, dim=-1)
-        image_features = F.normalize(self.encode_instances(X), dim=-1)
+        image_features = F.normalize(feats, dim=-1)
         logits = self.logit_scale.exp() * image_features @ text_features.t()
         if logits.shape[0] > 1:
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
