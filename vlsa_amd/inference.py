@@ -20,23 +20,32 @@ from .deepmil import VLFAN
 def evaluate_prototype_shap_imp(decoupled_similarity, logit_scale, verbose=False):
     """Exact Shapley values of the P prototypes for the survival risk sum_k (K - k) softmax(ls * mean_p sim)[k];
     the empty coalition is worth 1 (utils/model_inference.py:23-79).  O(P 2^P) on the host, vectorised."""
-    sim = torch.as_tensor(decoupled_similarity, dtype=torch.float32).cpu()
+    # numpy on purpose: the arrays are tiny ([2^P, P]); torch's CPU ops wake its whole intra-op thread pool for them, which
+    # on a many-core host costs milliseconds per call and is erratic (measured 1.7 ... 19 ms for the same input)
+    import numpy as np
+    sim = np.asarray(torch.as_tensor(decoupled_similarity, dtype=torch.float32).cpu().numpy(), dtype=np.float32)
     num_p, num_cls = sim.shape
     n_cases = 2 ** num_p
-    masks = ((torch.arange(n_cases)[:, None] >> torch.arange(num_p)[None, :]) & 1).float()  # [2^P, P]
-    cnt = masks.sum(dim=1)
-    mean_sim = (masks @ sim) / cnt.clamp_min(1)[:, None]
-    prob = F.softmax(float(logit_scale) * mean_sim, dim=1)
-    wts = (num_cls - torch.arange(0, num_cls)).float()
-    V = (prob * wts).sum(dim=1)
+    idx = np.arange(n_cases)
+    masks = ((idx[:, None] >> np.arange(num_p)[None, :]) & 1).astype(np.float32)          # [2^P, P]
+    cnt = masks.sum(axis=1)
+    mean_sim = (masks[:, :, None] * sim[None, :, :]).sum(axis=1) / np.maximum(cnt, 1.0)[:, None]
+    z = np.float32(logit_scale) * mean_sim
+    z = z - z.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    prob = e / e.sum(axis=1, keepdims=True)
+    wts = (num_cls - np.arange(0, num_cls)).astype(np.float32)
+    V = (prob * wts).sum(axis=1).astype(np.float32)
     V[0] = 1.0
     fac = [math.factorial(i) for i in range(num_p + 1)]
-    Wt = torch.tensor([fac[i] * fac[num_p - i - 1] / fac[num_p] for i in range(num_p)])
-    shap = torch.zeros(num_p)
-    idx = torch.arange(n_cases)
+    Wt = np.array([fac[i] * fac[num_p - i - 1] / fac[num_p] for i in range(num_p)], dtype=np.float32)
+    shap_np = np.zeros(num_p, dtype=np.float32)
+    cnt_i = cnt.astype(np.int64)
     for i in range(num_p):
         without = idx[((idx >> i) & 1) == 0]
-        shap[i] = (Wt[cnt[without].long()] * (V[without + (1 << i)] - V[without])).sum()
+        shap_np[i] = (Wt[cnt_i[without]] * (V[without + (1 << i)] - V[without])).sum()
+    shap = torch.from_numpy(shap_np)
+    V = torch.from_numpy(V)
     if verbose:
         print("[SHAP] base", V[0].item(), "full", V[-1].item(), "sum", shap.sum().item())
     return shap
