@@ -96,6 +96,9 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
     unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
     int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
     const bool pok = i16 < P;
+    // compact exchange slot of query p = i16 inside its g block, rotated by 4 g: ds_read_b128 is serviced in the lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... and without the rotation the g and g + 1 parts of a group share banks
+    const int xslot = i16 < bb::kMaxP ? (i16 + 4 * g) % bb::kMaxP : (4 * g) % bb::kMaxP;
 
     // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
     if (tid < B) {
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
             {
                 unsigned char* mine = exch + cw * kExchWave;
                 if (i16 < kMaxP) {  // compact tiles: [h][g][p < 12] x f32x4
-                    *reinterpret_cast<f32x4_ma*>(mine + ((0 * 4 + g) * kMaxP + i16) * 16) = S[0];
-                    *reinterpret_cast<f32x4_ma*>(mine + ((1 * 4 + g) * kMaxP + i16) * 16) = S[1];
-                    *reinterpret_cast<f32x4_ma*>(mine + kTileBytes + ((0 * 4 + g) * kMaxP + i16) * 16) = Dd[0];
-                    *reinterpret_cast<f32x4_ma*>(mine + kTileBytes + ((1 * 4 + g) * kMaxP + i16) * 16) = Dd[1];
+                    *reinterpret_cast<f32x4_ma*>(mine + ((0 * 4 + g) * kMaxP + xslot) * 16) = S[0];
+                    *reinterpret_cast<f32x4_ma*>(mine + ((1 * 4 + g) * kMaxP + xslot) * 16) = S[1];
+                    *reinterpret_cast<f32x4_ma*>(mine + kTileBytes + ((0 * 4 + g) * kMaxP + xslot) * 16) = Dd[0];
+                    *reinterpret_cast<f32x4_ma*>(mine + kTileBytes + ((1 * 4 + g) * kMaxP + xslot) * 16) = Dd[1];
                 }
                 if (g == (i16 >> 2)) {
                     const int r = i16 & 3;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
                 f32x4 T[2], DA[2], R2[2];
                 {
                     f32x4 tv[2][4], dv[2][4], rv[2][4];
-                    const int pidx = i16 < kMaxP ? i16 : 0;  // lanes >= 12 compute nothing useful (masked below)
+                    const int pidx = xslot;  // lanes >= 12 read slot of p = 0 and compute nothing useful (masked below)
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
