@@ -33,6 +33,11 @@ cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.cs
 python tools/bench_train.py > $O/bench_train.txt 2>&1
 python tools/bench_ingest.py > $O/bench_ingest.txt 2>&1
 python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1
+python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
+python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1
+python tools/bench_module.py > $O/bench_module.txt 2>&1
+python tools/bench_paths.py > $O/bench_paths.txt 2>&1
+python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2>/dev/null
 rm -rf $O/train $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
 cat $O/pytest_gpu.txt; cat $O/bench.json | cut -c1-600
