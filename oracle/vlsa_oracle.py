@@ -354,3 +354,36 @@ def vlsa_objective(logits: torch.Tensor, t, e, logit_scale_exp):
     """calc_objective_loss with loss_type SurvIFMLE-SurvEMD, weights 1/1 (runner/vlsa_handler.py:241-258)."""
     inc = torch.softmax(logits, dim=-1)
     return surv_ifmle(inc, t, e) + surv_emd(inc, t, e, logit_scale_exp)
+
+
+# ----------------------------------------------------------------------------------------------
+# Evaluation metric of the training parity test (BASELINE.json: "c-index parity")
+# ----------------------------------------------------------------------------------------------
+def discrete_risk(incidence: torch.Tensor) -> torch.Tensor:
+    """risk score the reference ranks patients by: sum_k S_k with S = 1 - cumsum(incidence) (eval/cindex.py:36-43);
+    LOW values = high risk (the reference passes -risk as the estimate)."""
+    return (1.0 - torch.cumsum(incidence.double(), dim=1)).sum(dim=1)
+
+
+def concordance_index(y_true: torch.Tensor, incidence: torch.Tensor, tied_tol: float = 1e-8) -> float:
+    """Harrell's C as the reference evaluates it (eval/cindex.py:6-43 -> its vendored concordance_index_censored,
+    eval/cindex.py:46 ff., scikit-survival's definition): a pair (i, j) is comparable when i had an event and j's time is
+    later, or equal with j censored; it is concordant when i's estimate (-risk) is larger, half-counted when the two
+    estimates differ by <= tied_tol.  y_true: [n, 2] = (time or time bin, event)."""
+    t, e = y_true[:, 0].double(), y_true[:, 1] > 0.5
+    est = -discrete_risk(incidence)
+    n = t.shape[0]
+    num = den = 0.0
+    for i in range(n):
+        if not bool(e[i]):
+            continue
+        comp = (t > t[i]) | ((t == t[i]) & ~e)
+        comp[i] = False
+        if not bool(comp.any()):
+            continue
+        d = est[i] - est[comp]
+        den += float(comp.sum())
+        num += float((d > tied_tol).sum()) + 0.5 * float((d.abs() <= tied_tol).sum())
+    if den == 0:
+        raise ValueError("no comparable pairs")
+    return num / den

@@ -187,3 +187,21 @@ TRAIN = dict(P=12, K=12, sizes=(300, 517, 900, 64), seed=601, lr=2e-4, wd=1e-5, 
 
 def train_bags():
     return [make_bag(n, TRAIN["seed"] + 10 + i, "clustered" if i % 2 else "iid") for i, n in enumerate(TRAIN["sizes"])]
+
+
+# ---- c-index cases (eval/cindex.py:6-43 through NLLSurv_Evaluator._c_index, eval/evaluator_surv.py:130-133): discrete time
+# bins (many ties in time), incidence predictions [n, K]; some rows get identical predictions (ties in risk).
+CINDEX_CASES = [(40, 4, 8100), (75, 12, 8101), (9, 4, 8102), (200, 8, 8103)]
+
+
+def make_cindex_case(n, K, seed):
+    g = gen(seed)
+    t = torch.randint(0, K, (n,), generator=g).float()
+    e = (torch.rand(n, generator=g) < 0.45).float()
+    e[0] = 1.0
+    inc = torch.softmax(torch.randn(n, K, generator=g) * 1.5, dim=-1)
+    if n >= 8:
+        inc[3] = inc[1]          # tied predictions
+        inc[5] = inc[1]
+        t[3], t[1] = t[1], t[3]
+    return torch.stack([t, e], dim=1), inc

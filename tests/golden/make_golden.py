@@ -289,12 +289,27 @@ def gen_train_step(ref):
     print("train", [out[f"loss{i}"] for i in range(cfg["steps"])])
 
 
+def gen_cindex(ref):
+    """The reference's c-index on discrete predictions (eval/cindex.py:6-43, type_pred='incidence')."""
+    from eval.cindex import concordance_index
+    out = {}
+    for (n, K, seed) in cases.CINDEX_CASES:
+        y, inc = cases.make_cindex_case(n, K, seed)
+        out[f"c{seed}"] = np.array([concordance_index(y.clone(), inc.clone(), type_pred="incidence")], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "cindex.npz"), **out)
+    print("cindex", {k: float(v[0]) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ref = _ref_import.import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "cindex":
+        gen_cindex(ref)
+        sys.exit(0)
     gen_vlfan(ref)
     gen_zeroshot(ref)
     gen_deepmil(ref)
     gen_interpretation(ref)
     gen_misc(ref)
     gen_train_step(ref)
+    gen_cindex(ref)
     print("done")

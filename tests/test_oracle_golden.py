@@ -138,3 +138,11 @@ def test_query_div_loss_matches_reference():
         Q = H.t(fx[f"{tag}.Q"])
         assert abs(O.query_div_loss(Q, 6, True).item() - float(fx[f"{tag}.loss_last_div"])) < 1e-6
         assert abs(O.query_div_loss(Q, 6, False).item() - float(fx[f"{tag}.loss_all"])) < 1e-6
+
+
+def test_concordance_index_matches_reference_fixture():
+    """oracle.concordance_index (the metric of the training parity test) vs the reference's evaluator on seeded cases."""
+    fx = H.load_fixture("cindex")
+    for (n, K, seed) in cases.CINDEX_CASES:
+        y, inc = cases.make_cindex_case(n, K, seed)
+        assert abs(O.concordance_index(y, inc) - float(fx[f"c{seed}"][0])) < 1e-12, seed
