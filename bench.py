@@ -95,6 +95,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and a.gpus > 1:
         sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    # VLSA_BENCH_BACKEND=gloo: development aid to walk the N > 1 code path with several ranks sharing ONE GPU (RCCL refuses
+    # two ranks on one device); the driver's runs use the default, one rank per GPU over RCCL
+    backend = os.environ.get("VLSA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from vlsa_amd import functional as F
@@ -105,7 +110,10 @@ def main():
         import torch.distributed as dist
         if force_sharded and "RANK" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     BPL = max(1, min(a.bags_per_launch, 64))
     bags, Q, T, W, b, ls = synth(device, 100 + rank, BPL)

@@ -1,0 +1,75 @@
+"""world_size = 2 on ONE GPU: two processes share cuda:0 and exchange their compact records through a gloo group (RCCL does
+not allow two ranks on one device; gloo moves CUDA tensors through the host).  Everything above the transport is the real
+N > 1 code on the real kernels: shard bounds, per-rank persistent kernel with reserved CUs, record fold, all-gather,
+global merge + head, the side-stream pipeline of ShardedVlfanBatchPlan and ShardedVlfanPlan.  Both ranks must reproduce the
+unsharded result."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vlsa_amd import functional as F
+        from vlsa_amd.sharded import ShardedVlfanBatchPlan, ShardedVlfanPlan, shard_bounds
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        P, K, B = 12, 4, 5
+        sizes = [20_000, 333, 4097, 64, 9000]
+        params = cases.make_params(P, K, 8200)
+        Q = (0.5 * params["resid"] + params["prompt"]).to(dev)
+        T, W, b = params["T"].to(dev), params["W"].to(dev), params["b"].to(dev)
+        ls = torch.tensor(cases.LOGIT_SCALE, device=dev)
+        full = [cases.make_bag(n, 8210 + i).to(torch.bfloat16).to(dev) for i, n in enumerate(sizes)]
+        shards = []
+        for x in full:
+            a, c = shard_bounds(x.shape[0], world, rank)
+            shards.append(x[a:c])
+        errs = {}
+        # unsharded reference on this rank
+        ref_plan = F.VlfanBatchPlan(B, P, K, dev)
+        ref_plan.set_bags(full)
+        ref = ref_plan.run(Q, T, ls, W, b).clone()
+        for pipeline in (False, True):
+            bp = ShardedVlfanBatchPlan(B, P, K, dev, dist, pipeline=pipeline)
+            bp.set_bags(shards)
+            for _ in range(3):
+                bp.run(Q, T, ls, W, b)
+            got = bp.finish().clone()
+            torch.cuda.synchronize()
+            errs[f"batch pipeline={pipeline}"] = (got - ref).abs().max().item()
+        # single-bag sharded plan, pipelined over 3 bags
+        a, c = shard_bounds(sizes[0], world, rank)
+        sp = ShardedVlfanPlan(c - a, 512, P, K, dev, dist, pipeline=True)
+        outs = []
+        for i in range(3):
+            sp.run(full[0][a:c], Q, T, ls, W, b)
+            if i > 0:
+                outs.append(sp.local.logits.clone())
+        outs.append(sp.finish().clone())
+        torch.cuda.synchronize()
+        errs["single"] = max((o - ref[0]).abs().max().item() for o in outs)
+        ret[rank] = errs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_result():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29800 + (os.getpid() % 150)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        for what, err in ret[r].items():
+            assert err < 2e-5, (r, what, err)
