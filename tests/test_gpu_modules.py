@@ -223,3 +223,22 @@ def test_forward_bags_matches_per_bag_forward():
             assert (logits[i] - l1[0]).abs().max().item() < 2e-5
             assert (feats[i] - f1[0]).abs().max().item() < 1e-5
     assert logits.shape == (5, K)
+
+
+@pytest.mark.parametrize("pooling", ["attention", "gated_attention"])
+def test_forward_bags_with_module_pooling_matches_per_bag_forward(pooling):
+    """query pooling by a module is not fusable into the head kernel: forward_bags still batches the aggregation."""
+    from vlsa_amd.vlsa import VLSA
+    dev = torch.device("cuda", 0)
+    P, K = 12, 4
+    params = cases.make_params(P, K, 9300)
+    torch.manual_seed(3)
+    cfg = dict(name="VLFAN", dim_in=512, dim_hid=64, use_feat_proj=False, query="Parameter", num_query=P, query_pooling=pooling)
+    m = VLSA(cfg, pretrained_text_features=params["T"].clone()).to(dev).eval()
+    bags = [cases.make_bag(n, 9310 + i).to(torch.bfloat16).to(dev)[None] for i, n in enumerate([700, 64, 2798, 1])]
+    with torch.no_grad():
+        lb, fb, tb = m.forward_bags(bags)
+        ref = [m(x) for x in bags]
+    assert (lb - torch.cat([r[0] for r in ref])).abs().max().item() < 1e-4
+    assert (fb - torch.cat([r[1] for r in ref])).abs().max().item() < 1e-5
+    assert (tb - ref[0][2]).abs().max().item() < 1e-6

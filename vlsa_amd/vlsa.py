@@ -186,6 +186,13 @@ class VLSA(nn.Module):
         ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512
                                                           and x.shape[0] > 0 for x in flat))
         if not ok:
+            if (isinstance(enc, VLFAN) and enc.feat_proj is None and len(flat) > 0
+                    and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)):
+                # pooling over the queries by a module (attention / gated attention): batched HIP aggregation, then the
+                # module, the adapter and the cosine logits as batched torch ops on [B, P, 512]
+                That = F.normalize(text_features, dim=-1)
+                feats = F.normalize(enc.forward_bags(flat), dim=-1)
+                return self.logit_scale.exp() * feats @ That.t(), feats, That
             outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), outs[0][2]
         mode, pw, W, b = spec
