@@ -285,6 +285,11 @@ int vlsa_prepare_gated_weights(const float* Wa, const float* ba, const float* Wg
 int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
                       void* stream);
 
+/* DeepMIL's Adapter head on the pooled bag vector f [D] (model/deepmil.py:283-286, model/layers.py:50-62):
+ * out = keep_ratio * f + (1 - keep_ratio) * relu(W2 relu(W1 f)), W1 [R, D], W2 [D, R] (bias-free); hidden: scratch [R]. */
+int vlsa_adapter_head(const float* f, int D, const float* W1, int R, const float* W2, float keep_ratio, float* hidden,
+                      float* out, void* stream);
+
 /*
  * Bag ingest (replaces the per-step host concat + blocking H2D of dataset/PatchWSI.py:205-215 / runner/vlsa_handler.py:205):
  * pack N freshly uploaded rows (fp32 -> bf16 round-to-nearest-even, or bf16 copy) into a resident bf16 arena.

@@ -5,30 +5,29 @@
 // the reference (and the first version here) runs it as two library GEMMs that write [N, 256] fp32 hidden activations to
 // memory and re-read them.  Here: ONE kernel, hidden activations never leave registers.
 //
-//   * workgroup = 128 rows x all 512 hidden units (both branches), 8 waves; wave w owns hidden units [32w, 32w+32) of BOTH
-//     branches, so the gate product is wave-local: 16 C tiles (8 row tiles x 2 column tiles) per branch = 128 accumulator
-//     registers per lane.
-//   * K loop in 16 steps of 32: the wave's weight fragments of a step (bf16 hi + lo split of the fp32 weights, packed in
-//     fragment order by k_prepare_gated_weights: 8 KB, contiguous, L2 resident) are loaded straight into registers one step
-//     ahead (double-buffered); the wave's 1 KB share of the step's X chunk (128 rows x 64 B) is loaded two steps ahead into
-//     registers and published to a double-buffered LDS tile (16-B chunks XOR-swizzled so that the A-fragment ds_read_b128
-//     is conflict free).  One barrier per step.  Plain loads only: the compiler counts vmcnt exactly (a variant with
-//     LDS-DMA for X and register loads for W showed that the two kinds do NOT retire in one common order).
+//   * workgroup = 256 rows x HALF of the hidden units (128 of each branch), 8 waves; wave w owns 16 hidden units of BOTH
+//     branches, so the gate product is wave-local: 16 row tiles x 2 branches = 128 accumulator registers per lane.  The two
+//     workgroups of a row tile add their partial scores into a zeroed a[] (two addends: order-independent).
+//   * K loop in 16 steps of 32: the wave's weight fragments of a step (bf16 hi + lo split of the fp32 weights, pre-scaled by
+//     the exp2 factors and packed in fragment order by k_prepare_gated_weights: 4 KB, contiguous, L2 resident) are loaded
+//     straight into a register ring three steps ahead; the thread's 32 B of the step's X chunk (256 rows x 64 B) are loaded
+//     two steps ahead into registers and published to a double-buffered LDS tile (16-B chunks XOR-swizzled for the
+//     non-contiguous ds_read_b128 lane groups: 0 bank conflicts).  One barrier per step.  Plain loads only: the compiler
+//     counts vmcnt exactly (a variant with LDS-DMA for X and register loads for W showed that the two kinds do NOT retire in
+//     one common order).
 //   * X is bf16 and consumed exactly; weights are 2-term bf16 splits (rel. 2^-17); fp32 accumulation: 64 MFMAs
 //     (16x16x32 bf16) per step and wave, hi and lo terms interleaved so that back-to-back MFMAs never share an accumulator.
-//   * epilogue: bias, tanh / sigmoid (v_exp_f32), gate, dot with w2 over the 32 hidden units of the wave (xor shuffles
-//     over the 16 column lanes), cross-wave sum through LDS, + c.
-// Roofline: nominally MFMA-bound: 2 terms x 2 branches x 2 x 512 x 256 = 1.05 MFLOP per patch -> 52 GFLOP per 50k bag =
-// 21 us at 2.5 PFLOP/s dense bf16.  Measured 74 us per 50k bag (28 %; 35 % at N = 400k); a K step costs a flat 2.0 us
-// (1.35 us without the gate branch) in every pipeline tried (LDS-DMA ring for the weights, register double-buffering,
-// reordered MFMAs, rotated K order), also with only 22 of the 256 CUs busy: ~1600 cycles of per-step fixed cost (barrier,
-// X publish, 8 A reads) + ~1600 cycles per (32 KB of weights + 32 MFMAs per wave).  Per step and CU 72 KB come in
-// (the 1 MB of packed weights is re-read for every 128-row tile: 8 KB per patch row) = 15 B/clk/CU.
-// PMC (N = 400k): MFMA pipe busy 37 % of the kernel, waves parked at waitcnt / barrier 40 %, issue-stalled 35 %, LDS bank
-// conflicts 0 (30 % before the lane-group-aware swizzle -- which did not change the time: LDS is not the limit).  The weight
-// fragments are prefetched exactly one step ahead (register budget: 128 accumulators + 2 x 32 fragment registers of 256), and
-// with the waves in barrier lock step that is not enough to cover an 8 x 8 KB L2 burst per CU.
-// Next step (not done): 256 rows x half of the hidden units per workgroup = 6 instead of 9 KB per row, longer K steps.
+//   * epilogue: accumulators start at the bias; tanh * sigmoid as (1 - u) / ((1 + u)(1 + v)) with two v_exp_f32 and one
+//     v_rcp_f32 per value; dot with w2 over the wave's 16 hidden units by four DPP row rotations; cross-wave sum through LDS.
+//   * bags that fit one round of the 256 CUs use smaller tiles (rows per tile = smallest multiple of 16 that still fits one
+//     round: a 2 798-patch bag runs on 176 CUs instead of 22); larger bags use the static 256-row variant.
+// Roofline: MFMA-bound: 2 terms x 2 branches x 2 x 512 x 256 = 1.05 MFLOP per patch -> 52 GFLOP per 50k bag = 21 us at
+// 2.5 PFLOP/s dense bf16.  Measured 62 us per 50k bag (2 rounds of tiles for 1.53 rounds of work) and 389 us at N = 400k =
+// 1.08 PFLOP/s executed = 43 % of the dense peak (a register-only probe with this accumulator / operand pattern reaches
+// 2.0 PFLOP/s at 2 waves per SIMD, tools/probes/mfma_rate.hip).  What was measured on the way (tools/kbench_gated.py):
+// the loop is NOT load- or barrier-bound (dropping all loads: -12 %, dropping publish + barrier: 0 %, LDS-DMA ring vs
+// register ring vs deeper prefetch: equal); the activations were (~25 % of a tile with IEEE divisions and ds_bpermute
+// shuffles, now ~15 %): N x 512 transcendental pairs at quarter rate are ~12 us per 50k bag on their own.
 #include "vlsa_common.h"
 
 namespace vlsa {
@@ -39,21 +38,22 @@ typedef float __attribute__((may_alias)) float_mag;
 typedef int i32x4g __attribute__((ext_vector_type(4)));
 
 namespace gs {
-constexpr int kRows = 128;
+constexpr int kRows = 256;                        // patch rows per workgroup tile
 constexpr int kHid = 256;
 constexpr int kD = 512;
-constexpr int kSteps = 16;
-constexpr int kXBuf = kRows * 64;                 // one K step of the tile: 128 rows x 32 bf16
+constexpr int kSteps = 16;                        // K steps of 32
+constexpr int kHalves = 2;                        // a workgroup covers kHid / kHalves hidden units (of both branches)
+constexpr int kXBuf = kRows * 64;                 // one K step of the tile: 256 rows x 32 bf16 = 16 KiB
 constexpr int kXOff = 0;
-constexpr int kScrOff = kXOff + 2 * kXBuf;        // 16 KiB
-constexpr int kLds = kScrOff + 8 * kRows * 4;     // + 4 KiB
+constexpr int kScrOff = kXOff + 2 * kXBuf;        // 32 KiB
+constexpr int kLds = kScrOff + 8 * kRows * 4;     // + 8 KiB
 }  // namespace gs
 
 struct GatedPrepLayout {
     size_t wpack, ba, bg, w2, c, total;
     __host__ __device__ explicit GatedPrepLayout(int gated) {
         wpack = 0;
-        ba = wpack + (size_t)8 * gs::kSteps * (gated ? 8 : 4) * 1024;
+        ba = wpack + (size_t)gs::kHalves * 8 * gs::kSteps * (gated ? 4 : 2) * 1024;
         bg = ba + gs::kHid * 4;
         w2 = bg + gs::kHid * 4;
         c = w2 + gs::kHid * 4;
@@ -61,23 +61,26 @@ struct GatedPrepLayout {
     }
 };
 
-// packed[((w * 16 + ks) * NF + f) * 1024 + lane * 16 + 2 e] = term(f & 1) of W_br[32 w + 16 ct + (lane & 15)][32 ks + 8 (lane >> 4) + e]
-// with f = (br * 2 + ct) * 2 + term.   grid = 8 * 16 * NF workgroups of 64 threads.
+// packed[(((half * 8 + w) * 16 + ks) * NF + f) * 1024 + lane * 16 + 2 e] =
+//     term(f & 1) of W_br[128 half + 16 w + (lane & 15)][32 ks + 8 (lane >> 4) + e],   f = br * 2 + term,  NF = 4 (gated) / 2.
+// grid = 2 * 8 * 16 * NF workgroups of 64 threads.
 __global__ __launch_bounds__(64) void k_prepare_gated_weights(const float* __restrict__ Wa, const float* __restrict__ ba,
                                                                const float* __restrict__ Wg, const float* __restrict__ bg,
                                                                const float* __restrict__ w2, const float* __restrict__ c,
                                                                int gated, unsigned char* __restrict__ prep) {
     const GatedPrepLayout L(gated);
-    const int NF = gated ? 8 : 4;
+    const int NF = gated ? 4 : 2;
     const int blk = blockIdx.x, lane = threadIdx.x;
-    const int f = blk % NF, ks = (blk / NF) % gs::kSteps, w = blk / (NF * gs::kSteps);
-    const int term = f & 1, ct = (f >> 1) & 1, br = f >> 2;
+    const int f = blk % NF, ks = (blk / NF) % gs::kSteps, hw = blk / (NF * gs::kSteps);  // hw = half * 8 + w
+    const int term = f & 1, br = f >> 1;
     const float* W = br ? Wg : Wa;
-    const int h = 32 * w + 16 * ct + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    const int h = 16 * hw + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = W[(size_t)h * gs::kD + k0 + e];
+        // branch a is pre-scaled by -2 log2(e), branch g by -log2(e): the accumulators then ARE the v_exp_f32 arguments of
+        // u = e^{-2x} and v = e^{-y} (see gate_act)
+        const float x = W[(size_t)h * gs::kD + k0 + e] * (br ? -kLog2e : -2.f * kLog2e);
         const __bf16 hi = (__bf16)x;
         o[e] = term ? (__bf16)(x - (float)hi) : hi;
     }
@@ -87,137 +90,176 @@ __global__ __launch_bounds__(64) void k_prepare_gated_weights(const float* __res
         float* pbg = reinterpret_cast<float*>(prep + L.bg);
         float* pw2 = reinterpret_cast<float*>(prep + L.w2);
         for (int i = lane; i < gs::kHid; i += 64) {
-            pba[i] = ba ? ba[i] : 0.f;
-            pbg[i] = (gated && bg) ? bg[i] : 0.f;
+            pba[i] = (ba ? ba[i] : 0.f) * (-2.f * kLog2e);
+            pbg[i] = ((gated && bg) ? bg[i] : 0.f) * (-kLog2e);
             pw2[i] = w2[i];
         }
         if (lane == 0) reinterpret_cast<float*>(prep + L.c)[0] = c ? c[0] : 0.f;
     }
 }
 
-__device__ __forceinline__ float fast_tanh(float x) {
-    // tanh x = 1 - 2 / (exp(2x) + 1); exp through v_exp_f32; |x| clamped where the result is +-1 in fp32 anyway
-    const float t = fminf(fmaxf(x, -15.f), 15.f);
-    const float e2 = fast_exp2(t * (2.f * kLog2e));
-    return 1.f - 2.f / (e2 + 1.f);
+// tanh(x) * sigmoid(y) = (1 - u) / ((1 + u)(1 + v)),  u = e^{-2x}, v = e^{-y}: two v_exp_f32 and ONE v_rcp_f32 (1 ulp) per
+// value.  The activations are a real cost here (N x 512 of them per bag at quarter rate; an IEEE division would add ~10
+// VALU instructions each).  The arguments au = -2 log2(e) x and av = -log2(e) y come straight out of the accumulators (weights
+// and biases are pre-scaled); they are clamped from above only: 2^43 * 2^57 keeps (1 + u)(1 + v) finite, where the result
+// is saturated in fp32 anyway, and exp2 of a very negative argument is simply 0.
+__device__ __forceinline__ float gate_act(float au, float av) {
+    const float u = fast_exp2(fminf(au, 43.f)), v = fast_exp2(fminf(av, 57.f));
+    return (1.f - u) * __builtin_amdgcn_rcpf((1.f + u) * (1.f + v));
 }
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    const float t = fminf(fmaxf(x, -80.f), 80.f);
-    return 1.f / (1.f + fast_exp2(-t * kLog2e));
+__device__ __forceinline__ float tanh_act(float au) {
+    const float u = fast_exp2(fminf(au, 43.f));
+    return (1.f - u) * __builtin_amdgcn_rcpf(1.f + u);
+}
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane: four full-rate VALU adds
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
 }
 
-template <bool GATED>
+template <bool GATED, bool FULL>
 __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__ X, long long N, long long ldx,
-                                                       const unsigned char* __restrict__ prep, float* __restrict__ a_out) {
+                                                       const unsigned char* __restrict__ prep, float* __restrict__ a_out,
+                                                       int rows_per_tile) {
     using namespace gs;
-    constexpr int NF = GATED ? 8 : 4;     // weight fragments per step and wave
-    constexpr int NB = GATED ? 4 : 2;     // (branch, column tile) pairs
+    constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
+    constexpr int NB = GATED ? 2 : 1;     // branches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const long long row0 = (long long)blockIdx.x * kRows;
-    const int nrows = (int)((N - row0) < kRows ? (N - row0) : kRows);
+    const int half = blockIdx.x & 1;
+    // rows_per_tile (a multiple of 16, <= 256) is chosen by the host so that the launch is a whole number of full rounds of
+    // the 256 CUs: a 50k-patch bag runs as 2 x 241 tiles of 208 rows instead of 2 x 196 tiles of 256 (1.5 rounds rounded up)
+    // FULL: 256-row tiles, everything static (large bags); otherwise the row-tile count is a run-time, wave-uniform value
+    const int nrt = FULL ? 16 : (rows_per_tile >> 4);
+    const long long row0 = (long long)(blockIdx.x >> 1) * rows_per_tile;
+    const int nrows = (int)((N - row0) < rows_per_tile ? (N - row0) : rows_per_tile);
     const GatedPrepLayout L(GATED ? 1 : 0);
 
-    // plain (compiler-tracked) loads only: weight fragments one step ahead into registers, the wave's 1 KB share of the X
-    // chunk two steps ahead into registers and from there into the shared LDS buffer of its step
-    const unsigned char* wp = prep + L.wpack + (size_t)w * kSteps * NF * 1024 + lane * 16;
-    const int xr = 16 * w + (lane >> 2);                         // this lane's row of the X chunk
+    // plain (compiler-tracked) loads only: weight fragments one step ahead (double-buffered registers; a 4-deep ring measured
+    // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
+    // into the shared LDS tile of its step
+    const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + w) * kSteps * NF * 1024 + lane * 16;
+    const int xr = tid >> 1, xc = (tid & 1) * 2;                  // this thread's row and first 16-B chunk of the X chunk
     const bool xok = xr < nrows;
-    const __bf16* xsrc = X + (row0 + xr) * ldx + (lane & 3) * 8;  // + 32 ks
+    const __bf16* xsrc = X + (row0 + xr) * ldx + xc * 8;          // + 32 ks
     // 16-B chunk c of row r is stored at position c ^ f(r), f(r) = (-(r >> 2)) & 3: ds_read_b128 is serviced in the lane groups
     // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), and with this f the 16 lanes of every
-    // group hit 16 different 4-bank sets (the plain (r >> 2) & 3 swizzle measured 2-way conflicts: PMC 30 %)
-    const int x_dst = xr * 64 + (((lane & 3) ^ ((0 - (xr >> 2)) & 3)) << 4);
+    // group hit 16 different 4-bank sets
+    const int fx = (0 - (xr >> 2)) & 3;
+    const int x_dst0 = xr * 64 + ((xc ^ fx) << 4), x_dst1 = xr * 64 + (((xc + 1) ^ fx) << 4);
     const int a_off = i16 * 64 + ((g ^ ((0 - (i16 >> 2)) & 3)) << 4);    // A fragment of row tile rt: + rt * 1024
-    auto load_x = [&](int ks) -> bf16x8 {
-        bf16x8 z = {};
-        return xok ? *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks) : z;
+    struct XPair { bf16x8 lo, hi; };
+    auto load_x = [&](int ks) -> XPair {
+        XPair r = {};
+        if (xok) {
+            r.lo = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks);
+            r.hi = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8);
+        }
+        return r;
     };
     auto load_b = [&](int ks, bf16x8 (&dst)[NF]) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(ks * NF + f) * 1024);
     };
 
-    f32x4 acc[8][NB];
+    // accumulators start at the (pre-scaled) bias of the lane's hidden unit
+    const int h = 128 * half + 16 * w + i16;
+    const float bav = reinterpret_cast<const float*>(prep + L.ba)[h];
+    const float bgv = GATED ? reinterpret_cast<const float*>(prep + L.bg)[h] : 0.f;
+    const float w2v = reinterpret_cast<const float*>(prep + L.w2)[h];
+    f32x4 acc[16][NB];
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+    for (int rt = 0; rt < 16; ++rt)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[rt][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) {
+            const float bb = b == 0 ? bav : bgv;
+            acc[rt][b] = f32x4{bb, bb, bb, bb};
+        }
 
-    bf16x8 B0[NF], B1[NF], X0, X1;
+    bf16x8 B0[NF], B1[NF], B2[NF], B3[NF];   // FULL: 4-deep ring, weights three steps ahead; else B0 / B1, one step ahead
+    XPair X0, X1;
     X0 = load_x(0);
     load_b(0, B0);
     X1 = load_x(1);
+    if (FULL) {
+        load_b(1, B1);
+        load_b(2, B2);
+    }
 
-    // one K step: publish this step's X share, barrier, start the loads of the next steps, 8 A reads, 64 (32) MFMAs
-    auto step = [&](int s, bf16x8 (&cur)[NF], bf16x8 (&nxt)[NF], bf16x8& xcur) {
+    // one K step: publish this step's X share, barrier, start the loads of later steps, 16 A reads, 64 (32) MFMAs
+    auto step = [&](int s, bf16x8 (&cur)[NF], bf16x8 (&nxt)[NF], XPair& xcur) {
         unsigned char* xb = smem + kXOff + (s & 1) * kXBuf;
-        *reinterpret_cast<bf16x8_mag*>(xb + x_dst) = xcur;
+        *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = xcur.lo;
+        *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = xcur.hi;
         __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
-        if (s + 1 < kSteps) load_b(s + 1, nxt);
+        if (s + (FULL ? 3 : 1) < kSteps) load_b(s + (FULL ? 3 : 1), nxt);
         if (s + 2 < kSteps) xcur = load_x(s + 2);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int q = 0; q < 4; ++q) {
+            if (4 * q >= nrt) break;         // uniform
             bf16x8 A[4];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (4 * h + r4) * 1024 + a_off);
-            // per pair of row tiles: the hi terms of its 2 NB accumulators, then the lo terms -- two MFMAs on the same
-            // accumulator are always 2 NB instructions apart (a dependent back-to-back pair stalls for the MFMA latency)
-#pragma unroll
-            for (int rp = 0; rp < 4; rp += 2)
+            for (int r4 = 0; r4 < 4; ++r4) A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (4 * q + r4) * 1024 + a_off);
+            if (4 * q + 4 <= nrt) {
+                // hi terms of the 4 NB accumulators of this group, then the lo terms: MFMAs on one accumulator are 4 NB apart
 #pragma unroll
                 for (int term = 0; term < 2; ++term)
 #pragma unroll
-                    for (int r4 = rp; r4 < rp + 2; ++r4)
+                    for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
-                            acc[4 * h + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + term], acc[4 * h + r4][b], 0, 0, 0);
+                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + term], acc[4 * q + r4][b], 0, 0, 0);
+            } else {                          // the last, partly filled group of row tiles
+#pragma unroll
+                for (int r4 = 0; r4 < 3; ++r4)
+                    if (4 * q + r4 < nrt) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
+                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + 1], acc[4 * q + r4][b], 0, 0, 0);
+                        }
+                    }
+            }
         }
     };
 #pragma unroll 1
-    for (int s = 0; s < kSteps; s += 2) {
-        step(s, B0, B1, X0);
-        step(s + 1, B1, B0, X1);
+    for (int s = 0; s < kSteps; s += 4) {
+        if (FULL) {
+            step(s, B0, B3, X0);
+            step(s + 1, B1, B0, X1);
+            step(s + 2, B2, B1, X0);
+            step(s + 3, B3, B2, X1);
+        } else {
+            step(s, B0, B1, X0);
+            step(s + 1, B1, B0, X1);
+            step(s + 2, B0, B1, X0);
+            step(s + 3, B1, B0, X1);
+        }
     }
 
-    // ---- epilogue: activations, gate, dot with w2 over this wave's 32 hidden units, then over the 8 waves ----------
-    const float* pba = reinterpret_cast<const float*>(prep + L.ba);
-    const float* pbg = reinterpret_cast<const float*>(prep + L.bg);
-    const float* pw2 = reinterpret_cast<const float*>(prep + L.w2);
-    float bav[2], bgv[2], w2v[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int h = 32 * w + 16 * ct + i16;
-        bav[ct] = pba[h];
-        bgv[ct] = GATED ? pbg[h] : 0.f;
-        w2v[ct] = pw2[h];
-    }
+    // ---- epilogue: activations, gate, w2, sum over this wave's 16 hidden units, then over the 8 waves, then (atomically) over
+    // the two workgroups that share the row tile
     float_mag* scr = reinterpret_cast<float_mag*>(smem + kScrOff);
 #pragma unroll
-    for (int rt = 0; rt < 8; ++rt)
+    for (int rt = 0; rt < 16; ++rt)
+        if (rt < nrt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                float e = fast_tanh(acc[rt][ct][r] + bav[ct]);
-                if (GATED) e *= fast_sigmoid(acc[rt][2 + ct][r] + bgv[ct]);
-                v = fmaf(e, w2v[ct], v);
-            }
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
+            const float e = GATED ? gate_act(acc[rt][0][r], acc[rt][NB - 1][r]) : tanh_act(acc[rt][0][r]);
+            const float v = row16_sum(e * w2v);
             if (i16 == 0) scr[w * kRows + 16 * rt + 4 * g + r] = v;
         }
     __syncthreads();
     if (tid < kRows && tid < nrows) {
-        float s = reinterpret_cast<const float*>(prep + L.c)[0];
+        float sum = half == 0 ? reinterpret_cast<const float*>(prep + L.c)[0] : 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) s += scr[ww * kRows + tid];
-        a_out[row0 + tid] = s;
+        for (int ww = 0; ww < 8; ++ww) sum += scr[ww * kRows + tid];
+        atomicAdd(a_out + row0 + tid, sum);     // two addends per element on a zeroed array: order-independent
     }
 }
 
@@ -231,8 +273,8 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
                                           const float* c, int dim_in, int dim_hid, int gated, void* prep, void* stream) {
     if (!Wa || !w2 || !prep || (gated && !Wg)) return VLSA_EINVAL;
     if (dim_in != gs::kD || dim_hid != gs::kHid) return VLSA_EUNSUPPORTED;
-    const int NF = gated ? 8 : 4;
-    hipLaunchKernelGGL(k_prepare_gated_weights, dim3(8 * gs::kSteps * NF), dim3(64), 0, (hipStream_t)stream, Wa, ba, Wg, bg, w2, c,
+    const int NF = gated ? 4 : 2;
+    hipLaunchKernelGGL(k_prepare_gated_weights, dim3(gs::kHalves * 8 * gs::kSteps * NF), dim3(64), 0, (hipStream_t)stream, Wa, ba, Wg, bg, w2, c,
                        gated ? 1 : 0, static_cast<unsigned char*>(prep));
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
@@ -244,15 +286,28 @@ extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t 
     if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * 2) % 16) || ldx * 2 * gs::kRows >= (1ll << 31)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
     }
-    const unsigned int tiles = (unsigned int)((N + gs::kRows - 1) / gs::kRows);
-    if (gated)
-        hipLaunchKernelGGL(k_gated_scores<true>, dim3(tiles), dim3(512), gs::kLds, (hipStream_t)stream, static_cast<const __bf16*>(X),
-                           (long long)N, (long long)ldx, static_cast<const unsigned char*>(prep), a);
-    else
-        hipLaunchKernelGGL(k_gated_scores<false>, dim3(tiles), dim3(512), gs::kLds, (hipStream_t)stream, static_cast<const __bf16*>(X),
-                           (long long)N, (long long)ldx, static_cast<const unsigned char*>(prep), a);
+    // rows per tile.  One round of the 256 CUs covers 2 halves x 128 tiles: bags that fit (N <= 32768) use the smallest multiple
+    // of 16 rows that still fits one round (a 2 798-patch bag runs as 2 x 88 tiles of 32 rows instead of 2 x 11 of 256);
+    // larger bags use the static 256-row kernel (predicated tiles measured slower there than the rounding loss).
+    int rows_per_tile = gs::kRows;
+    if (N <= 128 * gs::kRows) {
+        rows_per_tile = (int)(((N + 127) / 128 + 15) / 16 * 16);
+        if (rows_per_tile > gs::kRows) rows_per_tile = gs::kRows;
+    }
+    const bool full = rows_per_tile == gs::kRows;
+    const unsigned int tiles = (unsigned int)((N + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
+    const __bf16* Xp = static_cast<const __bf16*>(X);
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+#define VLSA_GS(G, F) hipLaunchKernelGGL((k_gated_scores<G, F>), dim3(tiles), dim3(512), gs::kLds, st, Xp, (long long)N, (long long)ldx, pp, a, rows_per_tile)
+    if (gated) { if (full) VLSA_GS(true, true); else VLSA_GS(true, false); }
+    else       { if (full) VLSA_GS(false, true); else VLSA_GS(false, false); }
+#undef VLSA_GS
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

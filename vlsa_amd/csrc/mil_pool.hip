@@ -536,6 +536,23 @@ __global__ __launch_bounds__(256) void k_normalize_many(const XT* __restrict__ X
     }
 }
 
+// ---- DeepMIL's Adapter head on the pooled bag vector (model/deepmil.py:283-286, model/layers.py:50-62):
+//      out = keep * f + (1 - keep) * relu(W2 relu(W1 f)),  W1 [R, D], W2 [D, R], bias-free.  One wave per output row.
+__global__ __launch_bounds__(256) void k_rows_dot_relu(const float* __restrict__ W, int rows, int cols, const float* __restrict__ x,
+                                                        const float* __restrict__ resid, float keep, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* w = W + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(w + c), b = *reinterpret_cast<const float4*>(x + c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = fmaxf(wave_sum(s), 0.f);
+    if (lane == 0) out[r] = resid != nullptr ? keep * resid[r] + (1.f - keep) * s : s;
+}
+
 }  // namespace vlsa
 
 using namespace vlsa;
@@ -694,6 +711,15 @@ extern "C" int vlsa_normalize_many(const void* X, int x_dtype, int64_t N, int64_
         return VLSA_EINVAL;
     }
 #undef VLSA_NM
+    return st();
+}
+
+extern "C" int vlsa_adapter_head(const float* f, int D, const float* W1, int R, const float* W2, float keep_ratio, float* hidden,
+                                 float* out, void* stream) {
+    if (!f || !W1 || !W2 || !hidden || !out || D < 4 || R < 4 || (D % 4) || (R % 4)) return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_rows_dot_relu, dim3((R + 3) / 4), dim3(256), 0, s, W1, R, D, f, (const float*)nullptr, 0.f, hidden);
+    hipLaunchKernelGGL(k_rows_dot_relu, dim3((D + 3) / 4), dim3(256), 0, s, W2, D, R, hidden, f, keep_ratio, out);
     return st();
 }
 

@@ -244,7 +244,11 @@ class DeepMIL(nn.Module):
             if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
                 raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
         if self.pred_head == "Adapter":
-            logit = self.keep_ratio * out_feat + (1 - self.keep_ratio) * self.visual_adapter(out_feat)
+            fc = self.visual_adapter.fc
+            if not (torch.is_grad_enabled() and any(p.requires_grad for p in fc.parameters())) and out_feat.is_cuda:
+                logit = VF.adapter_head(out_feat, fc[0].weight, fc[2].weight, self.keep_ratio)[None, :]   # two small HIP launches
+            else:
+                logit = self.keep_ratio * out_feat + (1 - self.keep_ratio) * self.visual_adapter(out_feat)
         else:
             logit = self.g(out_feat)
         if ret_with_attn:

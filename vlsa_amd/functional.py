@@ -532,6 +532,19 @@ def colmax(X: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def adapter_head(f: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, keep_ratio: float) -> torch.Tensor:
+    """keep * f + (1 - keep) * relu(W2 relu(W1 f)) for one pooled bag vector f [D] (DeepMIL's Adapter head, inference)."""
+    _need_gpu(f, W1, W2)
+    lib = nat.load()
+    f = _f32c(f).reshape(-1)
+    R, D = W1.shape
+    hid = torch.empty(R, dtype=torch.float32, device=f.device)
+    out = torch.empty(D, dtype=torch.float32, device=f.device)
+    nat.check(lib.vlsa_adapter_head(_p(f), D, _p(_f32c(W1)), R, _p(_f32c(W2)), float(keep_ratio), _p(hid), _p(out), _stream()),
+              "vlsa_adapter_head")
+    return out
+
+
 def attn_scores(H: torch.Tensor, Hg: Optional[torch.Tensor], b1, bg, w2, b2) -> torch.Tensor:
     """a[n] = w2 . (tanh(H[n] + b1) [* sigmoid(Hg[n] + bg)]) + b2 (inference path; H = X W1^T from rocBLAS)."""
     _need_gpu(H)
