@@ -183,6 +183,9 @@ def main():
         dt = float(tt.item())
 
     # ---- roofline of the dominant kernel: HIP events around each launch on the launching stream ----------------
+    # Measured right after the timed region, same plan / bags / launch configuration, one stream: inside the timed region
+    # the launches of the two streams queue behind each other (one persistent workgroup per CU), so an event pair there
+    # would time "wait for the CUs + kernel" (rocprofv3's kernel trace shows the same 2x for the queued launch).
     roof = None
     if rank == 0:
         base = plans[BPL][0].local if hasattr(plans[BPL][0], "local") else plans[BPL][0]
