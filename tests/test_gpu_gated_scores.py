@@ -27,7 +27,7 @@ def _ref(X, Wa, ba, Wg, bg, w2, c):
 
 
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 20000])
+@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 20000, 32768, 32769, 50001])
 def test_fused_scores_vs_torch(N, gated):
     from vlsa_amd import functional as F
     dev = torch.device("cuda", 0)
