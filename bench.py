@@ -239,7 +239,7 @@ def main():
                                  f"{256 - (RESERVED + 7) // 8 * 8} streaming workgroups + {(RESERVED + 7) // 8 * 8} CUs for the tail kernels"},
             "roofline": roof,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure (rank 0 only)
             out["cpu_baseline"] = cpu_baseline()
         try:  # flush anything native libraries (RCCL banner) left in the C stdio buffer, so the JSON is the last line
             import ctypes
