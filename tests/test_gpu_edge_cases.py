@@ -131,3 +131,15 @@ def test_error_codes_not_crashes():
     assert lib.vlsa_topk_mean(p(X), 1, 64, 40, 1.0, p(pm), s) == -2                                               # k > 32 and k < N
     assert lib.vlsa_error_string(-2) == b"unsupported configuration"
     torch.cuda.synchronize()
+
+
+def test_examples_synthetic_demo_runs():
+    """examples/synthetic_demo.py: ingest -> batched evaluation -> training steps -> interpretation, as a user would."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "synthetic_demo.py"), "--patients", "40", "--steps", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "demo ok" in r.stdout
