@@ -52,10 +52,18 @@ class ShardedVlfanPlan:
         self.group = group
         self.world = self.dist.get_world_size(group)
         self.local = VF.VlfanInferencePlan(N_local, D, P, K, device, gated=gated, pool=pool, identity_head=identity_head,
-                                           want_attn=want_attn)
+                                           want_attn=False)
         self.P, self.D, self.K = P, D, K
         rf = record_floats(P, D)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        # Attention weights (model/deepmil.py:198,206-215) stay sharded: A[:, shard].  With the pipeline the streaming kernel
+        # of bag i+1 runs BEFORE the tail of bag i, so everything the tail reads that the streaming kernel writes is held
+        # per slot -- the record, the gathered records and the raw scores; A is per slot so that a caller can still read
+        # bag i's weights after bag i+1 was enqueued.
+        self.want_attn = want_attn
+        self.scores = [f(P, N_local), f(P, N_local)] if want_attn else [None, None]
+        self.A_slots = [f(P, N_local), f(P, N_local)] if want_attn else [None, None]
+        self.A = None                                   # weights of the last bag whose tail was enqueued ([P, N_local])
         self.rec = [f(rf), f(rf)]                       # double-buffered: bag i's record is in flight while i+1 computes
         self.gathered = [f(self.world, rf), f(self.world, rf)]
         self.comm_stream = torch.cuda.Stream(device=device) if pipeline else None
@@ -74,7 +82,7 @@ class ShardedVlfanPlan:
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
         c(lib.vlsa_vlfan_partial(p(X), dt, pl_.N, X.stride(0), self.D, p(pl_.qprep), self.P, pl_.kernel, p(pl_.pm),
-                                 p(pl_.pl), p(pl_.pacc), p(pl_.scores), s), "vlfan_partial")
+                                 p(pl_.pl), p(pl_.pacc), p(self.scores[slot]), s), "vlfan_partial")
         rec = self.rec[slot]
         # fold the workgroup partials into the compact record in place: m2 -> rec[0:16], l -> rec[16:32], acc -> rec[32:]
         c(lib.vlsa_vlfan_merge(p(pl_.pm), p(pl_.pl), p(pl_.pacc), pl_.G, self.P, self.D, 0, p(rec),
@@ -90,8 +98,10 @@ class ShardedVlfanPlan:
         c(lib.vlsa_vlfan_merge_strided(ctypes.c_void_p(base), rf, ctypes.c_void_p(base + 4 * nat.P_STRIDE), rf,
                                        ctypes.c_void_p(base + 4 * REC_HDR), rf, self.world, self.P, self.D, 1,
                                        p(pl_.m2), p(pl_.l), p(pl_.out), s), "vlfan_merge(global)")
-        if pl_.scores is not None:
-            c(lib.vlsa_attn_normalise(p(pl_.scores), self.P, pl_.N, p(pl_.m2), p(pl_.l), p(pl_.A), s), "attn_normalise")
+        if self.want_attn:
+            c(lib.vlsa_attn_normalise(p(self.scores[slot]), self.P, pl_.N, p(pl_.m2), p(pl_.l), p(self.A_slots[slot]), s),
+              "attn_normalise")
+            self.A = self.A_slots[slot]
         c(lib.vlsa_normalize_rows(p(T), self.K, self.D, p(pl_.That), p(pl_.tnorm), s), "normalize_rows")
         c(lib.vlsa_head_forward(p(pl_.out), self.P, self.D, pl_.pool, p(pool_w), None if pl_.identity_head else p(W),
                                 None if pl_.identity_head else p(b), p(pl_.That), self.K, p(ls), p(pl_.ws), p(pl_.pooled),
@@ -99,7 +109,8 @@ class ShardedVlfanPlan:
 
     # -- driver ----------------------------------------------------------------------------------------------
     def run(self, X_local, Q, T, logit_scale, W=None, b=None, pool_w=None):
-        """Enqueue one bag. With pipeline=True the logits of THIS bag are valid after the next run() or finish()."""
+        """Enqueue one bag. With pipeline=True the logits (``local.logits``) and attention weights (``A``, this rank's
+        columns) of THIS bag are valid after the next run() or finish(); ``A`` stays intact until two more bags are run."""
         slot = self._i & 1
         self._i += 1
         cur = torch.cuda.current_stream()
