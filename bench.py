@@ -3,19 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json): synthetic 50k x 512 bf16 CONCH bag, P = 12 text-prototype queries, K = 4 ordinal rank
-prompts, mean query pooling, Linear(512,512) visual adapter -- `configs[2]`, the configuration the metric is quoted
-on.  A step = ONE bag through query/text normalisation, the streaming aggregation, the partial merge and the incidence
-head (= VLSA.forward in eval mode with cached text features, reference model/vlsa.py:181-198).  Bags are resident in
-HBM before the timed region.  Steps are issued 32 bags per launch (the reference's own batch of 32 bags per optimizer
-step, cfg_vlsa_conch.yaml:117-118; its eval loop is the same independent-bag stream): one persistent streaming kernel
-walks 32 DISTINCT bags (1.6 GB > the 256 MiB Infinity Cache, so every byte comes from HBM), then one batched merge and
-one batched head; query and text normalisation run once per launch (they are bag-independent).
+A STEP = one pass of the hot path over one batch = ONE launch of 32 distinct HBM-resident bags (the reference's own
+batch of 32 bags per optimizer step, cfg_vlsa_conch.yaml:117-118; its eval loop is the same independent-bag stream)
+through query / text normalisation, the persistent streaming aggregation kernel, the partial merge and the incidence
+head (= VLSA.forward in eval mode with cached text features, reference model/vlsa.py:181-198, once per bag).  The
+timed region is EXACTLY K such steps after W untimed ones, bracketed by barrier + synchronize; value = patches of all K
+steps / that time.  32 bags x 51.2 MB = 1.6 GB per step > the 256 MiB Infinity Cache: every byte comes from HBM.
 
-N > 1: every bag is N x 50k patches, patch-sharded across the ranks (weak scaling: 50k rows per GPU per bag); per
-launch each rank streams its shards of the 32 bags, folds them into 32 compact records, ONE RCCL all-gather moves
-world x 32 x 24.7 KB, every rank merges and runs the replicated head; the collective of launch i overlaps the streaming
-kernel of launch i+1.  value = whole-job patches/s.
+N = 1  -> BASELINE.json configs[2]: 50k x 512 bf16 bags, P = 12 queries, K = 4 rank prompts (the configuration the
+          metric is quoted on).  The line also carries `strong_scaling_base`: configs[3]'s 200k-patch, K = 8 bags on
+          this one GPU (what the N > 1 runs divide among the ranks).
+N > 1  -> BASELINE.json configs[3], STRONG scaling: 200k x 512 bf16 bags, P = 12, K = 8, every bag patch-sharded
+          across the N ranks (200k / N rows per GPU: 25k at N = 8).  Per step each rank streams its shards of the 32
+          bags, folds them into 32 compact records, ONE RCCL all-gather moves world x 32 x 24.7 KB, every rank merges
+          and runs the replicated head; the collective of step i overlaps the streaming kernel of step i+1.
+          `weak_scaling` in the same line = the round-1 workload (bags of N x 50k patches, 50k rows per GPU, K = 4).
 """
 import argparse
 import json
@@ -28,66 +30,92 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PER_GPU = 50_000
-D, P, K = 512, 12, 4
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+D, P = 512, 12
+BAGS_PER_STEP = 32
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+FLOP_PER_PATCH = 2 * 512 * P * 2 + 2 * 512   # scores + weighted sum + norm = 25 600 at P = 12
+CONFIGS = {"configs[2]": dict(rows=50_000, K=4), "configs[3]": dict(rows=200_000, K=8)}
 
 
-def synth(device, seed, n_bags):
-    g = torch.Generator(device=device).manual_seed(seed)
-    bags = [torch.randn(N_PER_GPU, D, device=device, generator=g).to(torch.bfloat16) for _ in range(n_bags)]
+def synth_params(device, K):
     gq = torch.Generator(device=device).manual_seed(1234)  # parameters identical on every rank
     Q = 0.5 * torch.randn(P, D, device=device, generator=gq) + torch.randn(P, D, device=device, generator=gq)
     T = torch.randn(K, D, device=device, generator=gq)
     W = (torch.rand(D, D, device=device, generator=gq) * 2 - 1) / D ** 0.5
     b = (torch.rand(D, device=device, generator=gq) * 2 - 1) / D ** 0.5
     ls = torch.tensor(4.0309, device=device)
-    return bags, Q, T, W, b, ls
+    return Q, T, W, b, ls
+
+
+def synth_bags(device, seed, n_bags, rows):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return [torch.randn(rows, D, device=device, generator=g).to(torch.bfloat16) for _ in range(n_bags)]
 
 
 def cpu_baseline(seconds=10.0):
-    """The CPU oracle (restatement of the reference's torch op sequence, pinned to the reference by
-    tests/golden) timed on this host's cores on the same workload: kind = "port"."""
+    """The CPU oracle (restatement of the reference's torch op sequence, pinned to the reference by tests/golden)
+    timed on this host's cores on configs[2]'s bag: kind = "port".  `cores` = the torch thread count actually used,
+    picked by a warmed best-of-3 calibration (torch CPU kernels stop scaling well below a GPU host's core count)."""
     from oracle import vlsa_oracle as O
     ncpu = os.cpu_count() or 1
+    rows, K = CONFIGS["configs[2]"]["rows"], CONFIGS["configs[2]"]["K"]
     g = torch.Generator().manual_seed(7)
-    X = torch.randn(N_PER_GPU, D, generator=g).to(torch.bfloat16).float()
+    X = torch.randn(rows, D, generator=g).to(torch.bfloat16).float()
     Q = torch.randn(P, D, generator=g)
     T = torch.randn(K, D, generator=g)
     W = torch.randn(D, D, generator=g) / D ** 0.5
     b = torch.randn(D, generator=g) / D ** 0.5
     ls = torch.tensor(4.0309)
+
+    def one():
+        O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+
     with torch.no_grad():
-        # torch CPU kernels stop scaling (and then regress) well below the core count of a GPU host: pick the
-        # fastest thread count from a short calibration and report THAT many cores.
         best = (float("inf"), 1)
-        for th in sorted({1, 8, 16, 32, 64, ncpu} & set(range(1, ncpu + 1))):
+        cands = sorted({1, 8, 16, 32, 64, ncpu} & set(range(1, ncpu + 1)))
+        for th in cands:
             torch.set_num_threads(th)
-            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
-            t0 = time.perf_counter()
-            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
-            best = min(best, (time.perf_counter() - t0, th))
+            one()                                    # warm: thread pool + allocator at this width
+            t = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                one()
+                t = min(t, time.perf_counter() - t0)
+            best = min(best, (t, th))
         cores = best[1]
         torch.set_num_threads(cores)
+        one()
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            O.vlsa_vlfan_forward(X, Q, T, ls, head_weight=W, head_bias=b)
+            one()
             n += 1
         dt = time.perf_counter() - t0
-    return {"value": N_PER_GPU * n / dt, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": f"{n} bags of 50000x512 (fp32 math on bf16-rounded values) in {dt:.1f} s, torch {torch.__version__} CPU, "
-                      f"best of 1/8/16/32/64/{ncpu} threads"}
+    return {"value": rows * n / dt, "unit": "patches/s", "cores": cores, "host_cores": ncpu, "kind": "port",
+            "sample": f"{n} bags of {rows}x512 (fp32 math on bf16-rounded values) in {dt:.1f} s, torch {torch.__version__} "
+                      f"CPU with {cores} threads (fastest of {'/'.join(map(str, cands))}, warmed best-of-3 each)"}
+
+
+def load_pmc():
+    for name in ("r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), "profiles/" + name
+            except Exception:
+                pass
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12800)
-    ap.add_argument("--warmup", type=int, default=2560)
-    ap.add_argument("--bags-per-launch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=400, help="timed steps (one step = one 32-bag launch)")
+    ap.add_argument("--warmup", type=int, default=80)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
     ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs without a streaming workgroup (-1: 32 when N > 1, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurement (strong_scaling_base / weak_scaling)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,6 +131,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from vlsa_amd import functional as F
+    from vlsa_amd.sharded import shard_bounds
 
     dist = None
     force_sharded = os.environ.get("VLSA_BENCH_FORCE_SHARDED") == "1"  # exercise the N > 1 code path on one GPU
@@ -115,130 +144,158 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    BPL = max(1, min(a.bags_per_launch, 64))
-    bags, Q, T, W, b, ls = synth(device, 100 + rank, BPL)
-
-    # N > 1: 32 of the 256 CUs (4 per XCD) carry no persistent streaming workgroup, so that the RCCL all-gather and the tail
-    # kernels of launch i run there while launch i+1 streams on the other 224.  N = 1: all 256 stream
-    # (reserving 32 measured +1 % step throughput for -3 % on the streaming kernel: within noise, not taken).
-    RESERVED = a.reserved_cus if a.reserved_cus >= 0 else (32 if (dist is not None and a.streams > 1) else 0)
-
-    def make_plan(nb):
-        if dist is None:
-            pl = F.VlfanBatchPlan(nb, P, K, device, reserved_cus=RESERVED)
-        else:
-            from vlsa_amd.sharded import ShardedVlfanBatchPlan
-            pl = ShardedVlfanBatchPlan(nb, P, K, device, dist, reserved_cus=RESERVED)
-        pl.set_bags(bags[:nb])
-        return pl
-
-    # Independent launches alternate between NS streams (each with its own plan = its own output / workspace buffers):
-    # the small merge / head / prepare kernels of one launch overlap the streaming kernel of the next.
+    BPL = BAGS_PER_STEP
     NS = max(1, a.streams)
+    RAMP = int(os.environ.get("VLSA_BENCH_RAMP", "48"))   # untimed clock-ramp launches (50k-row equivalents) before the warm-up
+    # N > 1: 32 of the 256 CUs (4 per XCD) carry no persistent streaming workgroup, so that the RCCL all-gather and the tail
+    # kernels of step i run there while step i+1 streams on the other 224.  N = 1: all 256 stream.
+    RESERVED = a.reserved_cus if a.reserved_cus >= 0 else (32 if (dist is not None and NS > 1) else 0)
     streams = [torch.cuda.Stream(device=device) for _ in range(NS)]
-    plans = {BPL: [make_plan(BPL) for _ in range(NS)]}
-
-    def run_steps(n_steps):
-        """exactly n_steps bags: full launches of BPL bags + one smaller launch for the remainder"""
-        cur = torch.cuda.current_stream()
-        for st in streams:
-            st.wait_stream(cur)
-        for i in range(n_steps // BPL):
-            with torch.cuda.stream(streams[i % NS]):
-                plans[BPL][i % NS].run(Q, T, ls, W, b)
-        rem = n_steps % BPL
-        if rem:
-            if rem not in plans:
-                plans[rem] = [make_plan(rem)]
-            with torch.cuda.stream(streams[0]):
-                plans[rem][0].run(Q, T, ls, W, b)
-        for i, pls in enumerate(plans.values()):
-            for j, pl in enumerate(pls):
-                if hasattr(pl, "finish"):
-                    with torch.cuda.stream(streams[j % NS]):
-                        pl.finish()
-        for st in streams:
-            cur.wait_stream(st)
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed, before the W warm-up steps: ~15 ms of the same launches so that the GPU clocks have ramped (an MI355X drops
-    # its clocks within a few hundred us of idling and needs ~5 ms to come back; profiles/README.md) and every plan exists.
-    run_steps(BPL * 48)
-    for n in {a.warmup, a.steps % BPL} - {0}:  # creates every plan the timed region needs
-        run_steps(n)
-    sync()
+    def measure(rows_local, rows_global, K, steps, warmup, seed, roofline):
+        """K-class head, BPL bags of `rows_local` rows on this rank (`rows_global` over all ranks).  Returns
+        (seconds of `steps` steps = max over ranks, roofline dict or None)."""
+        bags = synth_bags(device, seed, BPL, rows_local)
+        Q, T, W, b, ls = synth_params(device, K)
+        plans = []
+        for _ in range(NS):          # one plan per stream = its own output / workspace buffers
+            if dist is None:
+                pl = F.VlfanBatchPlan(BPL, P, K, device, reserved_cus=RESERVED)
+            else:
+                from vlsa_amd.sharded import ShardedVlfanBatchPlan
+                pl = ShardedVlfanBatchPlan(BPL, P, K, device, dist, reserved_cus=RESERVED)
+            pl.set_bags(bags)
+            plans.append(pl)
 
-    sync()
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        def run_steps(n):
+            cur = torch.cuda.current_stream()
+            for st in streams:
+                st.wait_stream(cur)
+            for i in range(n):       # independent launches alternate between the streams: the small merge / head /
+                with torch.cuda.stream(streams[i % NS]):      # prepare kernels of one step overlap the next step's stream
+                    plans[i % NS].run(Q, T, ls, W, b)
+            for j, pl in enumerate(plans):
+                if hasattr(pl, "finish"):
+                    with torch.cuda.stream(streams[j]):
+                        pl.finish()
+            for st in streams:
+                cur.wait_stream(st)
 
-    # ---- roofline of the dominant kernel: HIP events around each launch on the launching stream ----------------
-    # Measured right after the timed region, same plan / bags / launch configuration, one stream: inside the timed region
-    # the launches of the two streams queue behind each other (one persistent workgroup per CU), so an event pair there
-    # would time "wait for the CUs + kernel" (rocprofv3's kernel trace shows the same 2x for the queued launch).
-    roof = None
+        # Untimed, before the W warm-up steps: ~15 ms of the same launches so that the GPU clocks have ramped (an MI355X
+        # drops its clocks within a few hundred us of idling and needs ~5 ms to come back; profiles/README.md).
+        run_steps(max(16, int(RAMP * 50_000 / max(rows_local, 1))))
+        run_steps(warmup)
+        sync()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+
+        roof = None
+        if roofline and rank == 0:
+            # ---- roofline of the dominant kernel: HIP events around each launch on the launching stream (= the current
+            # stream here).  Measured right after the timed region, same plan / bags / launch configuration, one stream:
+            # inside the timed region the launches of the two streams queue behind each other (one persistent workgroup
+            # per CU), so an event pair there would time "wait for the CUs + kernel".
+            base = plans[0].local if hasattr(plans[0], "local") else plans[0]
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+            for _ in range(24):      # the event set-up above idled the GPU: let the clocks ramp back up
+                base.run_partial_only()
+            torch.cuda.synchronize()
+            for e0, e1 in ev:
+                e0.record()
+                base.run_partial_only()
+                e1.record()
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+            for e0, e1 in ev:        # an event pair around NOTHING = the pair's own cost on this stream; subtracted so that
+                e0.record()          # the figure is the kernel's duration (what rocprofv3 --kernel-trace reports)
+                e1.record()
+            torch.cuda.synchronize()
+            null_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
+            ts = [max(t - null_ms, 0.0) for t in ts]
+            avg_ms = sum(ts) / len(ts)
+            algo_bytes = BPL * rows_local * D * 2    # 1024 B per bf16 patch row (SURVEY.md 8(d)) x rows per launch
+            ach = algo_bytes / (avg_ms * 1e-3) / 1e9
+            tfl = BPL * rows_local * FLOP_PER_PATCH / (avg_ms * 1e-3) / 1e12
+            wgs = 256 - (RESERVED + 7) // 8 * 8
+            roof = {"bound": "hbm", "kernel": f"k_vlfan_partial_dma_batch (bf16 rows, D=512, {wgs} workgroups)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "avg_us": round(avg_ms * 1e3, 2), "min_us": round(ts[0] * 1e3, 2),
+                    "event_pair_us": round(null_ms * 1e3, 2), "bags_per_launch": BPL, "bytes_per_launch": algo_bytes,
+                    "mfma_util": None,
+                    "mfma_algorithmic": {"achieved": round(tfl, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
+                                         "note": "25 600 FLOP per patch (SURVEY.md 8(d)); the split-bf16 repeats are not counted"}}
+            # HBM traffic and matrix-pipe occupancy of this kernel / launch configuration from the committed PMC passes
+            # (separate `--pmc` runs of tools/run_batch.py 32 50000; FETCH_SIZE x 2 = the guide's gfx950 16-B/lane
+            # correction; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)).
+            pmc, src = load_pmc()
+            if pmc and rows_local == 50_000 and dist is None:
+                try:
+                    roof["traffic"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
+                    roof["traffic_source"] = f"{src} (rocprofv3 --pmc, 32 x 50k bags per launch)"
+                    cyc = pmc.get("GRBM_GUI_ACTIVE") or pmc["SQ_BUSY_CYCLES"] / 32.0   # SQ_BUSY_CYCLES sums the 32 shader engines
+                    roof["mfma_util"] = round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
+                except Exception:
+                    pass
+        del plans, bags
+        torch.cuda.empty_cache()
+        return dt, roof
+
+    extra = None
+    if world == 1 and not force_sharded:
+        cfg, scaling = "configs[2]", "strong"
+        rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
+        dt, roof = measure(rows, rows, K, a.steps, a.warmup, 100, True)
+        total = BPL * rows * a.steps
+        workload = (f"{cfg}: synthetic 50k x 512 bf16 bags, P=12 queries, K=4 rank prompts, mean pooling + Linear(512,512) "
+                    f"head; one step = one launch of {BPL} distinct bags")
+        if not a.no_extra:
+            r3, K3 = CONFIGS["configs[3]"]["rows"], CONFIGS["configs[3]"]["K"]
+            s3 = max(4, a.steps // 4)
+            dt3, _ = measure(r3, r3, K3, s3, max(1, a.warmup // 4), 300, False)
+            extra = ("strong_scaling_base", {"workload": "configs[3] on ONE GPU: 200k x 512 bf16 bags, P=12, K=8 (what --gpus N shards)",
+                                             "value": BPL * r3 * s3 / dt3, "unit": "patches/s", "steps": s3,
+                                             "ms_per_step": dt3 / s3 * 1e3})
+    else:
+        cfg, scaling = "configs[3]", "strong"
+        rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
+        lo, hi = shard_bounds(rows, world, rank)
+        dt, roof = measure(hi - lo, rows, K, a.steps, a.warmup, 100 + rank, True)
+        total = BPL * rows * a.steps
+        workload = (f"{cfg}: synthetic 200k x 512 bf16 bags, P=12, K=8, patch-sharded over {world} GPUs ({rows // world} rows per "
+                    f"GPU per bag), one RCCL all-gather of compact records per step; one step = one launch of {BPL} bags")
+        if not a.no_extra:
+            rw, Kw = CONFIGS["configs[2]"]["rows"], CONFIGS["configs[2]"]["K"]
+            dtw, _ = measure(rw, rw * world, Kw, a.steps, a.warmup, 500 + rank, False)
+            extra = ("weak_scaling", {"workload": f"bags of {world} x 50k patches, 50k rows per GPU per bag, P=12, K=4 (round-1 --gpus workload)",
+                                      "value": BPL * rw * world * a.steps / dtw, "unit": "patches/s", "steps": a.steps,
+                                      "ms_per_step": dtw / a.steps * 1e3, "scaling": "weak"})
+
     if rank == 0:
-        base = plans[BPL][0].local if hasattr(plans[BPL][0], "local") else plans[BPL][0]
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-        for _ in range(24):  # the event set-up above idled the GPU: let the clocks ramp back up (takes a few ms)
-            base.run_partial_only()
-        torch.cuda.synchronize()
-        for e0, e1 in ev:
-            e0.record()
-            base.run_partial_only()
-            e1.record()
-        torch.cuda.synchronize()
-        ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-        # an event pair around NOTHING measures the pair's own cost on this stream; subtract it so the figure is the
-        # kernel's duration (what rocprofv3 --kernel-trace reports), not duration + event overhead
-        for e0, e1 in ev:
-            e0.record()
-            e1.record()
-        torch.cuda.synchronize()
-        null_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
-        ts = [max(t - null_ms, 0.0) for t in ts]
-        avg_ms = sum(ts) / len(ts)
-        algo_bytes = BPL * N_PER_GPU * D * 2  # 1024 B per bf16 patch row (SURVEY.md 8(d)) x rows per launch
-        ach = algo_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_vlfan_partial_dma_batch (bf16 rows, D=512, {256 - (RESERVED + 7) // 8 * 8} workgroups)", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
-                "avg_us": round(avg_ms * 1e3, 2), "min_us": round(ts[0] * 1e3, 2), "event_pair_us": round(null_ms * 1e3, 2),
-                "bags_per_launch": BPL, "bytes_per_launch": algo_bytes}
-        # HBM traffic of this kernel/configuration from the committed PMC passes (separate `--pmc FETCH_SIZE` /
-        # `--pmc WRITE_SIZE` runs of tools/run_batch.py; FETCH_SIZE x 2 = gfx950 16-B/lane correction, MI355X_MICROARCH.md)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_batch_kernel.json")))
-            if BPL == 32:
-                roof["traffic"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
-                roof["traffic_source"] = "profiles/r01_pmc_batch_kernel.json (rocprofv3 --pmc, 32 x 50k bags per launch)"
-        except Exception:
-            pass
-    if dist is not None:
-        dist.barrier()
-
-    if rank == 0:
-        total_patches = N_PER_GPU * world * a.steps
+        wgs = 256 - (RESERVED + 7) // 8 * 8
         out = {
-            "metric": "patches/sec per slide (50k x 512 CONCH bag)", "value": total_patches / dt, "unit": "patches/s",
+            "metric": "patches/sec per slide (50k x 512 CONCH bag)", "value": total / dt, "unit": "patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic 50k x 512 bf16 bag per GPU, P=12 queries, K=4 rank prompts, "
-                                   "mean pooling + Linear(512,512) head; N GPUs = bags of N*50k patches, patch-sharded",
-                       "rows_per_gpu": N_PER_GPU, "D": D, "P": P, "K": K, "bags_per_launch": BPL,
-                       "distinct_bags": BPL, "launch": f"eager, 5 kernel launches per {BPL} bags, launches alternate over {NS} streams, "
-                                 f"{256 - (RESERVED + 7) // 8 * 8} streaming workgroups + {(RESERVED + 7) // 8 * 8} CUs for the tail kernels"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu_per_bag": rows // world, "D": D, "P": P, "K": K,
+                       "bags_per_step": BPL, "distinct_bags": BPL, "patches_per_step": BPL * rows,
+                       "launch": f"eager, 5 kernel launches per step, steps alternate over {NS} streams, {wgs} streaming "
+                                 f"workgroups + {256 - wgs} CUs for the tail kernels"},
             "roofline": roof,
         }
+        if extra is not None:
+            out[extra[0]] = extra[1]
         if not a.no_cpu_baseline and world == 1:   # the CPU baseline is an N = 1 figure (rank 0 only)
             out["cpu_baseline"] = cpu_baseline()
         try:  # flush anything native libraries (RCCL banner) left in the C stdio buffer, so the JSON is the last line
@@ -249,6 +306,7 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
