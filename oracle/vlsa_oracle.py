@@ -89,12 +89,14 @@ def query_pooling(out: torch.Tensor, method: str, params: Optional[Dict[str, tor
 def vlfan_forward(X: torch.Tensor, Q: torch.Tensor, *, gated_query: bool = False,
                   query_pooling_method: str = "mean", pooling_params=None,
                   head_weight: Optional[torch.Tensor] = None, head_bias: Optional[torch.Tensor] = None,
-                  scale: float = COATTN_SCALE):
-    """VLFAN.forward with use_feat_proj=False (model/deepmil.py:170-215).
+                  scale: float = COATTN_SCALE, feat_proj: Optional[Tuple[torch.Tensor, ...]] = None):
+    """VLFAN.forward (model/deepmil.py:170-215); feat_proj = (w, b, ln_w, ln_b) when use_feat_proj=True.
 
     Returns dict(v[D], A[P,N], out[P,D], pooled[D], pool_ext).
     head_weight None <=> pred_head='Identity'.
     """
+    if feat_proj is not None:          # use_feat_proj=True: Linear + LayerNorm on every patch row (model/deepmil.py:176-179)
+        X = feat_projecter_forward(X, *feat_proj)
     A_ = vlfan_attention_logits(X, Q, gated_query, scale)
     A = torch.softmax(A_, dim=-1)
     out = A @ X  # un-normalised X, model/deepmil.py:200
@@ -210,6 +212,22 @@ def taskres_query(prompt_features: torch.Tensor, residual: torch.Tensor, res_rat
         n = neg_prompt_features if neg_residual is None else res_ratio * neg_residual + neg_prompt_features
         q = torch.cat([q, n], dim=0)
     return q
+
+
+def prompt_adapter_forward(method: str, prompt_features: torch.Tensor, *, residual=None, res_ratio: float = 0.5,
+                           neg_prompt_features=None, neg_residual=None, adapter=None, keep_ratio: float = 0.8,
+                           fc_weight=None) -> torch.Tensor:
+    """PromptAdapter.forward in eval mode for every method (model/prompt_learners/prompt_adapter.py:118-149):
+    'default' -> the frozen features; 'Adapter' -> (1-keep) Adapter(f) + keep f (the negative prompt is NOT appended);
+    'TaskRes' -> see taskres_query; 'FC' -> [f ; neg] W^T (bias-free Linear, dropout off)."""
+    if method == "Adapter":
+        return (1 - keep_ratio) * adapter_forward(prompt_features, adapter[0], adapter[1]) + keep_ratio * prompt_features
+    if method == "TaskRes":
+        return taskres_query(prompt_features, residual, res_ratio, neg_prompt_features, neg_residual)
+    if method == "FC":
+        src = prompt_features if neg_prompt_features is None else torch.cat([prompt_features, neg_prompt_features], dim=0)
+        return src @ fc_weight.t()
+    return prompt_features
 
 
 def vlsa_vlfan_forward(X, Q, T, logit_scale, **vlfan_kw):

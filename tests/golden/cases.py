@@ -205,3 +205,50 @@ def make_cindex_case(n, K, seed):
         inc[5] = inc[1]
         t[3], t[1] = t[1], t[3]
     return torch.stack([t, e], dim=1), inc
+
+
+# ---- round-2 cases: Feat_Projecter in front of the encoders, DeepMIL's Linear head, PromptAdapter variants, bf16 DeepMIL ----
+def make_featproj_params(seed: int, d: int = D):
+    """Feat_Projecter = Linear(d, d) + LayerNorm(d) (model/layers.py:65-82) with a non-trivial affine LayerNorm."""
+    g = gen(seed)
+    bd = 1.0 / math.sqrt(d)
+    return dict(w=_uniform(g, (d, d), bd), b=_uniform(g, (d,), bd),
+                gamma=1.0 + 0.1 * torch.randn(d, generator=g), beta=0.1 * torch.randn(d, generator=g))
+
+
+def make_linear_params(seed: int, d_out: int, d_in: int, bias: bool = True):
+    g = gen(seed)
+    bd = 1.0 / math.sqrt(d_in)
+    out = dict(w=_uniform(g, (d_out, d_in), bd))
+    if bias:
+        out["b"] = _uniform(g, (d_out,), bd)
+    return out
+
+
+FEATPROJ_CASES = [
+    # name,            encoder,  N,   P, K, pooling,           seed
+    ("fp_vlfan",       "VLFAN",  200, 8, 8, "mean",            701),
+    ("fp_deepmil",     "DeepMIL", 150, 0, 4, "gated_attention", 702),
+    ("fp_deepmil_mean", "DeepMIL", 64, 0, 4, "mean",            703),
+]
+
+DEEPMIL_HEAD_CASES = [
+    # name, N, K, pooling, seed   (pred_head='default': self.g = Linear(dim_in, num_cls), model/deepmil.py:257-259,288-289)
+    ("dmh_attn", 120, 8, "attention", 711),
+    ("dmh_max", 40, 4, "max", 712),
+]
+
+PROMPT_ADAPTER_CASES = [
+    # name, method, P, negative prompt, seed
+    ("pa_default", "default", 6, False, 721),
+    ("pa_adapter", "Adapter", 12, False, 722),
+    ("pa_fc", "FC", 7, False, 723),
+    ("pa_fc_neg", "FC", 7, True, 724),
+    ("pa_taskres_neg", "TaskRes", 8, True, 725),
+]
+
+DEEPMIL_BF16_CASES = [
+    # name, N, K, pooling, seed   (bf16-rounded bag: pins the fused MFMA score kernel to the reference)
+    ("dmb_gattn", 3000, 12, "gated_attention", 731),
+    ("dmb_attn", 2500, 12, "attention", 732),
+]

@@ -1,5 +1,6 @@
-"""Fused attention-score kernel (vlsa_gated_scores) for the ABMIL-style pooling over N patches vs fp32 torch on the CPU
-(the op sequence of model/layers.py:85-153 on the bf16-rounded bag), and through the DeepMIL module."""
+"""Fused attention-score kernel (vlsa_gated_scores) for the ABMIL-style pooling over N patches vs the CPU oracle
+(oracle.gated_attention_pooling / attention_pooling on the bf16-rounded bag), and through the DeepMIL module; the module
+on bf16 bags is additionally pinned to reference-generated fixtures in tests/test_gpu_modules_r2.py."""
 import pytest
 import torch
 
@@ -19,11 +20,13 @@ def _weights(seed, gated, scale=1.0):
 
 
 def _ref(X, Wa, ba, Wg, bg, w2, c):
+    """raw scores from the CPU oracle's restatement of model/layers.py:103-122 / 137-153 (pinned to the reference by the
+    deepmil_dm_* / deepmil_dmb_* fixtures), on the bf16-rounded values in fp32"""
+    from oracle import vlsa_oracle as O
     Xf = X.float()
-    h = torch.tanh(Xf @ Wa.t() + ba)
     if Wg is not None:
-        h = h * torch.sigmoid(Xf @ Wg.t() + bg)
-    return (h @ w2.t() + c).squeeze(-1)
+        return O.gated_attention_pooling(Xf, Wa, ba, Wg, bg, w2, c)[1]
+    return O.attention_pooling(Xf, Wa, ba, w2, c)[1]
 
 
 @pytest.mark.parametrize("gated", [True, False])

@@ -85,6 +85,41 @@ def test_text_feature_cache_tracks_parameter_versions():
     assert len(calls) == 3
 
 
+def test_text_cache_with_module_provider_and_repeated_backward():
+    """a PromptAdapter given as the provider (the reference's 'Adapter' prompt learner) must be tracked by the
+    cache, registered as `prompt_adapter.*`, re-run after an optimizer step, survive a second backward (per-bag backward /
+    gradient accumulation) and follow train()/eval() (dropout of the 'FC' variant)."""
+    from vlsa_amd.prompt_adapter import PromptAdapter
+    from vlsa_amd.vlsa import VLSA
+    torch.manual_seed(0)
+    pa = PromptAdapter(method="Adapter", num_prompts=4, pretrained_prompt_features=torch.randn(4, 512))
+    m = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=pa)
+    assert any(k.startswith("prompt_adapter.adapter.fc.") for k in m.state_dict())
+    assert not any(k.startswith("text_provider") for k in m.state_dict())
+    a = m.forward_text_only()
+    a.sum().backward()                          # first backward frees the provider graph ...
+    b = m.forward_text_only()                   # ... so this must be a fresh graph, not the cached tensor
+    assert b is not a
+    b.sum().backward()                          # would raise "backward through the graph a second time" on the stale cache
+    with torch.no_grad():
+        c0 = m.forward_text_only().clone()
+        assert m.forward_text_only() is m.forward_text_only()
+        next(pa.adapter.parameters()).mul_(0.5)   # optimizer step
+        assert not torch.equal(m.forward_text_only(), c0)
+    fc = PromptAdapter(method="FC", num_prompts=4, pretrained_prompt_features=torch.randn(4, 512))
+    m2 = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=fc)
+    with torch.no_grad():
+        m2.train(); t1 = m2.forward_text_only().clone()
+        m2.eval(); t2 = m2.forward_text_only().clone()
+        assert not torch.equal(t1, t2)           # dropout on / off: the mode is part of the cache key
+    # an opaque callable with no declared modules is never cached
+    calls = []
+    m3 = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=lambda: (calls.append(1), torch.ones(4, 512))[1])
+    with torch.no_grad():
+        m3.forward_text_only(); m3.forward_text_only()
+    assert len(calls) == 2
+
+
 def test_query_div_loss_cpu():
     import numpy as np
     from vlsa_amd.deepmil import VLFAN

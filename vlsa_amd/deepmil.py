@@ -23,21 +23,43 @@ from .layers import Adapter, Attention_Pooling, Feat_Projecter, Gated_Attention_
 __all__ = ["logit_pooling", "FeatMIL", "VLFAN", "DeepMIL"]
 
 
+_LOGIT_POOLINGS = {"logit_mean": None, "logit_max": 1}
+
+
 def _parse_logit_pooling(method: str):
-    if method[:9] in ("logit_max", "logit_top"):
-        return 1 if method == "logit_max" else int(method.split("top")[-1])
-    if method == "logit_mean":
-        return None
+    """'logit_mean' -> None (all patches), 'logit_max' -> 1, 'logit_top<k>' -> k; anything else is not a logit pooling."""
+    if method in _LOGIT_POOLINGS:
+        return _LOGIT_POOLINGS[method]
+    head, _, digits = method.partition("logit_top")
+    if head == "" and digits.isdigit():
+        return int(digits)
     raise NotImplementedError(f"The pooling ({method}) is not implemented.")
 
 
 def logit_pooling(logits: torch.Tensor, method: str):
-    """logits: [N, C] per-patch class logits -> (preds[1], pooled[1, C]).  (model/deepmil.py:16-37)"""
+    """logits: [N, C] per-patch class logits -> (preds[1], pooled[1, C]).  (model/deepmil.py:16-37)
+    The per-class top-k mean runs in HIP; when the logits carry a gradient (zero-shot prompt tuning) the selection is
+    done with torch.topk so that autograd reaches them, as in the reference."""
     topk = _parse_logit_pooling(method)
     N = logits.size(0)
     k = N if topk is None else min(topk, N)
-    pooled = VF.topk_mean(logits.t().contiguous(), k)[None, :]
+    if torch.is_grad_enabled() and logits.requires_grad:
+        pooled = logits.topk(k, dim=0).values.mean(dim=0, keepdim=True) if k < N else logits.mean(dim=0, keepdim=True)
+    else:
+        pooled = VF.topk_mean(logits.t().contiguous(), k)[None, :]
     return pooled.argmax(dim=1), pooled
+
+
+def _cross_attention_autograd(X2: torch.Tensor, Q: torch.Tensor, gated: bool, scale: float):
+    """The cross attention of model/deepmil.py:187-200 as device torch ops -- taken ONLY when the bag itself carries a
+    gradient (a trainable Feat_Projecter in front of the aggregation): the HIP streaming kernels produce no dX.
+    Returns (out [P, D], A [P, N])."""
+    Xf = X2.float()
+    S = F.normalize(Q.float(), dim=-1) @ F.normalize(Xf, dim=-1).t()
+    if gated:
+        S = S[:-1] - S[-1:]
+    A = torch.softmax(S * scale, dim=-1)
+    return A @ Xf, A
 
 
 class FeatMIL(nn.Module):
@@ -105,25 +127,28 @@ class VLFAN(nn.Module):
         return self.Q() if callable(self.Q) else self.Q
 
     def query_div_loss(self, last_div=True, **kws):
-        Q = self.get_query()
-        nQ = F.normalize(Q, dim=-1)
-        if len(Q) == self.num_query + 1 and last_div:
-            sim = nQ[-1:] @ nQ[:-1].T
-        else:
-            sim = nQ @ nQ.T
-            sim = sim[~torch.eye(len(Q), dtype=torch.bool, device=sim.device)]
-        return sim.abs().mean()
+        """Diversity penalty on the queries = mean |cosine| (model/deepmil.py:157-168): between the gate query (last row)
+        and every other query when there is one and ``last_div``; otherwise over all ordered pairs of distinct queries."""
+        unit = F.normalize(self.get_query(), dim=-1)
+        n = unit.shape[0]
+        if last_div and n == self.num_query + 1:
+            cos = unit[:-1] @ unit[-1]                       # [P]: gate vs the P prototypes
+            return cos.abs().mean()
+        gram = (unit @ unit.t()).abs()
+        off_diag = gram.sum() - gram.diagonal().sum()        # the diagonal (self-similarity) does not count
+        return off_diag / (n * (n - 1))
 
     def forward_query_pooling(self, X):
-        """[B, P, C] -> ([B, C], scores or None)"""
-        if isinstance(self.query_pooling, str):
-            if self.query_pooling == "mean":
-                return torch.mean(X, dim=1), None
-            return torch.max(X, dim=1)[0], None
-        if callable(self.query_pooling) and not isinstance(self.query_pooling, nn.Parameter):
-            return self.query_pooling(X)
-        weight = F.softmax(self.query_pooling, dim=-1).unsqueeze(0)
-        return torch.matmul(weight, X).squeeze(1), None
+        """[B, P, C] aggregated rows -> ([B, C] pooled, scores of the pooling module or None)  (model/deepmil.py:133-150)"""
+        pool = self.query_pooling
+        if isinstance(pool, nn.Module):                       # Attention_Pooling / Gated_Attention_Pooling over the P rows
+            return pool(X)
+        if isinstance(pool, nn.Parameter):                    # 'weight': learnable convex combination of the P rows
+            mix = torch.softmax(pool, dim=-1)                 # [1, P]
+            return torch.einsum("op,bpc->bc", mix, X), None
+        if pool == "mean":
+            return X.mean(dim=1), None
+        return X.amax(dim=1), None
 
     # -- fused inference support -------------------------------------------------------------------------
     def fused_head_spec(self):
@@ -149,7 +174,11 @@ class VLFAN(nn.Module):
             assert self._pos_gated_query == -1, "The gated query is placed at the end by default."
             assert Q.shape[0] == self.num_query + 1, f"Query number is expected to be {self.num_query + 1}."
         scale = float(self.coattn_logit_scale.exp())
-        out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
+        if torch.is_grad_enabled() and X.requires_grad:
+            out, A = _cross_attention_autograd(VF._bag2d(X), Q, self.gated_query, scale)
+            A = A.detach() if ret_with_attn else None
+        else:
+            out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
         pooled_out, pooled_ext = self.forward_query_pooling(out.unsqueeze(0))
         visual_features = self.visual_adapter(pooled_out)
         if ret_with_attn:
@@ -202,7 +231,7 @@ class DeepMIL(nn.Module):
         """raw scores a[N] of the pooling module on all patches: hidden projections by rocBLAS, the rest in HIP when
         no autograd graph is needed (else torch elementwise ops so the pooling parameters get gradients)."""
         sg = self.sigma
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in sg.parameters())
+        need_grad = torch.is_grad_enabled() and (X2.requires_grad or any(p.requires_grad for p in sg.parameters()))
         gated = isinstance(sg, Gated_Attention_Pooling)
         lin_a = sg.fc1[0] if gated else sg.attention[0]
         if (not need_grad and not (gated and sg.training and sg.fc1[2].p > 0)
@@ -233,14 +262,18 @@ class DeepMIL(nn.Module):
         if self.feat_proj is not None:
             X = self.feat_proj(X)
         raw_attn = None
+        x_grad = torch.is_grad_enabled() and X.requires_grad   # trainable Feat_Projecter: pooling as torch ops (dX needed)
         if self.sigma == "mean":
-            out_feat = VF.scored_pool(X, None)[None, :]
+            out_feat = X.float().mean(dim=1) if x_grad else VF.scored_pool(X, None)[None, :]
         elif self.sigma == "max":
-            out_feat = VF.colmax(X)[None, :]
+            out_feat = X.float().amax(dim=1) if x_grad else VF.colmax(X)[None, :]
         else:
             X2 = VF._bag2d(X)
             a = self._attention_scores(X2)
-            out_feat = VF.scored_pool(X2, a)[None, :]
+            if x_grad:
+                out_feat = (torch.softmax(a, dim=0)[None, :] @ X2.float())
+            else:
+                out_feat = VF.scored_pool(X2, a)[None, :]
             if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
                 raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
         if self.pred_head == "Adapter":

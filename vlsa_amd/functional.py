@@ -58,6 +58,17 @@ def _bag2d(X: torch.Tensor) -> torch.Tensor:
     return X
 
 
+def _no_bag_grad(*bags):
+    """The HIP aggregation kernels produce gradients for the queries / scores only (the reference's bags carry none:
+    SURVEY.md a14).  A bag that requires grad (e.g. the output of a trainable Feat_Projecter) must not be silently
+    detached: the modules route that case to device torch ops; calling the functional API with it is an error."""
+    if torch.is_grad_enabled():
+        for x in bags:
+            if x is not None and x.requires_grad:
+                raise VlsaNativeError("the bag requires grad, but the HIP aggregation has no dX: use the module API "
+                                      "(VLFAN / DeepMIL route a differentiable bag through torch ops) or detach the bag")
+
+
 @dataclass
 class PreparedQueries:
     """Device block produced by vlsa_prepare_queries (unit queries, effective queries, bf16 split)."""
@@ -333,6 +344,7 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
     """out[P, D] = softmax_N(coattn_scale * cos(Q, X)) @ X (model/deepmil.py:187-200), differentiable w.r.t. Q.
     Returns (out, A) with A[P, N] the detached attention weights (None unless want_attn)."""
     _need_gpu(X, Q)
+    _no_bag_grad(X)
     out, A = _VlfanAggregateFn.apply(X, Q.float(), bool(gated), float(coattn_scale), int(kernel), bool(want_attn))
     return out, (A if want_attn else None)
 
@@ -453,6 +465,7 @@ def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coatt
     """out[B, P, D]: ``vlfan_cross_attention`` for a list of up to 64 bags that share the queries, through the
     persistent multi-bag kernels (forward and backward); what one optimizer step of the reference does bag by bag
     (runner/vlsa_handler.py:260-289).  Bags: [N_i, 512] device tensors, N_i >= 1, one dtype per batch."""
+    _no_bag_grad(*bags)
     table = _BagTable(bags)
     if any(x.shape[0] == 0 for x in table.bags):
         raise VlsaNativeError("empty bag in a batch")
@@ -512,6 +525,7 @@ class _ScoredPoolFn(torch.autograd.Function):
 def scored_pool(X: torch.Tensor, scores: Optional[torch.Tensor]) -> torch.Tensor:
     """softmax_N(scores) @ X -> [D]; scores None => mean over the N rows."""
     _need_gpu(X, scores)
+    _no_bag_grad(X)
     X2 = _bag2d(X)
     if X2.shape[0] == 0:
         raise ValueError("empty bag")

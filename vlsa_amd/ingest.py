@@ -70,7 +70,7 @@ class ArenaLayout:
 def read_patch_data(path: str) -> torch.Tensor:
     """One slide's features as a host tensor: ``.pt`` (torch.load on CPU) or ``.npy`` (utils/io.py:16-42)."""
     if path.endswith(".pt"):
-        t = torch.load(path, map_location="cpu")
+        t = torch.load(path, map_location="cpu", weights_only=True)   # feature files hold one tensor: never unpickle code
     elif path.endswith(".npy"):
         import numpy as np
         t = torch.from_numpy(np.load(path))
@@ -191,6 +191,9 @@ class DeviceBagArena:
     def reset(self):
         """Forget all bags (e.g. before loading the next fold); the arena memory and staging buffers are kept."""
         self.wait()
+        if self.data.is_cuda:
+            # kernels on ANY stream may still be reading bag views handed out earlier; the rows are about to be overwritten
+            torch.cuda.synchronize(self.device)
         self.layout.reset()
         self._ready.clear()
 

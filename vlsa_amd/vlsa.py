@@ -58,7 +58,14 @@ class VLSA(nn.Module):
             self.prompt_learner = prompt_learner
         if prompt_encoder is not None:
             self.prompt_encoder = prompt_encoder
-        self.text_provider = text_provider
+        # An nn.Module given as the provider IS the reference's 'Adapter' prompt learner (model/vlsa.py:65-66,166-167): it is
+        # registered under the reference's attribute name so that checkpoints carry `prompt_adapter.*` keys.
+        self._provider_is_module = isinstance(text_provider, nn.Module)
+        if self._provider_is_module:
+            self.prompt_adapter = text_provider
+            self.text_provider = None
+        else:
+            self.text_provider = text_provider
         self.cache_text_features = cache_text_features
         self._text_cache = None
         self._text_cache_key = None
@@ -66,23 +73,44 @@ class VLSA(nn.Module):
         self._plans = {}
 
     # -- text side -----------------------------------------------------------------------------------------
+    def _provider_modules(self):
+        mods = (getattr(self, n, None) for n in ("prompt_learner", "prompt_encoder", "prompt_adapter"))
+        return [m for m in mods if isinstance(m, nn.Module)]
+
     def _provider_key(self):
-        mods = [m for m in (getattr(self, "prompt_learner", None), getattr(self, "prompt_encoder", None)) if m is not None]
-        key = []
+        """Everything the provider's output depends on that this object can see: identity + in-place version of every
+        parameter and buffer of the provider modules, their train/eval flag (dropout in the 'FC' adapter) and the grad mode.
+        None = the provider is an opaque callable with no declared modules: its output cannot be cached safely."""
+        mods = self._provider_modules()
+        if not mods:
+            return None
+        key = [torch.is_grad_enabled()]
         for m in mods:
-            key.extend((id(p), p._version) for p in m.parameters())
-        return tuple(key), torch.is_grad_enabled()
+            key.append((id(m), m.training))
+            key.extend((id(t), t._version) for t in m.parameters())
+            key.extend((id(t), t._version) for t in m.buffers())
+        return tuple(key)
+
+    def _drop_text_cache(self, *_):
+        self._text_cache = self._text_cache_key = None
 
     def forward_text_only(self):
         if hasattr(self, "pretrained_text_features"):
             return self.pretrained_text_features.clone()
-        if self.text_provider is None:
+        provider = self.prompt_adapter if self._provider_is_module else self.text_provider
+        if provider is None:
             raise RuntimeError("no text features: give `pretrained_text_features` or `text_provider`")
-        if not self.cache_text_features:
-            return self.text_provider()
-        key = self._provider_key()
+        key = self._provider_key() if self.cache_text_features else None
+        if key is None:
+            return provider()
         if self._text_cache is None or key != self._text_cache_key:
-            self._text_cache, self._text_cache_key = self.text_provider(), key
+            feats = provider()
+            if feats.requires_grad and feats.grad_fn is not None:
+                # the cached tensor carries the provider's autograd graph: every bag of the step may hang off it, but once
+                # a backward pass has run through it the graph is gone -- the next forward must rebuild it (per-bag
+                # backward, gradient accumulation) even though no parameter has changed yet
+                feats.register_hook(self._drop_text_cache)
+            self._text_cache, self._text_cache_key = feats, key
         return self._text_cache
 
     def _text_features(self):
@@ -143,8 +171,9 @@ class VLSA(nn.Module):
             if fused is not None:
                 return fused
         enc = self.mil_encoder
-        if isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max"):
-            return self._forward_zeroshot(X, text_features)
+        if (isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max")
+                and not (torch.is_grad_enabled() and (text_features.requires_grad or X.requires_grad))):
+            return self._forward_zeroshot(X, text_features)      # inference: fused HIP route (nothing to differentiate)
         feats = self.encode_instances(X)
         if (not self._needs_grad(text_features) and feats.is_cuda and feats.dim() == 2 and feats.shape[0] == 1
                 and feats.shape[1] % 4 == 0 and feats.shape[1] <= 1024 and text_features.shape[0] <= 64):
@@ -154,7 +183,7 @@ class VLSA(nn.Module):
             h = VF.head_forward(feats, "given", None, None, None, That, self.logit_scale.detach())
             return h["logits"][None, :], h["vhat"][None, :], That
         text_features = F.normalize(text_features, dim=-1)
-        image_features = F.normalize(feats, dim=-1)
+        image_features = F.normalize(feats.float(), dim=-1)
         logits = self.logit_scale.exp() * image_features @ text_features.t()
         if logits.shape[0] > 1:
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
