@@ -152,6 +152,14 @@ typedef struct vlsa_bag_desc {
     int64_t ldx;     /* row stride in elements (>= 512, multiple of 8) */
 } vlsa_bag_desc;
 
+/* One fp32 [P, ld] matrix per bag (device-resident array of these): the optional per-bag score / attention-weight
+ * outputs of the batched forward.  ptr NULL = this bag wants none.  ptr 16-byte aligned, ld % 4 == 0 and
+ * ld >= N rounded up to a multiple of 64 (the streaming kernels store whole 4-row pieces; the pad columns get -inf / 0). */
+typedef struct vlsa_rows_desc {
+    float* ptr;
+    int64_t ld;
+} vlsa_rows_desc;
+
 int vlsa_batch_max_bags(void);                                /* B <= this (64) */
 int vlsa_batch_partials_per_bag(int B);                       /* partial records per bag the batch kernel leaves (256/S) */
 size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE after allocation; calls leave it reusable */
@@ -187,6 +195,26 @@ int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, co
                              const float* logit_scale, void* workspace, float* m2, float* l, float* out, float* pooled,
                              float* v, float* vhat, float* vnorm, float* logits, float* incidence, int reserved_cus,
                              int groups, void* stream);
+/*
+ * Attention weights out of the batched path -- what `VLFAN.forward(X, ret_with_attn=True)` returns per bag
+ * (model/deepmil.py:198,206-215: A = softmax over the patches, [1, P, N]) and utils/model_inference.py:122 consumes:
+ *  vlsa_vlfan_partial_batch_scores  = vlsa_vlfan_partial_batch_ex that also stores the log2-domain scores t_pn of every bag
+ *                                     whose scores_desc[bag].ptr is non-NULL (48 B per patch at P = 12 on top of the row read);
+ *  vlsa_attn_normalise_batch        = A[p, n] = exp2(t[p, n] - m2[bag, p]) / l[bag, p] for all bags in one launch (m2, l: [B, 16],
+ *                                     bag-global, i.e. after the merge -- in the multi-GPU path after the all-gather);
+ *                                     attn_desc may alias scores_desc (in place); max_N = largest N of the batch (host value);
+ *  vlsa_vlfan_forward_batch_attn    = vlsa_vlfan_forward_batch + both of the above (scores_desc / attn_desc both NULL or both set).
+ * scores_desc / attn_desc: device arrays of B vlsa_rows_desc.
+ */
+int vlsa_vlfan_partial_batch_scores(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, void* workspace,
+                                    int reserved_cus, int groups, const void* scores_desc, void* stream);
+int vlsa_attn_normalise_batch(const void* bag_desc, int B, int P, int64_t max_N, const void* scores_desc, const float* m2,
+                              const float* l, const void* attn_desc, void* stream);
+int vlsa_vlfan_forward_batch_attn(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, int pool_mode,
+                                  const float* pool_w, const float* W, const float* b, const float* That, int K,
+                                  const float* logit_scale, void* workspace, float* m2, float* l, float* out, float* pooled,
+                                  float* v, float* vhat, float* vnorm, float* logits, float* incidence, int reserved_cus,
+                                  int groups, const void* scores_desc, const void* attn_desc, int64_t max_N, void* stream);
 
 /*
  * Backward of the aggregation for a BATCH of bags w.r.t. the (shared) effective queries -- one training step of the

@@ -1,0 +1,35 @@
+"""Batched forward WITH and WITHOUT attention weights: 32 x 50k bf16 bags per launch, P = 12, K = 4.
+Algorithmic bytes per patch: 1024 B read, + 4 P = 48 B written when A is requested."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vlsa_amd import functional as F
+
+dev = "cuda"
+B, n, P, K = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 12, 4
+bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(B)]
+Q = torch.randn(P, 512, device=dev); T = torch.randn(K, 512, device=dev)
+W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)
+for want in (False, True):
+    plan = F.VlfanBatchPlan(B, P, K, dev, want_attn=want)
+    plan.set_bags(bags)
+    for _ in range(60):
+        plan.run(Q, T, ls, W, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R = 200
+    for _ in range(R):
+        plan.run(Q, T, ls, W, b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / R
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(30):
+        e0.record(); plan.run_partial_only(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    kern = sorted(ts)[len(ts) // 2] * 1e-3
+    bytes_pp = 1024 + (4 * P if want else 0)
+    print(f"want_attn={want}: step {dt * 1e6:.1f} us per {B} bags = {dt / B * 1e6:.2f} us/bag = {B * n / dt / 1e9:.2f} G patches/s; "
+          f"whole-step {B * n * bytes_pp / dt / 1e12:.2f} TB/s = {B * n * bytes_pp / dt / 8e12 * 100:.1f} % of the ({bytes_pp} B/patch) HBM roofline; "
+          f"streaming kernel alone {kern * 1e6:.1f} us (event pair included)")

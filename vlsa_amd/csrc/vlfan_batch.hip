@@ -25,6 +25,10 @@ struct BagDesc {  // device-side description of one bag (mirrors vlsa_bag_desc i
     int64_t N;
     int64_t ldx;
 };
+struct RowsDesc {  // one [P, ld] fp32 matrix per bag (mirrors vlsa_rows_desc in vlsa_hip.h)
+    float* ptr;
+    int64_t ld;
+};
 
 #ifdef VLSA_TIMING
 __device__ long long vlsa_dbg_batch[64];
@@ -44,10 +48,11 @@ constexpr int kWaveRing = 2 * kSlot;
 constexpr int kRingBytes = 8 * kWaveRing;        // 128 KiB
 constexpr int kExchWave = 2048 + 128;
 constexpr int kExchGroup = 4 * kExchWave;
-constexpr int kTabOff = kRingBytes + 2 * kExchGroup;  // bag table: 8 ints per bag
+constexpr int kTabOff = kRingBytes + 2 * kExchGroup;  // bag table: kTabInts ints per bag
+constexpr int kTabInts = 12;                          // 8 stream-descriptor ints + score pointer (lo, hi) + score pitch + pad
 constexpr int kMaxBags = 64;
-constexpr int kMlOff = kTabOff + kMaxBags * 32;       // (M, l) hand-off: 8 waves x 32 floats
-constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;        // 151,552 B
+constexpr int kMlOff = kTabOff + kMaxBags * kTabInts * 4;  // (M, l) hand-off: 8 waves x 32 floats
+constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;        // 152,576 B
 constexpr float kThr = 16.0f;
 }  // namespace bt
 
@@ -63,10 +68,15 @@ __device__ __forceinline__ int bswz(int row, int byte_off) { return row * 256 + 
 // S = number of workgroup groups: bag t is streamed by the Gb = G / S workgroups of group t % S only, so S bags are in
 // flight at once, every workgroup sees S times more rows per bag (fewer bag epilogues, better tile quantisation) and a
 // bag leaves Gb instead of G partials behind.
+// kScores: additionally store the normalised log2-domain scores t_pn of every bag whose entry of `sdesc` has a non-null
+// pointer ([P, ld] fp32 per bag, ld % 4 == 0, ld >= N rounded up to 64) -- the raw material of the attention weights
+// A = softmax_N (model/deepmil.py:198,206-215), which need the bag-global (m, l) and are finished by k_attn_normalise_batch.
+template <bool kScores>
 __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDesc* __restrict__ bags, int B,
                                                                      const __bf16* __restrict__ qsplit, int P,
                                                                      float* __restrict__ pm, float* __restrict__ pl,
-                                                                     float* __restrict__ pacc, int S) {
+                                                                     float* __restrict__ pacc, int S,
+                                                                     const RowsDesc* __restrict__ sdesc) {
     using namespace bt;
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -96,7 +106,14 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         if (rend > d.N) rend = d.N;
         const int nrows = (mine && rend > rbeg) ? (int)(rend - rbeg) : 0;
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 2ull;
-        int_ma* e = tab + tid * 8;
+        int_ma* e = tab + tid * kTabInts;
+        if constexpr (kScores) {
+            const RowsDesc sd = sdesc[tid];
+            const unsigned long long sp = sd.ptr ? reinterpret_cast<unsigned long long>(sd.ptr + rbeg) : 0ull;
+            e[8] = (int)(unsigned int)sp;
+            e[9] = (int)(sp >> 32);
+            e[10] = (int)sd.ld;
+        }
         e[0] = (int)(unsigned int)addr;
         e[1] = (int)((addr >> 32) & 0xffffu);
         e[2] = nrows > 0 ? (int)(((long long)(nrows - 1) * d.ldx + D) * 2) : 0;  // descriptor span in bytes
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * 8 + k]); };
+    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * kTabInts + k]); };
 
     const unsigned int ring_lds = (unsigned int)(uintptr_t)(lds_void_ptr)ring;
     const int lr = lane >> 4;
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     i32x4 rsrc = {0, 0, 0, 0x00020000};
     auto issue_tile = [&](int bag, int tile, int slot) {
         if (bag != ib) {
-            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * 32);
+            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * (kTabInts * 4));
             rsrc[0] = __builtin_amdgcn_readfirstlane(e.x);
             rsrc[1] = __builtin_amdgcn_readfirstlane(e.y);
             rsrc[2] = __builtin_amdgcn_readfirstlane(e.z);
@@ -187,6 +204,12 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         float M = -INFINITY, lsum = 0.f;
+        float* srow = nullptr;   // kScores: this lane's query row of the bag's score matrix, at this workgroup's first row
+        if constexpr (kScores) {
+            const unsigned long long sp = (unsigned long long)(unsigned int)tab_get(bag, 8) |
+                                          ((unsigned long long)(unsigned int)tab_get(bag, 9) << 32);
+            if (sp != 0 && cw < 2 && i16 < P) srow = reinterpret_cast<float*>(sp) + (size_t)i16 * tab_get(bag, 10) + 16 * cw + 4 * g;
+        }
 
         for (int it = 0; it < niter; ++it) {
             const int tile = 2 * it + rg;
@@ -275,6 +298,9 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (row0 + 16 * h + 4 * g + r >= nrows) T[h][r] = -INFINITY;
+                }
+                if constexpr (kScores) {  // the four column-quarter waves hold identical scores: waves cw = 0 / 1 store half h = cw
+                    if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = cw == 0 ? T[0] : T[1];
                 }
                 const float tmax = fmaxf(fmaxf(fmaxf(T[0][0], T[0][1]), fmaxf(T[0][2], T[0][3])),
                                          fmaxf(fmaxf(T[1][0], T[1][1]), fmaxf(T[1][2], T[1][3])));
@@ -562,6 +588,25 @@ __global__ __launch_bounds__(512, 4) void k_vlfan_merge_pool_batch(const float* 
     }
 }
 
+// A[p, n] = exp2(t[p, n] - m2[bag, p]) / l[bag, p] for every bag of a batch (softmax over the patches, model/deepmil.py:198),
+// from the scores the streaming kernel stored and the bag-global (m2, l) of the merge.  grid (chunks of 1024 patches, P, B);
+// float4 per thread; may run in place (A == scores).  Columns N .. ld-1 of a row hold -inf scores -> 0.
+__global__ __launch_bounds__(256) void k_attn_normalise_batch(const BagDesc* __restrict__ bags, const RowsDesc* __restrict__ sdesc,
+                                                             const RowsDesc* __restrict__ adesc, const float* __restrict__ m2,
+                                                             const float* __restrict__ l, int m_stride) {
+    const int bag = blockIdx.z, p = blockIdx.y;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t N = bags[bag].N;
+    const RowsDesc sd = sdesc[bag], ad = adesc[bag];
+    if (n >= N || sd.ptr == nullptr || ad.ptr == nullptr) return;
+    const float m = m2[(size_t)bag * m_stride + p], inv = 1.f / l[(size_t)bag * m_stride + p];
+    const f32x4 t = *reinterpret_cast<const f32x4*>(sd.ptr + (size_t)p * sd.ld + n);
+    f32x4 a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = fast_exp2(t[r] - m) * inv;
+    *reinterpret_cast<f32x4*>(ad.ptr + (size_t)p * ad.ld + n) = a;
+}
+
 }  // namespace vlsa
 
 using namespace vlsa;
@@ -637,10 +682,11 @@ extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
 }
 
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
-                                  float* pl, float* pacc, int S, int workgroups, hipStream_t s);  // vlfan_batch_f32.hip
+                                  float* pl, float* pacc, int S, int workgroups, const void* scores_desc, hipStream_t s);  // vlfan_batch_f32.hip
 
-extern "C" int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
-                                           void* workspace, int reserved_cus, int groups, void* stream) {
+extern "C" int vlsa_vlfan_partial_batch_scores(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                               void* workspace, int reserved_cus, int groups, const void* scores_desc,
+                                               void* stream) {
     if (!bag_desc || !qprep || !workspace) return VLSA_EINVAL;
     if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
     if (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) return VLSA_EINVAL;
@@ -653,17 +699,42 @@ extern "C" int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dt
     float* pacc = pl + (size_t)B * G * kPStride;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bt::kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bt::kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_dma_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bt::kLdsBytes);
     }
     const QPrepLayout L(D);
     if (x_dtype == VLSA_DT_F32) {
         const unsigned char* qp = static_cast<const unsigned char*>(qprep);
         return vlsa_launch_partial_f32_batch(bag_desc, B, reinterpret_cast<const float*>(qp + L.qeff),
-                                             reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, S, WG, (hipStream_t)stream);
+                                             reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, S, WG, scores_desc,
+                                             (hipStream_t)stream);
     }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
-    hipLaunchKernelGGL(k_vlfan_partial_dma_batch, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
-                       static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S);
+    if (scores_desc)
+        hipLaunchKernelGGL(k_vlfan_partial_dma_batch<true>, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
+                           static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S,
+                           static_cast<const RowsDesc*>(scores_desc));
+    else
+        hipLaunchKernelGGL(k_vlfan_partial_dma_batch<false>, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
+                           static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S,
+                           static_cast<const RowsDesc*>(nullptr));
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_vlfan_partial_batch_ex(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                           void* workspace, int reserved_cus, int groups, void* stream) {
+    return vlsa_vlfan_partial_batch_scores(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, groups, nullptr, stream);
+}
+
+extern "C" int vlsa_attn_normalise_batch(const void* bag_desc, int B, int P, int64_t max_N, const void* scores_desc,
+                                         const float* m2, const float* l, const void* attn_desc, void* stream) {
+    if (!bag_desc || !scores_desc || !attn_desc || !m2 || !l) return VLSA_EINVAL;
+    if (B < 1 || B > bt::kMaxBags || P < 1 || P > VLSA_MAX_P || max_N < 0) return VLSA_EINVAL;
+    if (max_N == 0) return VLSA_OK;
+    const unsigned int chunks = (unsigned int)((max_N + 1023) / 1024);
+    hipLaunchKernelGGL(k_attn_normalise_batch, dim3(chunks, P, B), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const BagDesc*>(bag_desc), static_cast<const RowsDesc*>(scores_desc),
+                       static_cast<const RowsDesc*>(attn_desc), m2, l, (int)kPStride);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
@@ -672,14 +743,19 @@ extern "C" int vlsa_vlfan_partial_batch(const void* bag_desc, int B, int x_dtype
     return vlsa_vlfan_partial_batch_ex(bag_desc, B, x_dtype, D, qprep, P, workspace, 0, 0, stream);
 }
 
-extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
-                                        int pool_mode, const float* pool_w, const float* W, const float* b,
-                                        const float* That, int K, const float* logit_scale, void* workspace, float* m2,
-                                        float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
-                                        float* logits, float* incidence, int reserved_cus, int groups, void* stream) {
+extern "C" int vlsa_vlfan_forward_batch_attn(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                             int pool_mode, const float* pool_w, const float* W, const float* b,
+                                             const float* That, int K, const float* logit_scale, void* workspace, float* m2,
+                                             float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
+                                             float* logits, float* incidence, int reserved_cus, int groups,
+                                             const void* scores_desc, const void* attn_desc, int64_t max_N, void* stream) {
     if (!That || !logit_scale || !m2 || !l || !out || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
     if (K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
-    const int rc = vlsa_vlfan_partial_batch_ex(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, groups, stream);
+    if ((scores_desc == nullptr) != (attn_desc == nullptr)) return VLSA_EINVAL;
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    const int rc = vlsa_vlfan_partial_batch_scores(bag_desc, B, x_dtype, D, qprep, P, workspace, reserved_cus, groups, scores_desc,
+                                                   stream);
     if (rc != VLSA_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int G = vlsa_batch_partials_per_bag_ex(B, reserved_cus, groups);
@@ -690,14 +766,24 @@ extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype
                                                              vlsa_batch_workspace_bytes(B, P, D) - (size_t)B * 64);
     const MergeStrides st{kPStride, kPStride, (int64_t)P * D, (int64_t)G * kPStride, (int64_t)G * kPStride,
                           (int64_t)G * P * D, kPStride, kPStride, (int64_t)P * D};
-    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT) return VLSA_EINVAL;
-    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
     // merge + pooling in one kernel; the head then starts from the pooled vectors (2 KB instead of P x 2 KB per workgroup)
     hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
                        pool_mode, pool_w, pooled);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     (void)counters;
-    return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
+    const int rh = vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
+    if (rh != VLSA_OK || !scores_desc) return rh;
+    return vlsa_attn_normalise_batch(bag_desc, B, P, max_N, scores_desc, m2, l, attn_desc, stream);
+}
+
+extern "C" int vlsa_vlfan_forward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                        int pool_mode, const float* pool_w, const float* W, const float* b,
+                                        const float* That, int K, const float* logit_scale, void* workspace, float* m2,
+                                        float* l, float* out, float* pooled, float* v, float* vhat, float* vnorm,
+                                        float* logits, float* incidence, int reserved_cus, int groups, void* stream) {
+    return vlsa_vlfan_forward_batch_attn(bag_desc, B, x_dtype, D, qprep, P, pool_mode, pool_w, W, b, That, K, logit_scale,
+                                         workspace, m2, l, out, pooled, v, vhat, vnorm, logits, incidence, reserved_cus, groups,
+                                         nullptr, nullptr, 0, stream);
 }
 
 extern "C" int vlsa_vlfan_merge_batch_strided(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D,

@@ -25,6 +25,10 @@ struct BagDesc {
     int64_t N;
     int64_t ldx;
 };
+struct RowsDesc {  // one [P, ld] fp32 matrix per bag (mirrors vlsa_rows_desc in vlsa_hip.h)
+    float* ptr;
+    int64_t ld;
+};
 
 namespace bf {
 constexpr int kTile = 16;                        // rows per tile
@@ -34,8 +38,9 @@ constexpr int kRingBytes = 8 * kWaveRing;        // 128 KiB
 constexpr int kExchWave = 1024 + 64;             // S partials (one f32x4 per lane) + 16 row sums of squares
 constexpr int kExchGroup = 4 * kExchWave;
 constexpr int kTabOff = kRingBytes + 2 * kExchGroup;
+constexpr int kTabInts = 12;                     // 8 stream-descriptor ints + score pointer (lo, hi) + score pitch + pad
 constexpr int kMaxBags = 64;
-constexpr int kMlOff = kTabOff + kMaxBags * 32;
+constexpr int kMlOff = kTabOff + kMaxBags * kTabInts * 4;
 constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;
 constexpr float kThr = 16.0f;
 }  // namespace bf
@@ -55,10 +60,13 @@ __device__ __forceinline__ int fswz(int row, int col) { return row * 512 + ((((c
 // S = number of workgroup groups: bag t is streamed by the Gb = G / S workgroups of group t % S only, so S bags are in
 // flight at once, every workgroup sees S times more rows per bag (fewer bag epilogues, better tile quantisation) and a
 // bag leaves Gb instead of G partials behind.
+// kScores: see k_vlfan_partial_dma_batch (vlfan_batch.hip) -- optional per-bag store of the normalised log2-domain scores.
+template <bool kScores>
 __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDesc* __restrict__ bags, int B,
                                                                      const float* __restrict__ qeff, const float* __restrict__ qmeta, int P,
                                                                      float* __restrict__ pm, float* __restrict__ pl,
-                                                                     float* __restrict__ pacc, int S) {
+                                                                     float* __restrict__ pacc, int S,
+                                                                     const RowsDesc* __restrict__ sdesc) {
     using namespace bf;
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -88,7 +96,14 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
         if (rend > d.N) rend = d.N;
         const int nrows = (mine && rend > rbeg) ? (int)(rend - rbeg) : 0;
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 4ull;
-        int_ma* e = tab + tid * 8;
+        int_ma* e = tab + tid * kTabInts;
+        if constexpr (kScores) {
+            const RowsDesc sd = sdesc[tid];
+            const unsigned long long sp = sd.ptr ? reinterpret_cast<unsigned long long>(sd.ptr + rbeg) : 0ull;
+            e[8] = (int)(unsigned int)sp;
+            e[9] = (int)(sp >> 32);
+            e[10] = (int)sd.ld;
+        }
         e[0] = (int)(unsigned int)addr;
         e[1] = (int)((addr >> 32) & 0xffffu);
         e[2] = nrows > 0 ? (int)(((long long)(nrows - 1) * d.ldx + D) * 4) : 0;  // descriptor span in bytes
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * 8 + k]); };
+    auto tab_get = [&](int bag, int k) -> int { return __builtin_amdgcn_readfirstlane(tab[bag * kTabInts + k]); };
 
     const unsigned int ring_lds = (unsigned int)(uintptr_t)(lds_void_ptr)ring;
     const int lr = lane >> 5, lc = lane & 31;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     i32x4 rsrc = {0, 0, 0, 0x00020000};
     auto issue_tile = [&](int bag, int tile, int slot) {
         if (bag != ib) {
-            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * 32);
+            const int4 e = *reinterpret_cast<const int4*>(smem + kTabOff + bag * (kTabInts * 4));
             rsrc[0] = __builtin_amdgcn_readfirstlane(e.x);
             rsrc[1] = __builtin_amdgcn_readfirstlane(e.y);
             rsrc[2] = __builtin_amdgcn_readfirstlane(e.z);
@@ -177,6 +192,12 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         float M = -INFINITY, lsum = 0.f;
+        float* srow = nullptr;   // kScores: this lane's query row of the bag's score matrix, at this workgroup's first row
+        if constexpr (kScores) {
+            const unsigned long long sp = (unsigned long long)(unsigned int)tab_get(bag, 8) |
+                                          ((unsigned long long)(unsigned int)tab_get(bag, 9) << 32);
+            if (sp != 0 && cw == 0 && i16 < P) srow = reinterpret_cast<float*>(sp) + (size_t)i16 * tab_get(bag, 10) + 4 * g;
+        }
 
         for (int it = 0; it < niter; ++it) {
             const int tile = 2 * it + rg;
@@ -250,6 +271,9 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (row0 + 4 * g + r >= nrows) T[r] = -INFINITY;
+                }
+                if constexpr (kScores) {  // the four column-quarter waves hold identical scores: wave cw = 0 stores them
+                    if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = T;
                 }
                 const float tmax = fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3]));
                 if (__builtin_amdgcn_ballot_w64(tmax > M + kThr) != 0) {
@@ -360,12 +384,19 @@ extern "C" __global__ void k_dummy_batch_dbg() {}
 using namespace vlsa;
 
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,
-                                  float* pl, float* pacc, int S, int workgroups, hipStream_t s) {
+                                  float* pl, float* pacc, int S, int workgroups, const void* scores_desc, hipStream_t s) {
     static DeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
     }
-    hipLaunchKernelGGL(k_vlfan_partial_f32_batch, dim3(workgroups), dim3(512), bf::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
-                       qeff, qmeta, P, pm, pl, pacc, S);
+    if (scores_desc)
+        hipLaunchKernelGGL(k_vlfan_partial_f32_batch<true>, dim3(workgroups), dim3(512), bf::kLdsBytes, s,
+                           static_cast<const BagDesc*>(bag_desc), B, qeff, qmeta, P, pm, pl, pacc, S,
+                           static_cast<const RowsDesc*>(scores_desc));
+    else
+        hipLaunchKernelGGL(k_vlfan_partial_f32_batch<false>, dim3(workgroups), dim3(512), bf::kLdsBytes, s,
+                           static_cast<const BagDesc*>(bag_desc), B, qeff, qmeta, P, pm, pl, pacc, S,
+                           static_cast<const RowsDesc*>(nullptr));
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

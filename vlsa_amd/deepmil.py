@@ -187,20 +187,36 @@ class VLFAN(nn.Module):
             return visual_features, attn
         return visual_features
 
-    def forward_bags(self, bags):
+    def forward_bags(self, bags, ret_with_attn=False):
         """Differentiable forward over a list of bags (each [1, N_i, C] or [N_i, C]) sharing this encoder: the cross
         attention of all bags runs in the persistent multi-bag kernels (forward and backward), the P x C tail as batched
         torch ops.  Equals ``torch.cat([self(x) for x in bags])``; one training step of the reference
-        (runner/vlsa_handler.py:260-289) is 32 such bags.  Returns visual features [B, C]."""
+        (runner/vlsa_handler.py:260-289) is 32 such bags.  Returns visual features [B, C]; with ``ret_with_attn`` also the
+        per-bag attention exactly as ``forward(x, ret_with_attn=True)`` hands it out: a list of ``A`` [1, P, N_i], or of
+        ``(A, pool_scores)`` when the query pooling is a module (model/deepmil.py:206-215)."""
         if self.feat_proj is not None:
-            return torch.cat([self.forward(x if x.dim() == 3 else x[None]) for x in bags])
+            rs = [self.forward(x if x.dim() == 3 else x[None], ret_with_attn=ret_with_attn) for x in bags]
+            if ret_with_attn:
+                return torch.cat([r[0] for r in rs]), [r[1] for r in rs]
+            return torch.cat(rs)
         Q = self.get_query()
         scale = float(self.coattn_logit_scale.exp())
-        outs = []
+        outs, attn = [], []
         for i in range(0, len(bags), 64):
-            outs.append(VF.vlfan_cross_attention_bags(bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale))
-        pooled_out, _ = self.forward_query_pooling(torch.cat(outs))
-        return self.visual_adapter(pooled_out)
+            r = VF.vlfan_cross_attention_bags(bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale,
+                                              want_attn=ret_with_attn)
+            if ret_with_attn:
+                outs.append(r[0])
+                attn.extend(a.unsqueeze(0) for a in r[1])
+            else:
+                outs.append(r)
+        pooled_out, pooled_ext = self.forward_query_pooling(torch.cat(outs))
+        feats = self.visual_adapter(pooled_out)
+        if not ret_with_attn:
+            return feats
+        if pooled_ext is not None:
+            attn = [(a, pooled_ext[i:i + 1].detach()) for i, a in enumerate(attn)]
+        return feats, attn
 
 
 class DeepMIL(nn.Module):

@@ -365,6 +365,26 @@ def choose_groups(sizes, reserved_cus: int = 0) -> int:
     return g
 
 
+class AttnBuffers:
+    """One fp32 [P, ld_i] matrix per bag of a batch (ld_i = N_i rounded up to 64) in ONE allocation, plus the device-side
+    ``vlsa_rows_desc`` table the batched kernels take.  The streaming kernel stores the log2-domain scores there and
+    ``vlsa_attn_normalise_batch`` turns them into the attention weights in place; ``views[i]`` is bag i's A [P, N_i]."""
+
+    def __init__(self, sizes, P: int, device):
+        self.sizes, self.P = [int(n) for n in sizes], int(P)
+        lds = [(n + 63) // 64 * 64 for n in self.sizes]
+        offs, tot = [], 0
+        for ld in lds:
+            offs.append(tot)
+            tot += P * ld
+        self.buf = torch.empty(max(tot, 4), dtype=torch.float32, device=device)
+        base = self.buf.data_ptr()
+        host = torch.tensor([[base + 4 * o if n > 0 else 0, ld] for o, ld, n in zip(offs, lds, self.sizes)], dtype=torch.int64)
+        self.desc = host.to(device)
+        self.views = [self.buf[o:o + P * ld].view(P, ld)[:, :n] for o, ld, n in zip(offs, lds, self.sizes)]
+        self.max_n = max(self.sizes) if self.sizes else 0
+
+
 class _BagTable:
     """Device-side descriptor table (pointer, N, row stride) of up to 64 bags for the batched kernels."""
 
@@ -391,7 +411,7 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
     """out[B, P, D] for B bags sharing the queries Q; differentiable w.r.t. Q (the bags carry no gradient)."""
 
     @staticmethod
-    def forward(ctx, Q, gated, coattn_scale, table):
+    def forward(ctx, Q, gated, coattn_scale, table, attn=None):
         lib, s = nat.load(), _stream()
         B, D = table.B, table.D
         dev = table.desc.device
@@ -399,7 +419,8 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         P = qp.P
         ws = torch.empty(lib.vlsa_batch_workspace_bytes(B, P, D), dtype=torch.uint8, device=dev)
         groups = choose_groups([x.shape[0] for x in table.bags], 0)
-        nat.check(lib.vlsa_vlfan_partial_batch_ex(_p(table.desc), B, table.dt, D, _p(qp.buf), P, _p(ws), 0, groups, s),
+        nat.check(lib.vlsa_vlfan_partial_batch_scores(_p(table.desc), B, table.dt, D, _p(qp.buf), P, _p(ws), 0, groups,
+                                                      None if attn is None else _p(attn.desc), s),
                   "vlsa_vlfan_partial_batch")
         G = int(lib.vlsa_batch_partials_per_bag_ex(B, 0, groups))
         wf = ws.view(torch.float32)
@@ -411,6 +432,9 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
                                   nat.P_STRIDE, nat.P_STRIDE, P * D)
         nat.check(lib.vlsa_vlfan_merge_batch_strided(_p(pm), _p(pl), _p(pacc), B, G, P, D, 1, st, _p(m2), _p(l), _p(out), s),
                   "vlsa_vlfan_merge_batch_strided")
+        if attn is not None:   # scores -> attention weights in place, with the bag-global (m2, l)
+            nat.check(lib.vlsa_attn_normalise_batch(_p(table.desc), B, P, attn.max_n, _p(attn.desc), _p(m2), _p(l), _p(attn.desc), s),
+                      "vlsa_attn_normalise_batch")
         ctx.save_for_backward(out, m2, l, qp.buf)
         ctx.table = table
         ctx.meta = (qp.nq, P, D, bool(gated), float(coattn_scale))
@@ -458,18 +482,25 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         qhat, qnorm = qp.qhat, qp.qnorm
         dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
         dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
-        return dQ, None, None, None
+        return dQ, None, None, None, None
 
 
-def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE):
+def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
+                               want_attn: bool = False):
     """out[B, P, D]: ``vlfan_cross_attention`` for a list of up to 64 bags that share the queries, through the
     persistent multi-bag kernels (forward and backward); what one optimizer step of the reference does bag by bag
-    (runner/vlsa_handler.py:260-289).  Bags: [N_i, 512] device tensors, N_i >= 1, one dtype per batch."""
+    (runner/vlsa_handler.py:260-289).  Bags: [N_i, 512] device tensors, N_i >= 1, one dtype per batch.
+    want_attn: also return the detached attention weights, a list of [P, N_i] (model/deepmil.py:198,206-215)."""
     _no_bag_grad(*bags)
     table = _BagTable(bags)
     if any(x.shape[0] == 0 for x in table.bags):
         raise VlsaNativeError("empty bag in a batch")
-    return _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table)
+    if not want_attn:
+        return _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table)
+    P = Q.shape[0] - (1 if gated else 0)
+    attn = AttnBuffers([x.shape[0] for x in table.bags], P, table.desc.device)
+    out = _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table, attn)
+    return out, attn.views
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -649,8 +680,11 @@ class VlfanBatchPlan:
     """
 
     def __init__(self, B: int, P: int, K: int, device, D: int = 512, gated: bool = False, pool: str = "mean",
-                 identity_head: bool = False, coattn_scale: float = COATTN_SCALE, reserved_cus: int = 0):
-        """reserved_cus: compute units left without a persistent streaming workgroup.  When batches are pipelined over two
+                 identity_head: bool = False, coattn_scale: float = COATTN_SCALE, reserved_cus: int = 0,
+                 want_attn: bool = False):
+        """want_attn: also produce every bag's attention weights A [P, N_i] (``attn.views`` after ``run``): the streaming
+        kernel stores its scores (48 B per patch at P = 12) and one more launch normalises them in place.
+        reserved_cus: compute units left without a persistent streaming workgroup.  When batches are pipelined over two
         streams, 32 (4 per XCD) lets the merge / head / prepare kernels of batch i run on those CUs while batch i+1 streams
         on the other 224: the HBM-bound streaming kernel loses ~2 %, the step gains ~4 % (0 for a single stream)."""
         lib = nat.load()
@@ -669,6 +703,7 @@ class VlfanBatchPlan:
         self.pooled, self.v, self.vhat, self.vnorm = f(B, D), f(B, D), f(B, D), f(B)
         self.logits, self.incidence = f(B, K), f(B, K)
         self._bags = None
+        self.want_attn, self.attn = bool(want_attn), None
         self.dt = nat.DT_BF16
         self.groups = 0
         self._desc_np = self.desc_host.numpy()     # same (pinned) memory, cheap element writes
@@ -699,6 +734,8 @@ class VlfanBatchPlan:
         self._bags = keep
         self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
         self.groups = choose_groups([r[1] for r in rows], self.reserved_cus)  # bags in flight
+        if self.want_attn and (self.attn is None or self.attn.sizes != [r[1] for r in rows]):
+            self.attn = AttnBuffers([r[1] for r in rows], self.P, self.desc.device)
         self.desc.copy_(self.desc_host, non_blocking=True)
         if self.desc_host.is_pinned():
             self._desc_ev = torch.cuda.Event()
@@ -714,11 +751,13 @@ class VlfanBatchPlan:
         nq = self.P + 1 if self.gated else self.P
         c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, k["qprep"], _p(T), self.K,
                                             k["That"], k["tnorm"], s), "prepare_queries_and_text")
-        c(lib.vlsa_vlfan_forward_batch(k["desc"], self.B, self.dt, self.D, k["qprep"], self.P, self.pool,
-                                       _p(pool_w), None if self.identity_head else _p(W),
-                                       None if self.identity_head else _p(b), k["That"], self.K, _p(logit_scale),
-                                       k["ws"], k["m2"], k["l"], k["out"], k["pooled"], k["v"], k["vhat"], k["vnorm"],
-                                       k["logits"], k["incidence"], self.reserved_cus, self.groups, s), "vlfan_forward_batch")
+        ad = _p(self.attn.desc) if self.want_attn else None
+        c(lib.vlsa_vlfan_forward_batch_attn(k["desc"], self.B, self.dt, self.D, k["qprep"], self.P, self.pool,
+                                            _p(pool_w), None if self.identity_head else _p(W),
+                                            None if self.identity_head else _p(b), k["That"], self.K, _p(logit_scale),
+                                            k["ws"], k["m2"], k["l"], k["out"], k["pooled"], k["v"], k["vhat"], k["vnorm"],
+                                            k["logits"], k["incidence"], self.reserved_cus, self.groups, ad, ad,
+                                            self.attn.max_n if self.want_attn else 0, s), "vlfan_forward_batch")
         return outs["logits"] if outs and "logits" in outs else self.logits
 
     def capture(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
@@ -739,6 +778,7 @@ class VlfanBatchPlan:
 
     def run_partial_only(self):
         """Only the persistent streaming kernel (roofline timing); queries must have been prepared by a run()."""
-        nat.check(self.lib.vlsa_vlfan_partial_batch_ex(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
-                                                       _p(self.ws), self.reserved_cus, self.groups, _stream()),
+        nat.check(self.lib.vlsa_vlfan_partial_batch_scores(_p(self.desc), self.B, self.dt, self.D, _p(self.qprep), self.P,
+                                                           _p(self.ws), self.reserved_cus, self.groups,
+                                                           _p(self.attn.desc) if self.want_attn else None, _stream()),
                   "vlfan_partial_batch")

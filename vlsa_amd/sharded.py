@@ -170,8 +170,11 @@ class ShardedVlfanBatchPlan:
     G = 256
 
     def __init__(self, B: int, P: int, K: int, device, dist_module=None, group=None, D: int = 512, gated: bool = False,
-                 pool: str = "mean", identity_head: bool = False, pipeline: bool = True, reserved_cus: Optional[int] = None):
-        """reserved_cus: compute units the persistent streaming kernel leaves free so that the RCCL all-gather of the
+                 pool: str = "mean", identity_head: bool = False, pipeline: bool = True, reserved_cus: Optional[int] = None,
+                 want_attn: bool = False):
+        """want_attn: every rank also gets ITS columns of each bag's attention weights, ``A`` = list of [P, N_local_i]
+        (valid after the next run() / finish(), like the logits; held per pipeline slot).
+        reserved_cus: compute units the persistent streaming kernel leaves free so that the RCCL all-gather of the
         previous batch and the tail kernels can run next to it (default: 32 = four per XCD when pipelined, else 0;
         env ``VLSA_RESERVED_CUS`` overrides)."""
         import os
@@ -192,6 +195,7 @@ class ShardedVlfanBatchPlan:
         self._pending = None
         self._i = 0
         self.lib = nat.load()
+        self.want_attn, self.attn, self.A = bool(want_attn), [None, None], None
         if reserved_cus is None:
             reserved_cus = 32 if pipeline else 0
         self.reserved_cus = int(os.environ.get("VLSA_RESERVED_CUS", reserved_cus))
@@ -209,13 +213,17 @@ class ShardedVlfanBatchPlan:
     def set_bags(self, local_shards):
         self.local.set_bags(local_shards)
         self._set_groups(self.local.groups)
+        if self.want_attn:   # one score / weight buffer per pipeline slot: batch i+1 streams before batch i's tail runs
+            sizes = [x.shape[0] for x in self.local._bags]
+            self.attn = [VF.AttnBuffers(sizes, self.P, self.local.desc.device) for _ in range(2)]
 
     def _local(self, Q, slot):
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         nq = self.P + 1 if pl_.gated else self.P
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
-        c(lib.vlsa_vlfan_partial_batch_ex(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
-                                          self.reserved_cus, pl_.groups, s), "vlfan_partial_batch")
+        c(lib.vlsa_vlfan_partial_batch_scores(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
+                                              self.reserved_cus, pl_.groups,
+                                              p(self.attn[slot].desc) if self.want_attn else None, s), "vlfan_partial_batch")
         base = pl_.ws.data_ptr()
         n_ml = self.B * self.G * nat.P_STRIDE * 4
         rec = self.rec[slot].data_ptr()
@@ -235,6 +243,11 @@ class ShardedVlfanBatchPlan:
                                                   p(pl_.That), self.K, p(ls), p(pl_.m2), p(pl_.l), p(pl_.out), p(pl_.pooled),
                                                   p(pl_.v), p(pl_.vhat), p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s),
           "merge_head_batch(global)")
+        if self.want_attn:   # this rank's columns, normalised with the GLOBAL (m2, l) of the merged records
+            ab = self.attn[slot]
+            c(lib.vlsa_attn_normalise_batch(p(pl_.desc), self.B, self.P, ab.max_n, p(ab.desc), p(pl_.m2), p(pl_.l), p(ab.desc), s),
+              "attn_normalise_batch")
+            self.A = ab.views
 
     def run(self, Q, T, logit_scale, W=None, b=None, pool_w=None):
         slot = self._i & 1

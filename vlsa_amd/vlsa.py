@@ -189,14 +189,18 @@ class VLSA(nn.Module):
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
         return logits, image_features, text_features
 
-    def forward_bags(self, bags):
+    def forward_bags(self, bags, ret_with_attn=False):
         """A list of independent bags in one call (the reference loops bag by bag: eval runner/vlsa_handler.py:315-345,
         training 260-289).  bf16 or fp32 bags with D == 512 and a VLFAN encoder go through the persistent multi-bag
         kernels, up to 64 bags per launch: fully fused when no gradient is needed, HIP aggregation forward + backward with
         a batched torch tail otherwise; anything else falls back to per-bag ``forward``.
-        Returns (logits [B, K], image_features [B, D], text_features [K, D])."""
+        Returns (logits [B, K], image_features [B, D], text_features [K, D]); with ``ret_with_attn`` (VLFAN encoders) a
+        fourth element: the per-bag attention weights ``[A_i [1, P, N_i]]`` of model/deepmil.py:198,206-215 -- from the same
+        launch (the streaming kernel stores its scores, one more launch normalises them)."""
         enc = self.mil_encoder
         text_features = self._text_features()
+        if ret_with_attn:
+            return self._forward_bags_attn(bags, text_features)
         if self._needs_grad(text_features):
             if (isinstance(enc, VLFAN) and len(bags) > 0 and all(x.is_cuda and x.shape[-1] == 512 and x.shape[-2] > 0 for x in bags)
                     and all(x.dtype == bags[0].dtype for x in bags)):
@@ -208,7 +212,26 @@ class VLSA(nn.Module):
         with torch.no_grad():
             return self._forward_bags_fused(bags, text_features)
 
-    def _forward_bags_fused(self, bags, text_features):
+    def _forward_bags_attn(self, bags, text_features):
+        enc = self.mil_encoder
+        if not isinstance(enc, VLFAN):
+            raise NotImplementedError("ret_with_attn over a list of bags is the VLFAN encoder's output (model/deepmil.py:206-215)")
+        grad = self._needs_grad(text_features)
+        spec = enc.fused_head_spec()
+        flat = [VF._bag2d(x) for x in bags]
+        ok = (len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat))
+        if grad or spec is None or not ok:
+            with torch.set_grad_enabled(grad):
+                text_n = F.normalize(text_features, dim=-1)
+                feats, attn = enc.forward_bags(bags, ret_with_attn=True)
+                feats = F.normalize(feats, dim=-1)
+                return self.logit_scale.exp() * feats @ text_n.t(), feats, text_n, attn
+        with torch.no_grad():
+            logits, feats, That, plans = self._forward_bags_fused(flat, text_features, want_attn=True)
+        attn = [a.unsqueeze(0).clone() for pl in plans for a in pl.attn.views]   # the plan's buffers are reused by later calls
+        return logits, feats, That, attn
+
+    def _forward_bags_fused(self, bags, text_features, want_attn=False):
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         flat = [VF._bag2d(x) for x in bags]
@@ -230,20 +253,21 @@ class VLSA(nn.Module):
         K = text_features.shape[0]
         T = text_features.detach().float().contiguous()
         ls = self.logit_scale.detach().float()
-        logits, feats, That = [], [], None
+        logits, feats, That, used = [], [], None, []
         Wc = None if W is None else W.detach().float().contiguous()
         bc = None if b is None else b.detach().float().contiguous()
         pwc = None if pw is None else pw.detach().float().reshape(-1).contiguous()
         step = 32
         for i in range(0, len(flat), step):
             chunk = flat[i:i + step]
-            key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None)
+            key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else 0)
             plan = self._plans.get(key)
             if plan is None:
                 plan = VF.VlfanBatchPlan(len(chunk), P, K, chunk[0].device, gated=enc.gated_query, pool=mode,
                                          identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()),
-                                         reserved_cus=0)
+                                         reserved_cus=0, want_attn=want_attn)
                 self._plans[key] = plan
+            used.append(plan)
             plan.set_bags(chunk, validated=True)
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=chunk[0].device)  # noqa: E731
             outs = {"logits": f(len(chunk), K), "vhat": f(len(chunk), 512)}
@@ -252,9 +276,8 @@ class VLSA(nn.Module):
             plan.run(Q, T, ls, Wc, bc, pwc, outs=outs)
             logits.append(outs["logits"])
             feats.append(outs["vhat"])
-        if len(logits) == 1:
-            return logits[0], feats[0], That
-        return torch.cat(logits), torch.cat(feats), That
+        res = (logits[0], feats[0], That) if len(logits) == 1 else (torch.cat(logits), torch.cat(feats), That)
+        return res + (used,) if want_attn else res
 
     def _forward_zeroshot(self, X, text_features):
         """Identity FeatMIL: per-patch cosine logits pooled over the patches (model/vlsa.py:194-196)."""
