@@ -47,6 +47,32 @@ def _worker(rank, world, port, ret):
             got = bp.finish().clone()
             torch.cuda.synchronize()
             errs[f"batch pipeline={pipeline}"] = (got - ref).abs().max().item()
+        # batched plan with attention weights, pipelined over two DIFFERENT batches of equal sizes: batch 2 streams before
+        # batch 1's tail runs, so batch 1's weights must come from its own per-slot score buffer
+        from oracle import vlsa_oracle as Orc
+        sizes2 = [3000, 517, 64]
+        setA = [cases.make_bag(n, 8400 + i).to(torch.bfloat16) for i, n in enumerate(sizes2)]
+        setB = [cases.make_bag(n, 8500 + i).to(torch.bfloat16) for i, n in enumerate(sizes2)]
+        bnd = [shard_bounds(n, world, rank) for n in sizes2]
+        for pipeline in (True, False):
+            bp = ShardedVlfanBatchPlan(len(sizes2), P, K, dev, dist, pipeline=pipeline, want_attn=True)
+            got = []
+            for bags_ in (setA, setB):
+                bp.set_bags([x[a:c].to(dev) for x, (a, c) in zip(bags_, bnd)])
+                bp.run(Q, T, ls, W, b)
+                if not pipeline:
+                    got.append([v.clone() for v in bp.A])
+                elif len(got) == 0 and bags_ is setB:
+                    got.append([v.clone() for v in bp.A])      # batch A's weights, drained by batch B's run()
+            if pipeline:
+                bp.finish()
+                got.append([v.clone() for v in bp.A])
+            torch.cuda.synchronize()
+            e = 0.0
+            for views, bags_ in zip(got, (setA, setB)):
+                for v, x, (a, c) in zip(views, bags_, bnd):
+                    e = max(e, (v.cpu() - Orc.vlfan_forward(x.float(), Q.cpu())["A"][:, a:c]).abs().max().item())
+            errs[f"attn batch pipeline={pipeline}"] = e
         # single-bag sharded plan, pipelined over 3 bags
         a, c = shard_bounds(sizes[0], world, rank)
         sp = ShardedVlfanPlan(c - a, 512, P, K, dev, dist, pipeline=True)

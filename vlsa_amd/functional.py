@@ -381,6 +381,8 @@ class AttnBuffers:
         base = self.buf.data_ptr()
         host = torch.tensor([[base + 4 * o if n > 0 else 0, ld] for o, ld, n in zip(offs, lds, self.sizes)], dtype=torch.int64)
         self.desc = host.to(device)
+        # bag table holding only the N_i (vlsa_bag_desc layout): lets the normalise launch outlive a later set_bags()
+        self.ndesc = torch.tensor([[0, n, 0] for n in self.sizes], dtype=torch.int64).to(device)
         self.views = [self.buf[o:o + P * ld].view(P, ld)[:, :n] for o, ld, n in zip(offs, lds, self.sizes)]
         self.max_n = max(self.sizes) if self.sizes else 0
 

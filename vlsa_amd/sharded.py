@@ -215,15 +215,16 @@ class ShardedVlfanBatchPlan:
         self._set_groups(self.local.groups)
         if self.want_attn:   # one score / weight buffer per pipeline slot: batch i+1 streams before batch i's tail runs
             sizes = [x.shape[0] for x in self.local._bags]
-            self.attn = [VF.AttnBuffers(sizes, self.P, self.local.desc.device) for _ in range(2)]
+            if self.attn[0] is None or self.attn[0].sizes != sizes:   # a pending batch keeps its own buffers (see run)
+                self.attn = [VF.AttnBuffers(sizes, self.P, self.local.desc.device) for _ in range(2)]
 
-    def _local(self, Q, slot):
+    def _local(self, Q, slot, ab=None):
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         nq = self.P + 1 if pl_.gated else self.P
         c(lib.vlsa_prepare_queries(p(Q), nq, self.D, int(pl_.gated), pl_.scale, p(pl_.qprep), s), "prepare_queries")
         c(lib.vlsa_vlfan_partial_batch_scores(p(pl_.desc), self.B, pl_.dt, self.D, p(pl_.qprep), self.P, p(pl_.ws),
                                               self.reserved_cus, pl_.groups,
-                                              p(self.attn[slot].desc) if self.want_attn else None, s), "vlfan_partial_batch")
+                                              p(ab.desc) if ab is not None else None, s), "vlfan_partial_batch")
         base = pl_.ws.data_ptr()
         n_ml = self.B * self.G * nat.P_STRIDE * 4
         rec = self.rec[slot].data_ptr()
@@ -232,7 +233,7 @@ class ShardedVlfanBatchPlan:
                                              self._st_local, ctypes.c_void_p(rec), ctypes.c_void_p(rec + 4 * nat.P_STRIDE),
                                              ctypes.c_void_p(rec + 4 * REC_HDR), s), "merge_batch(local)")
 
-    def _tail(self, slot, T, ls, W, b, pool_w):
+    def _tail(self, slot, T, ls, W, b, pool_w, ab=None):
         pl_, lib, s, c, p = self.local, self.lib, VF._stream(), nat.check, VF._p
         g = self.gathered[slot].data_ptr()
         c(lib.vlsa_normalize_rows(p(T), self.K, self.D, p(pl_.That), p(pl_.tnorm), s), "normalize_rows")
@@ -243,9 +244,8 @@ class ShardedVlfanBatchPlan:
                                                   p(pl_.That), self.K, p(ls), p(pl_.m2), p(pl_.l), p(pl_.out), p(pl_.pooled),
                                                   p(pl_.v), p(pl_.vhat), p(pl_.vnorm), p(pl_.logits), p(pl_.incidence), s),
           "merge_head_batch(global)")
-        if self.want_attn:   # this rank's columns, normalised with the GLOBAL (m2, l) of the merged records
-            ab = self.attn[slot]
-            c(lib.vlsa_attn_normalise_batch(p(pl_.desc), self.B, self.P, ab.max_n, p(ab.desc), p(pl_.m2), p(pl_.l), p(ab.desc), s),
+        if ab is not None:   # this rank's columns, normalised with the GLOBAL (m2, l) of the merged records
+            c(lib.vlsa_attn_normalise_batch(p(ab.ndesc), self.B, self.P, ab.max_n, p(ab.desc), p(pl_.m2), p(pl_.l), p(ab.desc), s),
               "attn_normalise_batch")
             self.A = ab.views
 
@@ -255,10 +255,11 @@ class ShardedVlfanBatchPlan:
         cur = torch.cuda.current_stream()
         if self.pipeline:
             cur.wait_event(self.done_comm[slot])
-        self._local(Q, slot)
+        ab = self.attn[slot] if self.want_attn else None
+        self._local(Q, slot, ab)
         if not self.pipeline:
             all_gather_records(self.rec[slot], self.gathered[slot], self.group)
-            self._tail(slot, T, logit_scale, W, b, pool_w)
+            self._tail(slot, T, logit_scale, W, b, pool_w, ab)
             return self.local.logits
         self.done_local[slot].record(cur)
         with torch.cuda.stream(self.comm_stream):
@@ -267,13 +268,13 @@ class ShardedVlfanBatchPlan:
             self.done_comm[slot].record(self.comm_stream)
         if self._pending is not None:
             self._drain()
-        self._pending = (slot, T, logit_scale, W, b, pool_w)
+        self._pending = (slot, T, logit_scale, W, b, pool_w, ab)
         return self.local.logits
 
     def _drain(self):
-        slot, T, ls, W, b, pw = self._pending
+        slot, T, ls, W, b, pw, ab = self._pending
         torch.cuda.current_stream().wait_event(self.done_comm[slot])
-        self._tail(slot, T, ls, W, b, pw)
+        self._tail(slot, T, ls, W, b, pw, ab)
         self._pending = None
 
     def finish(self):
