@@ -3,12 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A STEP = one pass of the hot path over one batch = ONE launch of 32 distinct HBM-resident bags (the reference's own
-batch of 32 bags per optimizer step, cfg_vlsa_conch.yaml:117-118; its eval loop is the same independent-bag stream)
-through query / text normalisation, the persistent streaming aggregation kernel, the partial merge and the incidence
-head (= VLSA.forward in eval mode with cached text features, reference model/vlsa.py:181-198, once per bag).  The
-timed region is EXACTLY K such steps after W untimed ones, bracketed by barrier + synchronize; value = patches of all K
-steps / that time.  32 bags x 51.2 MB = 1.6 GB per step > the 256 MiB Infinity Cache: every byte comes from HBM.
+A STEP = one pass of the hot path over one batch of 128 HBM-resident bags, issued as FOUR launches of 32 bags (32 = the
+reference's own batch per optimizer step, cfg_vlsa_conch.yaml:117-118; its eval loop is the same independent-bag
+stream): each launch = query / text normalisation, the persistent streaming aggregation kernel, the partial merge and
+the incidence head (= VLSA.forward in eval mode with cached text features, reference model/vlsa.py:181-198, once per
+bag).  The timed region is EXACTLY K such steps after W untimed ones, bracketed by barrier + synchronize; value =
+patches of all K steps / that time.  Every launch walks the same 32 distinct bags = 1.6 GB > the 256 MiB Infinity
+Cache, so every byte comes from HBM each time.  (Why 128 bags per step: the synchronize before the timed region idles
+the GPU, an MI355X drops its clocks at once and needs ~5 ms to ramp back; with one 0.27 ms launch per step a
+`--steps 20` run would sit entirely inside that ramp and read 5 % low -- profiles/README.md.)
 
 N = 1  -> BASELINE.json configs[2]: 50k x 512 bf16 bags, P = 12 queries, K = 4 rank prompts (the configuration the
           metric is quoted on).  The line also carries `strong_scaling_base`: configs[3]'s 200k-patch, K = 8 bags on
@@ -31,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 D, P = 512, 12
-BAGS_PER_STEP = 32
+BAGS_PER_LAUNCH = 32
+LAUNCHES_PER_STEP = 4
+BAGS_PER_STEP = BAGS_PER_LAUNCH * LAUNCHES_PER_STEP
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 FLOP_PER_PATCH = 2 * 512 * P * 2 + 2 * 512   # scores + weighted sum + norm = 25 600 at P = 12
@@ -110,8 +115,8 @@ def load_pmc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400, help="timed steps (one step = one 32-bag launch)")
-    ap.add_argument("--warmup", type=int, default=80)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (one step = 128 bags = four 32-bag launches)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
     ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs without a streaming workgroup (-1: 32 when N > 1, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,7 +149,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    BPL = BAGS_PER_STEP
+    BPL, LPS = BAGS_PER_LAUNCH, LAUNCHES_PER_STEP
     NS = max(1, a.streams)
     RAMP = int(os.environ.get("VLSA_BENCH_RAMP", "48"))   # untimed clock-ramp launches (50k-row equivalents) before the warm-up
     # N > 1: 32 of the 256 CUs (4 per XCD) carry no persistent streaming workgroup, so that the RCCL all-gather and the tail
@@ -172,7 +177,8 @@ def main():
             pl.set_bags(bags)
             plans.append(pl)
 
-        def run_steps(n):
+        def run_steps(n_steps):
+            n = n_steps * LPS
             cur = torch.cuda.current_stream()
             for st in streams:
                 st.wait_stream(cur)
@@ -188,7 +194,7 @@ def main():
 
         # Untimed, before the W warm-up steps: ~15 ms of the same launches so that the GPU clocks have ramped (an MI355X
         # drops its clocks within a few hundred us of idling and needs ~5 ms to come back; profiles/README.md).
-        run_steps(max(16, int(RAMP * 50_000 / max(rows_local, 1))))
+        run_steps(max(4, int(RAMP * 50_000 / max(rows_local, 1)) // LPS))
         run_steps(warmup)
         sync()
         t0 = time.perf_counter()
@@ -257,29 +263,30 @@ def main():
         cfg, scaling = "configs[2]", "strong"
         rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
         dt, roof = measure(rows, rows, K, a.steps, a.warmup, 100, True)
-        total = BPL * rows * a.steps
+        total = BPL * LPS * rows * a.steps
         workload = (f"{cfg}: synthetic 50k x 512 bf16 bags, P=12 queries, K=4 rank prompts, mean pooling + Linear(512,512) "
-                    f"head; one step = one launch of {BPL} distinct bags")
+                    f"head; one step = {BPL * LPS} bags = {LPS} launches of {BPL} distinct bags")
         if not a.no_extra:
             r3, K3 = CONFIGS["configs[3]"]["rows"], CONFIGS["configs[3]"]["K"]
-            s3 = max(4, a.steps // 4)
+            s3 = max(2, a.steps // 4)
             dt3, _ = measure(r3, r3, K3, s3, max(1, a.warmup // 4), 300, False)
             extra = ("strong_scaling_base", {"workload": "configs[3] on ONE GPU: 200k x 512 bf16 bags, P=12, K=8 (what --gpus N shards)",
-                                             "value": BPL * r3 * s3 / dt3, "unit": "patches/s", "steps": s3,
+                                             "value": BPL * LPS * r3 * s3 / dt3, "unit": "patches/s", "steps": s3,
                                              "ms_per_step": dt3 / s3 * 1e3})
     else:
         cfg, scaling = "configs[3]", "strong"
         rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
         lo, hi = shard_bounds(rows, world, rank)
         dt, roof = measure(hi - lo, rows, K, a.steps, a.warmup, 100 + rank, True)
-        total = BPL * rows * a.steps
+        total = BPL * LPS * rows * a.steps
         workload = (f"{cfg}: synthetic 200k x 512 bf16 bags, P=12, K=8, patch-sharded over {world} GPUs ({rows // world} rows per "
-                    f"GPU per bag), one RCCL all-gather of compact records per step; one step = one launch of {BPL} bags")
+                    f"GPU per bag), one RCCL all-gather of compact records per launch; one step = {BPL * LPS} bags = {LPS} "
+                    f"launches of {BPL} bags")
         if not a.no_extra:
             rw, Kw = CONFIGS["configs[2]"]["rows"], CONFIGS["configs[2]"]["K"]
             dtw, _ = measure(rw, rw * world, Kw, a.steps, a.warmup, 500 + rank, False)
             extra = ("weak_scaling", {"workload": f"bags of {world} x 50k patches, 50k rows per GPU per bag, P=12, K=4 (round-1 --gpus workload)",
-                                      "value": BPL * rw * world * a.steps / dtw, "unit": "patches/s", "steps": a.steps,
+                                      "value": BPL * LPS * rw * world * a.steps / dtw, "unit": "patches/s", "steps": a.steps,
                                       "ms_per_step": dtw / a.steps * 1e3, "scaling": "weak"})
 
     if rank == 0:
@@ -289,8 +296,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu_per_bag": rows // world, "D": D, "P": P, "K": K,
-                       "bags_per_step": BPL, "distinct_bags": BPL, "patches_per_step": BPL * rows,
-                       "launch": f"eager, 5 kernel launches per step, steps alternate over {NS} streams, {wgs} streaming "
+                       "bags_per_step": BPL * LPS, "bags_per_launch": BPL, "distinct_bags": BPL, "patches_per_step": BPL * LPS * rows,
+                       "launch": f"eager, 5 kernel launches per 32-bag launch, launches alternate over {NS} streams, {wgs} streaming "
                                  f"workgroups + {256 - wgs} CUs for the tail kernels"},
             "roofline": roof,
         }
