@@ -338,6 +338,57 @@ int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, int B, int 
                    const float* logit_scale_exp, float alpha, float eps, int p, int raw_distance, float w_ifmle,
                    float w_emd, float* out_ifmle, float* out_emd, float* grad, void* stream);
 
+/* ---- text side: the frozen CoCa text tower on the prompts' compact rows -------------------------- */
+
+/* One pre-LN transformer block (model/conch/transformer.py:191-247): DEVICE pointers to fp32 tensors in the layouts
+ * nn.MultiheadAttention / nn.Linear store them ([out_features, in_features]). */
+typedef struct vlsa_tt_layer {
+    const float *ln1_w, *ln1_b;   /* ln_1            [width] */
+    const float *in_w, *in_b;     /* attn.in_proj    [3 width, width], [3 width] */
+    const float *out_w, *out_b;   /* attn.out_proj   [width, width], [width] */
+    const float *ln2_w, *ln2_b;   /* ln_2            [width] */
+    const float *fc_w, *fc_b;     /* mlp.c_fc        [4 width, width], [4 width] */
+    const float *proj_w, *proj_b; /* mlp.c_proj      [width, 4 width], [width] */
+} vlsa_tt_layer;
+
+/* The tower (HOST struct; `layer` is a HOST array of `layers` entries).  width % 128 == 0, width <= 768, 64 features per head
+ * (CONCH: 768 / 12 heads / 12 layers, model/conch/model_configs/conch_ViT-B-16.json), out_dim % 64 == 0. */
+typedef struct vlsa_tt_model {
+    int width, heads, layers, out_dim, ctx_len;  /* ctx_len = positions incl. the CLS slot (128) */
+    const vlsa_tt_layer* layer;
+    const float* pos_emb;    /* positional_embedding [ctx_len, width] */
+    const float* cls_emb;    /* [width] */
+    const float *lnf_w, *lnf_b; /* ln_final */
+    const float* text_proj;  /* text_projection [width, out_dim] */
+} vlsa_tt_model;
+
+/* The compact rows of a batch of prompts (HOST struct of DEVICE int arrays, built once per prompt-length pattern).
+ * A prompt whose CLS token may attend to positions 0..m contributes rows for positions 0..m followed by its CLS row:
+ * causal attention makes every later position irrelevant to the pooled output (model/prompt_encoder.py:245-252,299-303).
+ *   row_seq[row] prompt index; row_pos[row] position (CLS: ctx_len - 1); row_src[row] token index into prompts_embedding
+ *   (-1: the CLS row); seq_row0[n_seq + 1] first row of each prompt; cls_keep[row] 1 if the prompt's CLS row attends to
+ *   this row (for the CLS row itself: whether it attends to itself).  M rows, allocated M_pad (multiple of 48);
+ *   max_len = most rows of one prompt (<= 128; backward <= 64). */
+typedef struct vlsa_tt_rows {
+    int n_seq, M, M_pad, max_len;
+    const int *row_seq, *row_pos, *row_src, *seq_row0;
+    const unsigned char* cls_keep;
+} vlsa_tt_rows;
+
+/*
+ * Replaces CONCHPromptEncoder.forward (model/prompt_encoder.py:267-322): prompts_embedding [n_seq, ctx_len - 1, width]
+ * (element [s, t] at emb + s * emb_seq_stride + t * emb_tok_stride, unit inner stride) -> text features out [n_seq, out_dim].
+ * workspace: vlsa_tt_workspace_bytes(model, rows, save_for_backward) bytes; with save_for_backward != 0 it keeps every
+ * block's inputs for vlsa_tt_backward, which turns dout [n_seq, out_dim] into d prompts_embedding (demb, same strides;
+ * demb_floats = size of the whole demb allocation, zeroed here first).  The tower's own weights get no gradient: frozen in
+ * every shipped configuration (cfg_vlsa_conch.yaml:69).
+ */
+size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* model, const vlsa_tt_rows* rows, int save_for_backward);
+int vlsa_tt_forward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const float* emb, int64_t emb_seq_stride,
+                    int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out, void* stream);
+int vlsa_tt_backward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const float* dout, void* workspace, float* demb,
+                     int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream);
+
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
 

@@ -1,0 +1,146 @@
+"""Text side on the GPU: rank prompt learner + CoCa text tower in HIP vs the fixtures the REFERENCE
+produced around a seeded random-weight tower (tests/golden/make_golden_text.py) and vs the CPU oracle: text features
+[K, out] and the gradients w.r.t. the learnable context / rank embeddings within 1e-4; the tokenised-text path; the
+compact-row evaluation against garbage in unreachable slots; VLSA end to end (text tower -> cached features -> bag logits)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import cases
+import text_cases as TC
+import text_helpers as TH
+from test_text_modules_cpu import build_learner
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def build_encoder(tower, seed):
+    from vlsa_amd.prompt_encoder import CONCHPromptEncoder
+    c = TC.TOWERS[tower]
+    enc = CONCHPromptEncoder(width=c["width"], heads=c["heads"], layers=c["layers"], vocab_size=c["vocab"], output_dim=c["out_dim"])
+    enc.load_state_dict(TC.make_tower_weights(tower, seed))
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    return enc.cuda().eval()
+
+
+@pytest.mark.parametrize("case", TC.RANK_CASES, ids=[c[0] for c in TC.RANK_CASES])
+def test_rank_prompts_through_the_tower_forward_and_backward(case):
+    (name, tower, seed, K, base, position) = case
+    inp = TH.rank_case_inputs(case)
+    fx = inp["fx"]
+    enc = build_encoder(tower, seed)
+    pl = build_learner(case, inp).cuda()
+    with torch.no_grad():
+        pl.context_embeds.copy_(torch.from_numpy(fx["context_embeds"]))
+        pl.rank_embeds.copy_(torch.from_numpy(fx["rank_embeds"]))
+        f0 = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)       # inference route (nothing saved)
+    assert np.abs(f0.cpu().numpy() - fx["text_features"]).max() < TOL
+    feats = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)         # training route
+    assert np.abs(feats.detach().cpu().numpy() - fx["text_features"]).max() < TOL
+    (feats * torch.from_numpy(fx["G"]).cuda()).sum().backward()
+    for key, p in (("grad_context", pl.context_embeds), ("grad_rank", pl.rank_embeds)):
+        ref = fx[key]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err < TOL * max(1.0, np.abs(ref).max()), (key, err, np.abs(ref).max())
+    # a second forward / backward on the same plan (workspaces are per call) gives the same numbers
+    pl.zero_grad()
+    feats2 = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+    assert torch.equal(feats2.detach(), feats.detach())
+    (feats2 * torch.from_numpy(fx["G"]).cuda()).sum().backward()
+    assert np.abs(pl.rank_embeds.grad.cpu().numpy() - fx["grad_rank"]).max() < TOL * max(1.0, np.abs(fx["grad_rank"]).max())
+
+
+@pytest.mark.parametrize("case", TC.TEXT_CASES, ids=[c[0] for c in TC.TEXT_CASES])
+def test_tokenised_text_path(case):
+    (name, tower, seed, lens) = case
+    fx = TH.load(name)
+    enc = build_encoder(tower, seed)
+    with torch.no_grad():
+        feats = enc(prompts_text=torch.from_numpy(fx["token_ids"]).cuda())
+    assert np.abs(feats.cpu().numpy() - fx["text_features"]).max() < TOL
+
+
+def test_unreachable_slots_are_ignored_and_reachable_ones_are_not():
+    case = [c for c in TC.RANK_CASES if c[1] == "mid"][0]
+    (name, tower, seed, K, base, position) = case
+    inp = TH.rank_case_inputs(case)
+    enc = build_encoder(tower, seed)
+    pl = build_learner(case, inp).cuda()
+    with torch.no_grad():
+        sent = pl()
+        n = int((pl.pseudo_sentence_tokens[0] > 0).sum())
+        f0 = enc(prompts_embedding=sent, prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+        junk = sent.clone()
+        junk[:, n + 1:] = float("nan")                           # never read: not even NaNs get through
+        f1 = enc(prompts_embedding=junk, prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+        assert torch.equal(f0, f1)
+        junk = sent.clone()
+        junk[:, n] += 0.3 * torch.randn_like(junk[:, n])         # the first pad slot IS seen by the CLS token (shifted mask)
+        f2 = enc(prompts_embedding=junk, prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+        assert (f2 - f0).abs().max().item() > 1e-3
+
+
+def test_frozen_tower_is_enforced_and_cpu_inputs_fail_loudly():
+    from vlsa_amd._native import VlsaNativeError
+    enc = build_encoder("small", 1)
+    x = torch.zeros(2, 127, 128, device="cuda", requires_grad=True)
+    pt = torch.ones(2, 127, dtype=torch.long, device="cuda")
+    next(enc.transformer.parameters()).requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        enc(prompts_embedding=x, prompts_pseudo_tokens=pt)
+    with torch.no_grad():
+        enc(prompts_embedding=x, prompts_pseudo_tokens=pt)      # fine without autograd
+    with pytest.raises(VlsaNativeError):
+        enc(prompts_embedding=x.detach().cpu(), prompts_pseudo_tokens=pt)
+
+
+def test_vlsa_end_to_end_with_gpu_text_side():
+    """VLSA(prompt_learner=RankPromptLearner, prompt_encoder=CONCHPromptEncoder): rank prompts -> text tower -> cached text
+    features -> bag logits, forward and one backward, vs the CPU oracles (model/vlsa.py:149-156,181-198)."""
+    from oracle import text_oracle as TO, vlsa_oracle as O
+    from vlsa_amd.prompt_adapter import PromptAdapter
+    from vlsa_amd.vlsa import VLSA
+    case = [c for c in TC.RANK_CASES if c[0] == "rank_conch_k4"][0]
+    (name, tower, seed, K, base, position) = case
+    inp = TH.rank_case_inputs(case)
+    enc = build_encoder(tower, seed)
+    pl = build_learner(case, inp)
+    P = 12
+    params = cases.make_params(P, K, 4242)
+    qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
+    cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, num_query=P, query="Text", gated_query=False,
+               query_pooling="mean", pred_head="default")
+    model = VLSA(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    with torch.no_grad():
+        qnet.residual_features.copy_(params["resid"])
+        model.mil_encoder.visual_adapter.weight.copy_(params["W"]); model.mil_encoder.visual_adapter.bias.copy_(params["b"])
+    model = model.cuda()
+    bags = [cases.make_bag(n, 4250 + i) for i, n in enumerate((700, 1300, 64))]
+    # CPU oracle: text features, then the bag path
+    feats_ref, leaves = TH.oracle_rank_case(case, requires_grad=True)
+    with torch.no_grad():   # the oracle case uses the fixture's (perturbed) embeddings: give the model the same
+        pl.context_embeds.copy_(leaves["context"].detach()); pl.rank_embeds.copy_(leaves["rank"].detach())
+    Q = 0.5 * params["resid"] + params["prompt"]
+    ref_logits = torch.cat([O.vlsa_vlfan_forward(x, Q, feats_ref, torch.tensor(cases.LOGIT_SCALE), head_weight=params["W"],
+                                                 head_bias=params["b"])["logits"] for x in bags])
+    model.eval()
+    with torch.no_grad():
+        logits, _, That = model.forward_bags([x.cuda() for x in bags])
+        assert model.forward_text_only() is model.forward_text_only()          # cached: the tower ran once
+    assert (logits.cpu() - ref_logits.detach()).abs().max().item() < TOL
+    model.train()
+    logits2, _, _ = model.forward_bags([x.cuda() for x in bags])
+    G = torch.randn(logits2.shape, generator=torch.Generator().manual_seed(5))
+    (logits2 * G.cuda()).sum().backward()
+    (ref_logits * G).sum().backward()
+    for p, leaf in ((pl.context_embeds, leaves["context"]), (pl.rank_embeds, leaves["rank"])):
+        ref = leaf.grad
+        assert (p.grad.cpu() - ref).abs().max().item() < 2e-3 * max(1e-3, ref.abs().max().item()) + 1e-5
+    # after an optimizer-like update the cached text features are recomputed
+    with torch.no_grad():
+        t0 = model.forward_text_only().clone()
+        pl.rank_embeds.add_(0.01)
+        assert not torch.equal(model.forward_text_only(), t0)

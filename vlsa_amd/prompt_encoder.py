@@ -1,0 +1,275 @@
+"""Text tower of the VL model on the GPU: drop-in counterpart of the reference's ``CONCHPromptEncoder``
+(model/prompt_encoder.py:209-322) -- same constructor contract (wraps a CoCa model's ``.text`` tower), same attribute
+and state-dict names (``positional_embedding``, ``cls_emb``, ``transformer.resblocks.N.{ln_1,attn,ln_2,mlp}.*``,
+``ln_final.*``, ``text_projection``, ``token_embedding.weight``), same ``forward(prompts_text | prompts_embedding,
+prompts_pseudo_tokens)`` -> ``[n_prompts, output_dim]``.
+
+The 12 pre-LN blocks run in libvlsa_hip.so (vlsa_amd/csrc/text_tower.hip) on the COMPACT rows of the prompts: only the
+positions that can reach the pooled CLS token are evaluated (a 13-row problem per rank prompt instead of 128 -- exact, see
+the kernel file), f32 MFMA throughout.  Differentiable w.r.t. ``prompts_embedding`` (the learnable context / rank
+embeddings of the prompt learner); the tower itself is frozen as in every shipped configuration
+(``vlsa_txt_encoder_frozen: True``, cfg_vlsa_conch.yaml:69) -- a tower parameter that requires grad raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+from ._native import VlsaNativeError
+
+
+class _TTLayer(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("ln1_w", "ln1_b", "in_w", "in_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc_w", "fc_b",
+                                               "proj_w", "proj_b")]
+
+
+class _TTModel(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int), ("heads", ctypes.c_int), ("layers", ctypes.c_int), ("out_dim", ctypes.c_int),
+                ("ctx_len", ctypes.c_int), ("layer", ctypes.POINTER(_TTLayer)), ("pos_emb", ctypes.c_void_p),
+                ("cls_emb", ctypes.c_void_p), ("lnf_w", ctypes.c_void_p), ("lnf_b", ctypes.c_void_p), ("text_proj", ctypes.c_void_p)]
+
+
+class _TTRows(ctypes.Structure):
+    _fields_ = [("n_seq", ctypes.c_int), ("M", ctypes.c_int), ("M_pad", ctypes.c_int), ("max_len", ctypes.c_int),
+                ("row_seq", ctypes.c_void_p), ("row_pos", ctypes.c_void_p), ("row_src", ctypes.c_void_p),
+                ("seq_row0", ctypes.c_void_p), ("cls_keep", ctypes.c_void_p)]
+
+
+# -- parameter holders with the reference's names (model/conch/transformer.py:191-247,290-322) ---------------------------
+class _SelfAttention(nn.Module):          # the parameters of nn.MultiheadAttention(width, heads)
+    def __init__(self, width):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * width, width))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * width))
+        self.out_proj = nn.Linear(width, width)
+
+
+class _Block(nn.Module):
+    def __init__(self, width):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(width)
+        self.attn = _SelfAttention(width)
+        self.ln_2 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(width, 4 * width)), ("gelu", nn.GELU()),
+                                              ("c_proj", nn.Linear(4 * width, width))]))
+
+
+class _Transformer(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.ModuleList([_Block(width) for _ in range(layers)])
+
+
+def compact_rows(pseudo_tokens: torch.Tensor, ctx_len: int):
+    """Host-side row plan for a [n, ctx_len - 1] pseudo-token matrix (0 = pad).  The CLS row (appended last) may attend to
+    column 0 and to column j + 1 for every non-pad token j (build_cls_mask, model/prompt_encoder.py:245-252: the pad mask is
+    shifted right by one); token rows are causal.  Prompt s therefore needs positions 0..m_s (m_s = last column < ctx_len - 1
+    the CLS row can see) plus the CLS row.  Returns dict of int lists."""
+    pt = pseudo_tokens.detach().to("cpu")
+    n, L = pt.shape
+    if L != ctx_len - 1:
+        raise ValueError(f"expected {ctx_len - 1} token positions, got {L}")
+    row_seq, row_pos, row_src, seq_row0, cls_keep = [], [], [], [0], []
+    max_len = 0
+    for s in range(n):
+        keep = [True] + [bool(v) for v in (pt[s] != 0).tolist()]          # keep[c]: CLS attends to column c (c = L: itself)
+        m = max(c for c in range(L) if keep[c])
+        for c in range(m + 1):
+            row_seq.append(s); row_pos.append(c); row_src.append(c); cls_keep.append(1 if keep[c] else 0)
+        row_seq.append(s); row_pos.append(ctx_len - 1); row_src.append(-1); cls_keep.append(1 if keep[L] else 0)
+        seq_row0.append(len(row_seq))
+        max_len = max(max_len, m + 2)
+    return dict(row_seq=row_seq, row_pos=row_pos, row_src=row_src, seq_row0=seq_row0, cls_keep=cls_keep, max_len=max_len,
+                n_seq=n, M=len(row_seq))
+
+
+class _RowPlan:
+    """Device copies of the compact-row tables + the C struct, cached per pseudo-token pattern."""
+
+    def __init__(self, pseudo_tokens, ctx_len, device):
+        rp = compact_rows(pseudo_tokens, ctx_len)
+        self.n_seq, self.M, self.max_len = rp["n_seq"], rp["M"], rp["max_len"]
+        self.M_pad = (self.M + 47) // 48 * 48
+        pad = self.M_pad - self.M
+        i32 = lambda v, fill: torch.tensor(v + [fill] * pad, dtype=torch.int32).to(device)   # noqa: E731
+        self.row_seq, self.row_pos, self.row_src = i32(rp["row_seq"], 0), i32(rp["row_pos"], 0), i32(rp["row_src"], -1)
+        self.seq_row0 = torch.tensor(rp["seq_row0"], dtype=torch.int32).to(device)
+        self.cls_keep = torch.tensor(rp["cls_keep"] + [0] * pad, dtype=torch.uint8).to(device)
+        self.c = _TTRows(self.n_seq, self.M, self.M_pad, self.max_len, self.row_seq.data_ptr(), self.row_pos.data_ptr(),
+                         self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr())
+        self.ws = None    # inference workspace (no activations kept), allocated on first use
+
+
+class _TextTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, enc, plan):
+        lib = nat.load()
+        model = enc._c_model(emb.device)
+        save = 1 if ctx.needs_input_grad[0] else 0
+        nbytes = lib.vlsa_tt_workspace_bytes(ctypes.byref(model), ctypes.byref(plan.c), save)
+        if nbytes == 0:
+            raise VlsaNativeError("text tower: unsupported shape (width % 128, width <= 768, 64 features per head, <= 128 rows per prompt)")
+        if save:
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=emb.device)      # holds the activations until backward
+        else:
+            if plan.ws is None or plan.ws.numel() < nbytes:
+                plan.ws = torch.zeros(nbytes, dtype=torch.uint8, device=emb.device)
+            ws = plan.ws
+        x = emb.detach()
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            x = x.float().contiguous()
+        out = torch.empty(plan.n_seq, enc.output_dim, dtype=torch.float32, device=emb.device)
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1),
+                                      ctypes.c_void_p(ws.data_ptr()), save, ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
+        if save:
+            ctx.ws, ctx.plan, ctx.enc, ctx.shape = ws, plan, enc, tuple(emb.shape)
+        ctx.keep = x
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = nat.load()
+        enc, plan = ctx.enc, ctx.plan
+        model = enc._c_model(dout.device)
+        g = dout.detach().float().contiguous()
+        demb = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        nat.check(lib.vlsa_tt_backward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(g.data_ptr()),
+                                       ctypes.c_void_p(ctx.ws.data_ptr()), ctypes.c_void_p(demb.data_ptr()), demb.stride(0),
+                                       demb.stride(1), demb.numel(), s), "vlsa_tt_backward")
+        ctx.ws = None
+        return demb, None, None
+
+
+class CONCHPromptEncoder(nn.Module):
+    """``CONCHPromptEncoder(coca_model)`` adopts the text tower of a CoCa model exactly like the reference does
+    (``coca_model.text.{positional_embedding, transformer, ln_final, cls_emb, text_projection, token_embedding, heads,
+    pad_id}``, model/prompt_encoder.py:213-243); ``CONCHPromptEncoder(width=..., heads=..., layers=...)`` builds an empty tower
+    of the CONCH text architecture to ``load_state_dict`` into (model/conch/model_configs/conch_ViT-B-16.json: 768 / 12 / 12,
+    128 positions, 32007 tokens, 512 outputs)."""
+
+    def __init__(self, coca_model=None, *, width: int = 768, heads: int = 12, layers: int = 12, context_length: int = 128,
+                 vocab_size: int = 32007, output_dim: int = 512):
+        super().__init__()
+        if coca_model is not None:
+            t = coca_model.text
+            self.pad_id = t.pad_id
+            assert self.pad_id == 0, "Assume pad_id = 0 in CONCH to encode prompts as expected."
+            self.heads = t.heads
+            self.positional_embedding = t.positional_embedding
+            self.transformer = t.transformer
+            self.ln_final = t.ln_final
+            self.cls_emb = t.cls_emb
+            self.text_projection = t.text_projection
+            self.token_embedding = t.token_embedding
+            if self.cls_emb is None:
+                raise NotImplementedError("the CONCH text tower embeds a CLS token (embed_cls=True); towers without one are not supported")
+        else:
+            self.pad_id, self.heads = 0, heads
+            self.positional_embedding = nn.Parameter(torch.empty(context_length, width))
+            self.transformer = _Transformer(width, layers, heads)
+            self.ln_final = nn.LayerNorm(width)
+            self.cls_emb = nn.Parameter(torch.empty(width))
+            self.text_projection = nn.Parameter(torch.empty(width, output_dim))
+            self.token_embedding = nn.Embedding(vocab_size, width)
+            self.reset_parameters()
+        self.context_length = self.positional_embedding.shape[0]
+        self.output_dim = self.text_projection.shape[1]
+        self.text_config = {"max_num_tokens": self.context_length - 1, "embedding_dim": self.token_embedding.embedding_dim,
+                            "embedding_dtype": self.token_embedding.weight.dtype}
+        self._cm, self._cm_key, self._plans = None, None, {}
+
+    def reset_parameters(self):
+        """TextTransformer.init_parameters (model/conch/transformer.py:376-392)."""
+        d, L = self.transformer.width, self.transformer.layers
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        nn.init.normal_(self.cls_emb, std=0.01)
+        proj_std, attn_std, fc_std = (d ** -0.5) * ((2 * L) ** -0.5), d ** -0.5, (2 * d) ** -0.5
+        for blk in self.transformer.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(blk.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=d ** -0.5)
+
+    # -- C-side view of the weights ------------------------------------------------------------------------------------
+    def _tower_tensors(self):
+        ts = [self.positional_embedding, self.cls_emb, self.ln_final.weight, self.ln_final.bias, self.text_projection]
+        for blk in self.transformer.resblocks:
+            ts += [blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.attn.out_proj.weight,
+                   blk.attn.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias,
+                   blk.mlp.c_proj.weight, blk.mlp.c_proj.bias]
+        return ts
+
+    def _c_model(self, device):
+        ts = self._tower_tensors()
+        key = tuple(t.data_ptr() for t in ts)
+        if self._cm is not None and key == self._cm_key:
+            return self._cm
+        for t in ts:
+            if not t.is_cuda or t.device != device:
+                raise VlsaNativeError("the text tower runs on the MI355X only: its weights must be on the device of the prompts "
+                                      "(there is no CPU fallback)")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise VlsaNativeError("text tower weights must be contiguous fp32 tensors")
+        blocks = list(self.transformer.resblocks)
+        arr = (_TTLayer * len(blocks))()
+        for i in range(len(blocks)):
+            for j, name in enumerate(n for n, _ in _TTLayer._fields_):
+                setattr(arr[i], name, ts[5 + 12 * i + j].data_ptr())
+        width = self.positional_embedding.shape[1]
+        self._cm = _TTModel(width, self.heads, len(blocks), self.output_dim, self.context_length, arr, ts[0].data_ptr(),
+                            ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), ts[4].data_ptr())
+        self._cm_arr, self._cm_key = arr, key
+        return self._cm
+
+    def _plan(self, pseudo_tokens, device) -> _RowPlan:
+        key = (pseudo_tokens.data_ptr(), pseudo_tokens._version, tuple(pseudo_tokens.shape), str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 16:
+                self._plans.clear()
+            plan = _RowPlan(pseudo_tokens, self.context_length, device)
+            plan.keep = pseudo_tokens           # keeps the key's data_ptr alive / unique
+            self._plans[key] = plan
+        return plan
+
+    # -- reference API ---------------------------------------------------------------------------------------------------
+    def generate_pseudo_tokens(self, text):
+        """1, 2, ... up to the token before the first pad, zeros behind it (model/prompt_encoder.py:257-265).  A row without
+        any pad yields all zeros there (argmax of an all-False row is 0) -- kept as is."""
+        first_pad = (text == self.pad_id).int().argmax(dim=-1)
+        pos = torch.arange(text.shape[1], device=text.device)[None, :]
+        return torch.where(pos < first_pad[:, None], pos + 1, torch.zeros_like(pos)).to(text.dtype)
+
+    def forward(self, prompts_text=None, prompts_embedding=None, prompts_pseudo_tokens=None):
+        """prompts_text [n, 128] token ids (last slot = CLS placeholder) or prompts_embedding [n, 127, width] with
+        prompts_pseudo_tokens [n, 127] (0 = pad) -> [n, output_dim]   (model/prompt_encoder.py:267-322)."""
+        L = self.context_length - 1
+        if prompts_text is not None:
+            assert prompts_text.shape[1] == L + 1, "Found invalid input of `prompts_text`."
+            ids = prompts_text[:, :-1]                              # make space for the CLS token
+            if prompts_pseudo_tokens is None:
+                prompts_pseudo_tokens = self.generate_pseudo_tokens(ids)
+            x = self.token_embedding(ids.to(self.token_embedding.weight.device))
+        else:
+            assert prompts_embedding is not None, "Found null `prompts_text`, please specify `prompts_embedding`."
+            assert prompts_pseudo_tokens is not None, "Found null `prompts_text`, please specify `prompts_pseudo_tokens`."
+            x = prompts_embedding
+        assert x.shape[1] == L
+        if not x.is_cuda:
+            raise VlsaNativeError("vlsa_amd runs on MI355X only: got CPU prompt embeddings (there is no CPU fallback; the CPU "
+                                  "oracle under oracle/ is test infrastructure)")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in self._tower_tensors()):
+            raise NotImplementedError("the text tower is frozen on this path (vlsa_txt_encoder_frozen: True): freeze its parameters; "
+                                      "gradients are produced for prompts_embedding only")
+        plan = self._plan(prompts_pseudo_tokens, x.device)
+        return _TextTowerFn.apply(x, self, plan)

@@ -58,6 +58,10 @@ class VLSA(nn.Module):
             self.prompt_learner = prompt_learner
         if prompt_encoder is not None:
             self.prompt_encoder = prompt_encoder
+        if (text_provider is None and pretrained_text_features is None and prompt_learner is not None
+                and prompt_encoder is not None):
+            # the reference's CoOp route (model/vlsa.py:149-156,163-164): rank prompts -> text tower, both on the GPU here
+            text_provider = self._coop_text_features
         # An nn.Module given as the provider IS the reference's 'Adapter' prompt learner (model/vlsa.py:65-66,166-167): it is
         # registered under the reference's attribute name so that checkpoints carry `prompt_adapter.*` keys.
         self._provider_is_module = isinstance(text_provider, nn.Module)
@@ -90,6 +94,14 @@ class VLSA(nn.Module):
             key.extend((id(t), t._version) for t in m.parameters())
             key.extend((id(t), t._version) for t in m.buffers())
         return tuple(key)
+
+    def compute_text_features_with_coop(self, prompt_learner):
+        """prompt learner's sentence embeddings through the text tower (model/vlsa.py:149-156)."""
+        return self.prompt_encoder(prompts_embedding=prompt_learner(),
+                                   prompts_pseudo_tokens=prompt_learner.pseudo_sentence_tokens)
+
+    def _coop_text_features(self):
+        return self.compute_text_features_with_coop(self.prompt_learner)
 
     def _drop_text_cache(self, *_):
         self._text_cache = self._text_cache_key = None
