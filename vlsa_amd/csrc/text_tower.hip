@@ -74,7 +74,11 @@ enum { PRO_NONE = 0, PRO_LN = 1 };
 enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_GELU = 4 };
 constexpr int kSlabMax = 12;   // PRO_LN: (K / NW) / 16 groups of the A slab kept in registers (K <= 768 at NW = 4)
 
-template <int MT, int NW, int PRO>
+// GT = number of 16-column groups per wave as a compile-time constant (0: runtime).  With GT known every loop below unrolls
+// into straight-line code and the compiler's s_waitcnt pass can keep the prefetched loads in flight; with a runtime trip
+// count it parks the ring behind `s_waitcnt vmcnt(0)` + register moves at every basic-block edge (measured: 36 us instead
+// of 5 us for the fc2 product).  The CONCH sizes are instantiated, anything else takes the runtime path.
+template <int MT, int NW, int PRO, int GT>
 __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
                                                         float* __restrict__ Y, int ldy, float* __restrict__ Ypre, int N, int K,
@@ -100,13 +104,24 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
         }
     }
     const int n0 = ntile * 32, m0 = mg * (16 * MT);
-    const int KW = K / NW, kbeg = w * KW, G = KW >> 4;
+    const int KW = K / NW, kbeg = w * KW;
+    const int G = GT > 0 ? GT : (KW >> 4);
     const float* Ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)(m0 + 16 * t + r) * lda + kbeg + 4 * g;
     const float* Wp[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) Wp[u] = W + (size_t)(n0 + 16 * u + r) * K + kbeg + 4 * g;
+#ifdef VLSA_TT_DEBUG
+    if (epi & 512) {    // experiment: every workgroup reads weight tile 0 (stays in L2) instead of its own
+#pragma unroll
+        for (int u = 0; u < 2; ++u) Wp[u] = W + (size_t)(16 * u + r) * K + kbeg + 4 * g;
+    }
+    if (epi & 1024) {   // experiment: every workgroup reads A rows 0..15
+#pragma unroll
+        for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)r * lda + kbeg + 4 * g;
+    }
+#endif
 
     f32x4 acc[MT][2];
 #pragma unroll
@@ -116,6 +131,14 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 
     if constexpr (PRO == PRO_LN) {
         // ---- LayerNorm fused into the operand load: this wave's [16 MT rows] x [KW columns] slab of A in registers --------
+        // the LayerNorm affine parameters go through LDS (first loads issued, so they are the first to land; reading them back
+        // later is an LDS access and does not queue behind the weight stream the way a global load would: vmcnt is in-order)
+        float* sgam = red + 1024;           // [K] gamma | [K] beta   (K <= 768: 6 KB of the 24 KB reduction buffer)
+        f32x4 gld = {0.f, 0.f, 0.f, 0.f}, bld = {0.f, 0.f, 0.f, 0.f};
+        if (tid * 4 < K) {
+            gld = *reinterpret_cast<const f32x4*>(ln_w + tid * 4);
+            bld = *reinterpret_cast<const f32x4*>(ln_b + tid * 4);
+        }
         f32x4 slab[MT][kSlabMax];
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
@@ -123,6 +146,21 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 #pragma unroll
                 for (int t = 0; t < MT; ++t) slab[t][jj] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * jj);
             }
+        // ... and ALL of this wave's weight groups behind them: the kernel is a latency chain (few waves per CU, every weight
+        // read once from HBM), so everything the wave will ever need is put in flight before the first dependent use; the
+        // LayerNorm statistics below overlap the weight fetch
+        f32x4 wall[kSlabMax][2];
+#pragma unroll
+        for (int jj = 0; jj < kSlabMax; ++jj)
+            if (jj < G) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) wall[jj][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * jj);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the weight loads next to their MFMAs)
+        if (tid * 4 < K) {
+            *reinterpret_cast<f32x4*>(sgam + tid * 4) = gld;
+            *reinterpret_cast<f32x4*>(sgam + K + tid * 4) = bld;
+        }
         float* st = red;                    // [NW][16 MT] partial row statistics (the reduction buffer is free until the end)
         float mean[MT], rstd[MT];
 #pragma unroll
@@ -167,61 +205,91 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
             rstd[t] = 1.f / sqrtf(s / (float)K + kLnEps);
         }
         __syncthreads();                    // st is handed back to the final reduction
-        const float* gw = ln_w + kbeg + 4 * g;
-        const float* gb = ln_b + kbeg + 4 * g;
-        f32x4 b[2], bn[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const f32x4*>(Wp[u]);
+        // normalise the slab in place (affine parameters from LDS); the MFMA loop below then runs on registers only
+        const float* gw = sgam + kbeg + 4 * g;
+        const float* gb = sgam + K + kbeg + 4 * g;
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
-                if (jj + 1 < G) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) bn[u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * (jj + 1));
-                }
                 const f32x4 gam = *reinterpret_cast<const f32x4*>(gw + 16 * jj);
                 const f32x4 bet = *reinterpret_cast<const f32x4*>(gb + 16 * jj);
-                f32x4 a[MT];
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[t][i] = fmaf((slab[t][jj][i] - mean[t]) * rstd[t], gam[i], bet[i]);
+                    for (int i = 0; i < 4; ++i) slab[t][jj][i] = fmaf((slab[t][jj][i] - mean[t]) * rstd[t], gam[i], bet[i]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < kSlabMax; ++jj)
+            if (jj < G) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], b[u][i], acc[t][u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) b[u] = bn[u];
+                        for (int u = 0; u < 2; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(slab[t][jj][i], wall[jj][u][i], acc[t][u], 0, 0, 0);
             }
     } else {
-        f32x4 a[MT], b[2], an[MT], bn[2];
+        // register ring PF groups deep: the loads of group jj + PF are issued when group jj is consumed (vmcnt returns in order)
+        constexpr int PF = MT == 1 ? 8 : 6;
+        f32x4 ra[PF][MT], rb[PF][2];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(Ap[t]);
+        for (int sI = 0; sI < PF; ++sI)
+            if (sI < G) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const f32x4*>(Wp[u]);
-        for (int jj = 0; jj < G; ++jj) {
-            if (jj + 1 < G) {
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * sI);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + 1));
-#pragma unroll
-                for (int u = 0; u < 2; ++u) bn[u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * (jj + 1));
+                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * sI);
             }
+        // keep the machine scheduler from sinking the prefetch loads next to their uses (it minimises register pressure and
+        // would leave ~2 groups in flight): nothing moves across these fences
+        __builtin_amdgcn_sched_barrier(0);
+        auto stage = [&](int sI, int jj) __attribute__((always_inline)) {
+            f32x4 a[MT], b[2];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = ra[sI][t];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = rb[sI][u];
+            if (jj + PF < G) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + PF));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * (jj + PF));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef VLSA_TT_DEBUG
+            if (epi & 256) {   // experiment: no MFMAs, keep the loads alive with one add per loaded vector
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t][0] += a[t];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[0][u] += b[u];
+            } else
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], b[u][i], acc[t][u], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (GT > 0) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t) a[t] = an[t];
+            for (int jj = 0; jj < GT; ++jj) stage(jj % PF, jj);
+        } else {
+            for (int j0 = 0; j0 < G; j0 += PF) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) b[u] = bn[u];
+                for (int sI = 0; sI < PF; ++sI)
+                    if (j0 + sI < G) stage(sI, j0 + sI);
+            }
         }
     }
 
     // ---- reduce the NW K-slices through LDS (fixed order), then bias / GELU / residual and store -------------------------
+    if constexpr (PRO == PRO_LN) __syncthreads();   // every wave is done reading gamma / beta from the buffer reused below
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -251,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 // A workgroup owns 16 MT rows x 64 columns: lane (c = l & 15, g) loads W[k][n0 + 4 c .. + 3] with one 16-byte load and feeds
 // the four values to four column tiles (tile u holds column n0 + 4 c + u), k = 16 jj + 4 g + s for MFMA step s.
 enum { EPN_GELU_BWD = 1 };
-template <int MT, int NW>
+template <int MT, int NW, int GT>
 __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nn(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
                                                         float* __restrict__ Y, int ldy, int Kc, int MG, int epi,
                                                         const float* __restrict__ H, int ldh) {
@@ -262,7 +330,8 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nn(const float* __restrict_
     const int c = lane & 15, g = lane >> 4;
     const int ctile = blockIdx.x / MG, mg = blockIdx.x % MG;
     const int n0 = ctile * 64, m0 = mg * (16 * MT);
-    const int KW = Kc / NW, kbeg = w * KW, G = KW >> 4;
+    const int KW = Kc / NW, kbeg = w * KW;
+    const int G = GT > 0 ? GT : (KW >> 4);
     const float* Ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)(m0 + 16 * t + c) * lda + kbeg + 4 * g;
@@ -273,28 +342,47 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nn(const float* __restrict_
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 a[MT], b[4], an[MT], bn[4];
+    constexpr int PF = MT == 1 ? 6 : 4;     // register ring, as in k_tt_gemm_nt
+    f32x4 ra[PF][MT], rb[PF][4];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const f32x4*>(Ap[t]);
+    for (int sI = 0; sI < PF; ++sI)
+        if (sI < G) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)s * ldw);
-    for (int jj = 0; jj < G; ++jj) {
-        if (jj + 1 < G) {
+            for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * sI);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) an[t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + 1));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) bn[s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)(16 * (jj + 1) + s) * ldw);
+            for (int s = 0; s < 4; ++s) rb[sI][s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)(16 * sI + s) * ldw);
         }
+    __builtin_amdgcn_sched_barrier(0);
+    auto stage = [&](int sI, int jj) __attribute__((always_inline)) {
+        f32x4 a[MT], b[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = ra[sI][t];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = rb[sI][s];
+        if (jj + PF < G) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + PF));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rb[sI][s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)(16 * (jj + PF) + s) * ldw);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[s][u], acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (GT > 0) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = an[t];
+        for (int jj = 0; jj < GT; ++jj) stage(jj % PF, jj);
+    } else {
+        for (int j0 = 0; j0 < G; j0 += PF) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = bn[s];
+            for (int sI = 0; sI < PF; ++sI)
+                if (j0 + sI < G) stage(sI, j0 + sI);
+        }
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -330,17 +418,21 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
                                                     int heads, int d) {
     __shared__ float Ks[kAttnMaxS][kHeadDim + 1];
     __shared__ float Vs[kAttnMaxS][kHeadDim + 1];
+    __shared__ float Qs[kAttnMaxS][kHeadDim];
     const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
     const int r0 = seq_row0[seq], S = seq_row0[seq + 1] - r0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < S * kHeadDim; e += 256) {
+    for (int e = tid; e < S * kHeadDim; e += 256) {   // q, k, v of the prompt in ONE round of global loads
         const int j = e >> 6, c = e & 63;
-        Ks[j][c] = qkv[(size_t)(r0 + j) * ld + d + h * kHeadDim + c];
-        Vs[j][c] = qkv[(size_t)(r0 + j) * ld + 2 * d + h * kHeadDim + c];
+        const size_t base = (size_t)(r0 + j) * ld + h * kHeadDim + c;
+        const float qv = qkv[base], kv = qkv[base + d], vv = qkv[base + 2 * d];
+        Qs[j][c] = qv * 0.125f;   // head_dim^-0.5
+        Ks[j][c] = kv;
+        Vs[j][c] = vv;
     }
     __syncthreads();
     for (int i = w; i < S; i += 4) {
-        const float q = qkv[(size_t)(r0 + i) * ld + h * kHeadDim + lane] * 0.125f;   // head_dim^-0.5
+        const float q = Qs[i][lane];
         const bool is_cls = i == S - 1;
         float s[2], p[2];
 #pragma unroll
@@ -455,12 +547,13 @@ __global__ __launch_bounds__(256) void k_tt_ln_bwd(const float* __restrict__ da,
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int nslot = d >> 6;
-    float xv[kLnSlots], gv[kLnSlots];
+    float xv[kLnSlots], gv[kLnSlots], rv[kLnSlots];
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) {
+        if (k < nslot) {   // every load of the row in one round
             xv[k] = x[(size_t)row * d + lane + 64 * k];
             gv[k] = da[(size_t)row * d + lane + 64 * k] * gamma[lane + 64 * k];
+            rv[k] = dres ? dres[(size_t)row * d + lane + 64 * k] : 0.f;
         }
     float mean, rstd;
     ln_stats(xv, nslot, d, mean, rstd);
@@ -476,11 +569,7 @@ __global__ __launch_bounds__(256) void k_tt_ln_bwd(const float* __restrict__ da,
     sgx = wave_sum(sgx) / (float)d;
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) {
-            float o = rstd * (gv[k] - sg - xv[k] * sgx);
-            if (dres) o += dres[(size_t)row * d + lane + 64 * k];
-            dx[(size_t)row * d + lane + 64 * k] = o;
-        }
+        if (k < nslot) dx[(size_t)row * d + lane + 64 * k] = rv[k] + rstd * (gv[k] - sg - xv[k] * sgx);
 }
 
 // pooled[s] = ln_final(x[CLS row of prompt s]); rows n_seq .. n_pad-1 of pooled are zeroed (GEMM padding).
@@ -595,25 +684,42 @@ inline size_t scratch_floats(const Shape& s) {
     return (size_t)s.M_pad * s.d * (1 + 1 + 4 + 2 + 4) + (size_t)s.ns_pad * s.d * 2 + (size_t)s.ns_pad * s.out_dim;
 }
 
-template <int MT, int NW, int PRO>
-int launch_nt(const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
-              float* Ypre, int N, int K, int M_pad, int epi, const float* ln_w, const float* ln_b, hipStream_t st) {
+template <int MT, int NW, int PRO, int GT>
+int launch_nt_g(const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
+                float* Ypre, int N, int K, int M_pad, int epi, const float* ln_w, const float* ln_b, hipStream_t st) {
     const int MG = M_pad / (16 * MT), NT = N / 32;
     const size_t lds = (size_t)NW * MT * 8 * 64 * sizeof(float);
-    hipLaunchKernelGGL((k_tt_gemm_nt<MT, NW, PRO>), dim3(NT * MG), dim3(NW * 64), lds, st, A, lda, W, bias, resid, ldr, Y, ldy, Ypre,
-                       N, K, MG, (NT % 8 == 0) ? 1 : 0, epi, ln_w, ln_b);
+    hipLaunchKernelGGL((k_tt_gemm_nt<MT, NW, PRO, GT>), dim3(NT * MG), dim3(NW * 64), lds, st, A, lda, W, bias, resid, ldr, Y, ldy,
+                       Ypre, N, K, MG, (NT % 8 == 0) ? 1 : 0, epi, ln_w, ln_b);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
+// G1, G2: the group counts of the CONCH-size tower for this product (compile-time specialisations); anything else: runtime G
+template <int MT, int NW, int PRO, int G1, int G2 = G1>
+int launch_nt(const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
+              float* Ypre, int N, int K, int M_pad, int epi, const float* ln_w, const float* ln_b, hipStream_t st) {
+    const int G = K / NW / 16;
+    if (G == G1) return launch_nt_g<MT, NW, PRO, G1>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
+    if (G == G2) return launch_nt_g<MT, NW, PRO, G2>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
+    return launch_nt_g<MT, NW, PRO, 0>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
+}
 
-template <int MT, int NW>
-int launch_nn(const float* A, int lda, const float* W, int ldw, float* Y, int ldy, int Kc, int Nout, int M_pad, int epi,
-              const float* H, int ldh, hipStream_t st) {
+template <int MT, int NW, int GT>
+int launch_nn_g(const float* A, int lda, const float* W, int ldw, float* Y, int ldy, int Kc, int Nout, int M_pad, int epi,
+                const float* H, int ldh, hipStream_t st) {
     const int MG = M_pad / (16 * MT);
     const size_t lds = (size_t)NW * MT * 16 * 64 * sizeof(float);
     static DeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm_nn<MT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tt_gemm_nn<MT, NW>), dim3((Nout / 64) * MG), dim3(NW * 64), lds, st, A, lda, W, ldw, Y, ldy, Kc, MG, epi, H, ldh);
+    if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm_nn<MT, NW, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_tt_gemm_nn<MT, NW, GT>), dim3((Nout / 64) * MG), dim3(NW * 64), lds, st, A, lda, W, ldw, Y, ldy, Kc, MG, epi, H, ldh);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+template <int MT, int NW, int G1, int G2 = G1>
+int launch_nn(const float* A, int lda, const float* W, int ldw, float* Y, int ldy, int Kc, int Nout, int M_pad, int epi,
+              const float* H, int ldh, hipStream_t st) {
+    const int G = Kc / NW / 16;
+    if (G == G1) return launch_nn_g<MT, NW, G1>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
+    if (G == G2) return launch_nn_g<MT, NW, G2>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
+    return launch_nn_g<MT, NW, 0>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
 }
 
 #define TT_TRY(expr)                  \
@@ -630,6 +736,17 @@ extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_
     const size_t regions = save_for_backward ? (size_t)s.layers : 1;
     return (regions * layer_floats(s) + scratch_floats(s)) * sizeof(float);
 }
+
+#ifdef VLSA_TT_DEBUG
+#include <cstdlib>
+static int tt_debug_bits() {
+    const char* e = getenv("VLSA_TT_DEBUG_BITS");
+    return e ? atoi(e) : 0;
+}
+#define TT_DBG tt_debug_bits()
+#else
+#define TT_DBG 0
+#endif
 
 extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const float* emb, int64_t emb_seq_stride,
                                int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out, void* stream) {
@@ -659,14 +776,14 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         float* h_pre = x_mid + (size_t)Mp * d;
         float* x_next = (L + 1 < s.layers) ? (save_for_backward ? region(L + 1) : x_in) : x_final;
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
-        TT_TRY((launch_nt<3, 4, PRO_LN>(x_in, d, w.in_w, w.in_b, nullptr, 0, qkv, 3 * d, nullptr, 3 * d, d, Mp, EPI_BIAS, w.ln1_w, w.ln1_b, st)));
+        TT_TRY((launch_nt<3, 4, PRO_LN, 12>(x_in, d, w.in_w, w.in_b, nullptr, 0, qkv, 3 * d, nullptr, 3 * d, d, Mp, EPI_BIAS, w.ln1_w, w.ln1_b, st)));
         hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, attn, d, r->seq_row0, r->cls_keep,
                            s.heads, d);
         if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-        TT_TRY((launch_nt<3, 8, PRO_NONE>(attn, d, w.out_w, w.out_b, x_in, d, x_mid, d, nullptr, d, d, Mp, EPI_BIAS | EPI_RESID, nullptr, nullptr, st)));
-        TT_TRY((launch_nt<3, 4, PRO_LN>(x_mid, d, w.fc_w, w.fc_b, nullptr, 0, h_act, 4 * d, save_for_backward ? h_pre : nullptr, 4 * d, d, Mp,
+        TT_TRY((launch_nt<3, 8, PRO_NONE, 6>(attn, d, w.out_w, w.out_b, x_in, d, x_mid, d, nullptr, d, d, Mp, EPI_BIAS | EPI_RESID, nullptr, nullptr, st)));
+        TT_TRY((launch_nt<3, 4, PRO_LN, 12>(x_mid, d, w.fc_w, w.fc_b, nullptr, 0, h_act, 4 * d, save_for_backward ? h_pre : nullptr, 4 * d, d, Mp,
                                         EPI_BIAS | EPI_GELU, w.ln2_w, w.ln2_b, st)));
-        TT_TRY((launch_nt<1, 8, PRO_NONE>(h_act, 4 * d, w.proj_w, w.proj_b, x_mid, d, x_next, d, nullptr, d, 4 * d, Mp, EPI_BIAS | EPI_RESID, nullptr,
+        TT_TRY((launch_nt<1, 8, PRO_NONE, 24>(h_act, 4 * d, w.proj_w, w.proj_b, x_mid, d, x_next, d, nullptr, d, 4 * d, Mp, EPI_BIAS | EPI_RESID | TT_DBG, nullptr,
                                           nullptr, st)));
     }
     hipLaunchKernelGGL(k_tt_lnf_fwd, dim3((s.ns_pad + 3) / 4), dim3(256), 0, st, x_final, r->seq_row0, m->lnf_w, m->lnf_b, pooled, d,
@@ -674,7 +791,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     // text features = pooled @ text_projection  ([ns_pad, d] x [d, out_dim]); the padded rows land in scratch, then copy out
     float* feat = pooled + (size_t)s.ns_pad * d * 2;   // dout_pad slot doubles as the padded output
-    TT_TRY((launch_nn<3, 4>(pooled, d, m->text_proj, s.out_dim, feat, s.out_dim, d, s.out_dim, s.ns_pad, 0, nullptr, 0, st)));
+    TT_TRY((launch_nn<3, 4, 12>(pooled, d, m->text_proj, s.out_dim, feat, s.out_dim, d, s.out_dim, s.ns_pad, 0, nullptr, 0, st)));
     if (hipMemcpyAsync(out, feat, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
     return VLSA_OK;
 }
@@ -705,7 +822,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
     if (hipMemcpyAsync(dout_pad, dout, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
     // d pooled = dout @ text_projection^T: text_projection [d, out_dim] read as W[n = d][k = out_dim]
     if ((s.out_dim / 4) % 16) return VLSA_EUNSUPPORTED;
-    TT_TRY((launch_nt<3, 4, PRO_NONE>(dout_pad, s.out_dim, m->text_proj, nullptr, nullptr, 0, dpool, d, nullptr, d, s.out_dim, s.ns_pad, 0, nullptr,
+    TT_TRY((launch_nt<3, 4, PRO_NONE, 8>(dout_pad, s.out_dim, m->text_proj, nullptr, nullptr, 0, dpool, d, nullptr, d, s.out_dim, s.ns_pad, 0, nullptr,
                                       nullptr, st)));
     hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, dpool, x_final, r->row_seq, r->row_src, m->lnf_w, dxa, d, s.M, Mp);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
@@ -721,18 +838,18 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         float* x_mid = qkv + (size_t)Mp * 3 * d;
         float* h_pre = x_mid + (size_t)Mp * d;
         // MLP branch: d h_pre = (dx @ W_proj) * gelu'(h_pre);  d ln_2 out = d h_pre @ W_fc;  dx_mid = dx + ln_2'(.)
-        TT_TRY((launch_nn<3, 8>(dx, d, w.proj_w, 4 * d, h_act, 4 * d, d, 4 * d, Mp, EPN_GELU_BWD, h_pre, 4 * d, st)));
-        TT_TRY((launch_nn<1, 8>(h_act, 4 * d, w.fc_w, d, dbig, d, 4 * d, d, Mp, 0, nullptr, 0, st)));
+        TT_TRY((launch_nn<3, 8, 6>(dx, d, w.proj_w, 4 * d, h_act, 4 * d, d, 4 * d, Mp, EPN_GELU_BWD, h_pre, 4 * d, st)));
+        TT_TRY((launch_nn<1, 8, 24, 18>(h_act, 4 * d, w.fc_w, d, dbig, d, 4 * d, d, Mp, 0, nullptr, 0, st)));
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, dbig, x_mid, w.ln2_w, dx, dx2, d, Mp);
         if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
         // attention branch: d attn = dx_mid @ W_out;  dqkv = attention'(.);  d ln_1 out = dqkv @ W_in;  dx_in = dx_mid + ln_1'(.)
-        TT_TRY((launch_nn<1, 4>(dx2, d, w.out_w, d, attn, d, d, d, Mp, 0, nullptr, 0, st)));
+        TT_TRY((launch_nn<1, 4, 12>(dx2, d, w.out_w, d, attn, d, d, d, Mp, 0, nullptr, 0, st)));
         hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, attn, d, dbig, r->seq_row0,
                            r->cls_keep, s.heads, d);
         if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
         // rows M .. M_pad-1 of dqkv are never written by the attention kernel: they hold stale finite numbers that only reach
         // the (discarded) padding rows of the next products
-        TT_TRY((launch_nn<1, 8>(dbig, 3 * d, w.in_w, d, h_act, d, 3 * d, d, Mp, 0, nullptr, 0, st)));
+        TT_TRY((launch_nn<1, 8, 24, 18>(dbig, 3 * d, w.in_w, d, h_act, d, 3 * d, d, Mp, 0, nullptr, 0, st)));
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, h_act, x_in, w.ln1_w, dx2, dx, d, Mp);
         if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     }
