@@ -378,16 +378,22 @@ typedef struct vlsa_tt_rows {
 /*
  * Replaces CONCHPromptEncoder.forward (model/prompt_encoder.py:267-322): prompts_embedding [n_seq, ctx_len - 1, width]
  * (element [s, t] at emb + s * emb_seq_stride + t * emb_tok_stride, unit inner stride) -> text features out [n_seq, out_dim].
- * workspace: vlsa_tt_workspace_bytes(model, rows, save_for_backward) bytes; with save_for_backward != 0 it keeps every
- * block's inputs for vlsa_tt_backward, which turns dout [n_seq, out_dim] into d prompts_embedding (demb, same strides;
+ * workspace: vlsa_tt_workspace_bytes(model, rows, save_for_backward) bytes, zeroed once by the caller; with
+ * save_for_backward != 0 it keeps every block's inputs for vlsa_tt_backward, which turns dout [n_seq, out_dim] into d prompts_embedding (demb, same strides;
  * demb_floats = size of the whole demb allocation, zeroed here first).  The tower's own weights get no gradient: frozen in
  * every shipped configuration (cfg_vlsa_conch.yaml:69).
  */
+/* The products read the weights from "tiled" (MFMA-fragment-major) copies: 1 KB per load instruction instead of 16 rows x 64 B.
+ * vlsa_tt_pack_weights writes them into `packed` (vlsa_tt_packed_bytes(model, with_backward) bytes; with_backward also packs
+ * the transposes the input-gradient products use) -- once per version of the (frozen) weights. */
+size_t vlsa_tt_packed_bytes(const vlsa_tt_model* model, int with_backward);
+int vlsa_tt_pack_weights(const vlsa_tt_model* model, void* packed, int with_backward, void* stream);
 size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* model, const vlsa_tt_rows* rows, int save_for_backward);
-int vlsa_tt_forward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const float* emb, int64_t emb_seq_stride,
-                    int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out, void* stream);
-int vlsa_tt_backward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const float* dout, void* workspace, float* demb,
-                     int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream);
+int vlsa_tt_forward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const void* packed, const float* emb,
+                    int64_t emb_seq_stride, int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out,
+                    void* stream);
+int vlsa_tt_backward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const void* packed, const float* dout, void* workspace,
+                     float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream);
 
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);

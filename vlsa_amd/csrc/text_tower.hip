@@ -19,12 +19,13 @@
 //
 // Kernels
 //   k_tt_embed            compact rows <- prompts_embedding[seq, pos] (or cls_emb) + positional_embedding[pos]
-//   k_tt_gemm_nt<MT,NW>   Y = pro(A) W^T (+ bias) (+ GELU) (+ residual); W [N, K] as nn.Linear stores it.  A workgroup owns
-//                         16 MT rows x 32 columns; its NW waves split K and are reduced through LDS (deterministic, no
-//                         atomics).  pro = LayerNorm fused into the A-operand load (the wave's whole A slab sits in
-//                         registers; row statistics by a two-pass reduction across the waves), or identity.
-//   k_tt_gemm_nn<MT,NW>   Y = A W (contraction along W's rows: the input-gradient products of backward, and the final
-//                         text projection); a workgroup owns 16 MT rows x 64 columns, 16-byte weight loads.
+//   k_tt_pack             weights -> "tiled" (MFMA-fragment-major) copies, once per weight version: W for the forward products,
+//                         W^T for the input-gradient products (the tower is frozen, so both are constants)
+//   k_tt_gemm<MT,NW>      Y = pro(A) W^T (+ bias) (+ GELU | * GELU') (+ residual) on tiled operands: every load instruction
+//                         reads 1 KB contiguous.  A workgroup owns 16 MT rows x 32 columns; its NW waves split K and are
+//                         reduced through LDS (deterministic, no atomics).  pro = LayerNorm fused into the A-operand load
+//                         (the wave's whole A slab sits in registers; row statistics by a two-pass reduction across the
+//                         waves), or identity.  The one product kernel serves forward, backward and the text projection.
 //   k_tt_attn_fwd/bwd     per (prompt, head) attention over the compact rows: causal for token rows, explicit key list for
 //                         the CLS row; <= 128 rows forward, <= 64 rows backward.
 //   k_tt_ln_bwd, k_tt_lnf_fwd/bwd, k_tt_scatter   LayerNorm backward (+ residual), ln_final on the CLS rows, d prompts_embedding.
@@ -44,57 +45,101 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tt_embed(float* __restrict__ x, int d, const float* __restrict__ emb, int64_t s_seq,
-                                                 int64_t s_tok, const int* __restrict__ row_seq, const int* __restrict__ row_pos,
-                                                 const int* __restrict__ row_src, const float* __restrict__ pos_emb,
-                                                 const float* __restrict__ cls_emb, int M) {
+// ---------------------------------------------------------------------------------------------------------------
+// "Tiled" fp32 matrices.  Every operand of the products below -- the weights (packed once: the tower is frozen) and the
+// activations (written that way by their producers) -- is stored as 16 x 16 tiles of 1 KB, tiles row-major over
+// (row block, column block); inside a tile element (r, c) sits at float ((c >> 2) * 16 + r) * 4 + (c & 3).  That is the
+// register image of one v_mfma_f32_16x16x4_f32 operand GROUP (four consecutive MFMA steps): lane l = (c >> 2) * 16 + r
+// fetches its four k-values with ONE 16-byte load at tile + 16 l, so a wave instruction reads 1 KB contiguous.
+// Why: the same fragments fetched from row-major storage are 16 rows x 64 B per wave instruction, which the texture
+// path serves at ~75 cycles per instruction (tools/probes/rowload_probe.hip: 9.1 us vs 4.1 us for 72 loads per wave) -- the
+// first version of these products spent 35 us on 5 us of MFMA work, independent of MFMA, HBM and L2 locality.
+__device__ __forceinline__ size_t tiled_index(int r, int c, int C) {
+    return ((size_t)(r >> 4) * (C >> 4) + (c >> 4)) * 256 + ((((c & 15) >> 2) * 16 + (r & 15)) << 2) + (c & 3);
+}
+
+// out (tiled [R, C]) <- W: transpose == 0: R = rows, C = cols, out(r, c) = W[r, c];  transpose != 0: R = cols, C = rows,
+// out(r, c) = W[c, r].  One thread per output float, lane-linear inside a tile.
+__global__ __launch_bounds__(256) void k_tt_pack(const float* __restrict__ W, int rows, int cols, int transpose, float* __restrict__ out) {
+    const int R = transpose ? cols : rows, C = transpose ? rows : cols;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * C) return;
+    const size_t tile = idx >> 8;
+    const int in = (int)(idx & 255), l = in >> 2, i = in & 3;
+    const int r = (int)(tile / (C >> 4)) * 16 + (l & 15), c = (int)(tile % (C >> 4)) * 16 + 4 * (l >> 4) + i;
+    out[idx] = transpose ? W[(size_t)c * cols + r] : W[(size_t)r * cols + c];
+}
+
+// row-major src [n, C] -> tiled dst [n_pad, C], rows n .. n_pad-1 zero.  grid n_pad / 16 row blocks x C / 16.
+__global__ __launch_bounds__(256) void k_tt_tile_rows(const float* __restrict__ src, int n, int C, float* __restrict__ dst) {
+    const int rb = blockIdx.x, cb = blockIdx.y, in = threadIdx.x, l = in >> 2, i = in & 3;
+    const int r = rb * 16 + (l & 15), c = cb * 16 + 4 * (l >> 4) + i;
+    dst[((size_t)rb * gridDim.y + cb) * 256 + in] = r < n ? src[(size_t)r * C + c] : 0.f;
+}
+
+// compact rows <- prompts_embedding[seq, src] (or cls_emb) + positional_embedding[pos]; row-major x and its tiled copy xt
+__global__ __launch_bounds__(256) void k_tt_embed(float* __restrict__ x, float* __restrict__ xt, int d, const float* __restrict__ emb,
+                                                 int64_t s_seq, int64_t s_tok, const int* __restrict__ row_seq,
+                                                 const int* __restrict__ row_pos, const int* __restrict__ row_src,
+                                                 const float* __restrict__ pos_emb, const float* __restrict__ cls_emb, int M) {
     const int row = blockIdx.x;
     float* xr = x + (size_t)row * d;
-    if (row >= M) {
-        for (int c = threadIdx.x * 4; c < d; c += 1024) *reinterpret_cast<f32x4*>(xr + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
-    }
-    const int src = row_src[row];
-    const float* e = src >= 0 ? emb + (size_t)row_seq[row] * s_seq + (size_t)src * s_tok : cls_emb;
-    const float* pe = pos_emb + (size_t)row_pos[row] * d;
-    for (int c = threadIdx.x * 4; c < d; c += 1024) {
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = e[c + i] + pe[c + i];     // e may be a strided view: scalar loads
-        *reinterpret_cast<f32x4*>(xr + c) = v;
+    const bool live = row < M;
+    const int src = live ? row_src[row] : 0;
+    const float* e = !live ? nullptr : (src >= 0 ? emb + (size_t)row_seq[row] * s_seq + (size_t)src * s_tok : cls_emb);
+    const float* pe = live ? pos_emb + (size_t)row_pos[row] * d : nullptr;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float v = live ? e[c] + pe[c] : 0.f;
+        xr[c] = v;
+        xt[tiled_index(row, c, d)] = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Y[m, n] = sum_k pro(A)[m, k] W[n, k]  (+ bias[n]) (gelu) (+ resid[m, n]).
+// Y[m, n] = sum_k pro(A)[m, k] W[n, k]  (+ bias[n]) (gelu | * gelu'(H)) (+ resid[m, n]);  A tiled [M_pad, K], W tiled [N, K].
 // MFMA v_mfma_f32_16x16x4_f32: first operand lane (i = l & 15, kslot = l >> 4) = A[i][k], second operand lane (j = l & 15,
-// kslot) = B[k][j], result lane (j, g = l >> 4) holds D[4 g + v][j], v = 0..3.  One 16-byte load gives a lane the operands of
-// FOUR consecutive MFMA steps: k-slot g of step s contracts column 16 jj + 4 g + s -- the same permutation on both operands.
+// kslot) = B[k][j], result lane (j, g = l >> 4) holds D[4 g + v][j], v = 0..3; k-slot g of step s of group jj contracts
+// column 16 jj + 4 g + s -- the same permutation on both operands.
+// A workgroup owns 16 MT rows x 32 columns; its NW waves split K (each wave streams KW = K / NW columns of both operands:
+// 1 KB per load instruction, each weight read exactly once from HBM per row group) and are reduced through LDS in a fixed
+// order (deterministic, no atomics).  Outputs: row-major Y and / or tiled Yt (the next product's A operand).
 enum { PRO_NONE = 0, PRO_LN = 1 };
-enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_GELU = 4 };
+enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_GELU = 4, EPI_GELU_BWD = 8 };
 constexpr int kSlabMax = 12;   // PRO_LN: (K / NW) / 16 groups of the A slab kept in registers (K <= 768 at NW = 4)
 
-// GT = number of 16-column groups per wave as a compile-time constant (0: runtime).  With GT known every loop below unrolls
-// into straight-line code and the compiler's s_waitcnt pass can keep the prefetched loads in flight; with a runtime trip
-// count it parks the ring behind `s_waitcnt vmcnt(0)` + register moves at every basic-block edge (measured: 36 us instead
-// of 5 us for the fc2 product).  The CONCH sizes are instantiated, anything else takes the runtime path.
+struct GemmArgs {
+    const float* A;        // tiled [M_pad, K]
+    const float* W;        // tiled [N, K]
+    const float* bias;     // [N] or null
+    const float* resid;    // row-major [M_pad, ldr] or null
+    float* Y;              // row-major [M_pad, ldy] or null
+    float* Yt;             // tiled [M_pad, N] or null
+    float* Ypre;           // row-major pre-activation copy (EPI_GELU, training) or null
+    const float* H;        // row-major [M_pad, ldh]: EPI_GELU_BWD multiplies by gelu'(H)
+    const float *ln_w, *ln_b;
+    int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
+};
+
+// Tile choice (measured, K = 12 prompts -> 192 padded rows): the operands reach the MFMAs through the CU's L1 at ~46 B/clk, and an
+// f32 MFMA group needs 512 B of fresh operands per 2 x 16 x 16 x 16 FLOP unless fragments are reused, so the products sit on
+// the L1 limit, not on the matrix pipe: MT = 1 tiles move 1.5 fragments per MFMA (fc2: 170 MB through the L1s = 6 us for 6 us
+// of MFMA work), MT = 3 tiles 0.83; wider workgroups (16 waves, 98 KB reduction buffer) measured 2.3x SLOWER (49 vs 21 us).
+// GT = number of 16-column groups per wave as a compile-time constant (0: runtime).  With GT known the loops unroll into
+// straight-line code and the s_waitcnt pass keeps the prefetched loads in flight; with a runtime trip count it parks the
+// ring behind `s_waitcnt vmcnt(0)` + register moves at every basic-block edge.  The CONCH sizes are instantiated, anything
+// else takes the runtime path.
 template <int MT, int NW, int PRO, int GT>
-__global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict__ A, int lda, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, const float* __restrict__ resid, int ldr,
-                                                        float* __restrict__ Y, int ldy, float* __restrict__ Ypre, int N, int K,
-                                                        int MG, int xcd_map, int epi, const float* __restrict__ ln_w,
-                                                        const float* __restrict__ ln_b) {
+__global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     constexpr int Q = MT * 8;              // accumulator registers per lane
-    constexpr int QW = Q / NW;             // ... reduced and stored by each wave
-    static_assert(Q % NW == 0, "accumulators must split evenly over the waves");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
+    const int K = p.K, N = p.N, MG = p.MG, epi = p.epi;
     int ntile, mg;
     {
         const int b = blockIdx.x;
-        if (xcd_map) {   // the MG workgroups that share a weight tile run on one XCD (block b -> XCD b % 8): W comes from ITS L2
+        if (p.xcd_map) {   // the MG workgroups that share a weight tile run on one XCD (block b -> XCD b % 8): W comes from ITS L2
             const int j = b >> 3;
             ntile = (j / MG) * 8 + (b & 7);
             mg = j % MG;
@@ -104,24 +149,14 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
         }
     }
     const int n0 = ntile * 32, m0 = mg * (16 * MT);
-    const int KW = K / NW, kbeg = w * KW;
+    const int KW = K / NW, kbeg = w * KW, KG = K >> 4;
     const int G = GT > 0 ? GT : (KW >> 4);
     const float* Ap[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)(m0 + 16 * t + r) * lda + kbeg + 4 * g;
+    for (int t = 0; t < MT; ++t) Ap[t] = p.A + ((size_t)((m0 >> 4) + t) * KG + (kbeg >> 4)) * 256 + lane * 4;
     const float* Wp[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) Wp[u] = W + (size_t)(n0 + 16 * u + r) * K + kbeg + 4 * g;
-#ifdef VLSA_TT_DEBUG
-    if (epi & 512) {    // experiment: every workgroup reads weight tile 0 (stays in L2) instead of its own
-#pragma unroll
-        for (int u = 0; u < 2; ++u) Wp[u] = W + (size_t)(16 * u + r) * K + kbeg + 4 * g;
-    }
-    if (epi & 1024) {   // experiment: every workgroup reads A rows 0..15
-#pragma unroll
-        for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)r * lda + kbeg + 4 * g;
-    }
-#endif
+    for (int u = 0; u < 2; ++u) Wp[u] = p.W + ((size_t)((n0 >> 4) + u) * KG + (kbeg >> 4)) * 256 + lane * 4;
 
     f32x4 acc[MT][2];
 #pragma unroll
@@ -129,39 +164,37 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    constexpr int PF = MT == 1 ? 8 : 6;    // weight (and, without LayerNorm, activation) register ring: groups in flight
     if constexpr (PRO == PRO_LN) {
-        // ---- LayerNorm fused into the operand load: this wave's [16 MT rows] x [KW columns] slab of A in registers --------
-        // the LayerNorm affine parameters go through LDS (first loads issued, so they are the first to land; reading them back
-        // later is an LDS access and does not queue behind the weight stream the way a global load would: vmcnt is in-order)
-        float* sgam = red + 1024;           // [K] gamma | [K] beta   (K <= 768: 6 KB of the 24 KB reduction buffer)
+        // ---- LayerNorm fused into the operand load: this wave's [16 MT rows] x [KW columns] slab of A in registers ------
+        // the affine parameters go through LDS (first loads issued; reading them back later is an LDS access that does not
+        // queue behind the weight stream the way a global load would: vmcnt is in-order)
+        float* sgam = red + 1024;           // [K] gamma | [K] beta   (K <= 768: 6 KB of the reduction buffer)
         f32x4 gld = {0.f, 0.f, 0.f, 0.f}, bld = {0.f, 0.f, 0.f, 0.f};
         if (tid * 4 < K) {
-            gld = *reinterpret_cast<const f32x4*>(ln_w + tid * 4);
-            bld = *reinterpret_cast<const f32x4*>(ln_b + tid * 4);
+            gld = *reinterpret_cast<const f32x4*>(p.ln_w + tid * 4);
+            bld = *reinterpret_cast<const f32x4*>(p.ln_b + tid * 4);
         }
         f32x4 slab[MT][kSlabMax];
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) slab[t][jj] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * jj);
+                for (int t = 0; t < MT; ++t) slab[t][jj] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * jj);
             }
-        // ... and ALL of this wave's weight groups behind them: the kernel is a latency chain (few waves per CU, every weight
-        // read once from HBM), so everything the wave will ever need is put in flight before the first dependent use; the
-        // LayerNorm statistics below overlap the weight fetch
-        f32x4 wall[kSlabMax][2];
+        f32x4 rb[PF][2];
 #pragma unroll
-        for (int jj = 0; jj < kSlabMax; ++jj)
-            if (jj < G) {
+        for (int sI = 0; sI < PF; ++sI)
+            if (sI < G) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) wall[jj][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * jj);
+                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
             }
-        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the weight loads next to their MFMAs)
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the prefetch next to its uses)
         if (tid * 4 < K) {
             *reinterpret_cast<f32x4*>(sgam + tid * 4) = gld;
             *reinterpret_cast<f32x4*>(sgam + K + tid * 4) = bld;
         }
-        float* st = red;                    // [NW][16 MT] partial row statistics (the reduction buffer is free until the end)
+        float* st = red;                    // [NW][16 MT] partial row statistics
         float mean[MT], rstd[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -204,8 +237,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
             for (int ww = 0; ww < NW; ++ww) s += st[ww * (16 * MT) + 16 * t + r];
             rstd[t] = 1.f / sqrtf(s / (float)K + kLnEps);
         }
-        __syncthreads();                    // st is handed back to the final reduction
-        // normalise the slab in place (affine parameters from LDS); the MFMA loop below then runs on registers only
+        // normalise the slab in place (affine parameters from LDS); the MFMA loop below then runs on registers + the ring
         const float* gw = sgam + kbeg + 4 * g;
         const float* gb = sgam + K + kbeg + 4 * g;
 #pragma unroll
@@ -222,25 +254,35 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
+                const int sI = jj % PF;
+                f32x4 b[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[u] = rb[sI][u];
+                if (jj + PF < G) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(slab[t][jj][i], wall[jj][u][i], acc[t][u], 0, 0, 0);
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(slab[t][jj][i], b[u][i], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        __syncthreads();                    // every wave is done with gamma / beta in the buffer the reduction reuses
     } else {
         // register ring PF groups deep: the loads of group jj + PF are issued when group jj is consumed (vmcnt returns in order)
-        constexpr int PF = MT == 1 ? 8 : 6;
         f32x4 ra[PF][MT], rb[PF][2];
 #pragma unroll
         for (int sI = 0; sI < PF; ++sI)
             if (sI < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * sI);
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * sI);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * sI);
+                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
             }
         // keep the machine scheduler from sinking the prefetch loads next to their uses (it minimises register pressure and
         // would leave ~2 groups in flight): nothing moves across these fences
@@ -253,27 +295,17 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
             for (int u = 0; u < 2; ++u) b[u] = rb[sI][u];
             if (jj + PF < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + PF));
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * (jj + PF));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 16 * (jj + PF));
+                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef VLSA_TT_DEBUG
-            if (epi & 256) {   // experiment: no MFMAs, keep the loads alive with one add per loaded vector
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t][0] += a[t];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[0][u] += b[u];
-            } else
-#endif
-            {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], b[u][i], acc[t][u], 0, 0, 0);
-            }
             __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (GT > 0) {
@@ -288,8 +320,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
         }
     }
 
-    // ---- reduce the NW K-slices through LDS (fixed order), then bias / GELU / residual and store -------------------------
-    if constexpr (PRO == PRO_LN) __syncthreads();   // every wave is done reading gamma / beta from the buffer reused below
+    // ---- reduce the NW K-slices through LDS (fixed order), then bias / activation / residual and store ------------------
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -297,115 +328,21 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nt(const float* __restrict_
 #pragma unroll
             for (int v = 0; v < 4; ++v) red[(w * Q + (t * 2 + u) * 4 + v) * 64 + lane] = acc[t][u][v];
     __syncthreads();
-#pragma unroll
-    for (int qi = 0; qi < QW; ++qi) {
-        const int q = w * QW + qi;
+    for (int q = w; q < Q; q += NW) {       // accumulator register q of every lane: summed and stored by wave q % NW
         float val = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) val += red[(ww * Q + q) * 64 + lane];
         const int t = q >> 3, u = (q >> 2) & 1, v = q & 3;
         const int row = m0 + 16 * t + 4 * g + v, col = n0 + 16 * u + r;
-        if (epi & EPI_BIAS) val += bias[col];
+        if (epi & EPI_BIAS) val += p.bias[col];
         if (epi & EPI_GELU) {
-            if (Ypre) Ypre[(size_t)row * ldy + col] = val;
+            if (p.Ypre) p.Ypre[(size_t)row * p.ldy + col] = val;
             val = gelu(val);
         }
-        if (epi & EPI_RESID) val += resid[(size_t)row * ldr + col];
-        Y[(size_t)row * ldy + col] = val;
-    }
-}
-
-// Y[m, n] = sum_k A[m, k] W[k, n]  (W row-major [Kc, ldw]); optional epilogue Y *= gelu'(H[m, n]).
-// A workgroup owns 16 MT rows x 64 columns: lane (c = l & 15, g) loads W[k][n0 + 4 c .. + 3] with one 16-byte load and feeds
-// the four values to four column tiles (tile u holds column n0 + 4 c + u), k = 16 jj + 4 g + s for MFMA step s.
-enum { EPN_GELU_BWD = 1 };
-template <int MT, int NW, int GT>
-__global__ __launch_bounds__(NW * 64) void k_tt_gemm_nn(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
-                                                        float* __restrict__ Y, int ldy, int Kc, int MG, int epi,
-                                                        const float* __restrict__ H, int ldh) {
-    extern __shared__ __attribute__((aligned(16))) float red[];
-    constexpr int Q = MT * 16;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    const int ctile = blockIdx.x / MG, mg = blockIdx.x % MG;
-    const int n0 = ctile * 64, m0 = mg * (16 * MT);
-    const int KW = Kc / NW, kbeg = w * KW;
-    const int G = GT > 0 ? GT : (KW >> 4);
-    const float* Ap[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) Ap[t] = A + (size_t)(m0 + 16 * t + c) * lda + kbeg + 4 * g;
-    const float* Wp = W + (size_t)(kbeg + 4 * g) * ldw + n0 + 4 * c;
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int PF = MT == 1 ? 6 : 4;     // register ring, as in k_tt_gemm_nt
-    f32x4 ra[PF][MT], rb[PF][4];
-#pragma unroll
-    for (int sI = 0; sI < PF; ++sI)
-        if (sI < G) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * sI);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) rb[sI][s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)(16 * sI + s) * ldw);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    auto stage = [&](int sI, int jj) __attribute__((always_inline)) {
-        f32x4 a[MT], b[4];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = ra[sI][t];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[s] = rb[sI][s];
-        if (jj + PF < G) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 16 * (jj + PF));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) rb[sI][s] = *reinterpret_cast<const f32x4*>(Wp + (size_t)(16 * (jj + PF) + s) * ldw);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b[s][u], acc[t][u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (GT > 0) {
-#pragma unroll
-        for (int jj = 0; jj < GT; ++jj) stage(jj % PF, jj);
-    } else {
-        for (int j0 = 0; j0 < G; j0 += PF) {
-#pragma unroll
-            for (int sI = 0; sI < PF; ++sI)
-                if (j0 + sI < G) stage(sI, j0 + sI);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) red[(w * Q + (t * 4 + v) * 4 + u) * 64 + lane] = acc[t][u][v];
-    __syncthreads();
-    // output piece (t, v) of lane (c, g): row m0 + 16 t + 4 g + v, the four columns n0 + 4 c .. + 3 (u = 0..3): one 16-byte store
-    for (int pc = w; pc < MT * 4; pc += NW) {
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) val[u] += red[(ww * Q + pc * 4 + u) * 64 + lane];
-        const int t = pc >> 2, v = pc & 3;
-        const int row = m0 + 16 * t + 4 * g + v, col = n0 + 4 * c;
-        if (epi & EPN_GELU_BWD) {
-            const f32x4 h = *reinterpret_cast<const f32x4*>(H + (size_t)row * ldh + col);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) val[u] *= gelu_grad(h[u]);
-        }
-        *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + col) = val;
+        if (epi & EPI_GELU_BWD) val *= gelu_grad(p.H[(size_t)row * p.ldh + col]);
+        if (epi & EPI_RESID) val += p.resid[(size_t)row * p.ldr + col];
+        if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
+        if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
 }
 
@@ -413,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm_nn(const float* __restrict_
 // attention of one (prompt, head) over the prompt's compact rows.  Token row i sees rows j <= i (causal); the CLS row (last)
 // sees the rows flagged in cls_keep (model/prompt_encoder.py:245-252,299-303).
 constexpr int kAttnMaxS = 128;
-__global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out, int ldo,
+__global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out_t,
                                                     const int* __restrict__ seq_row0, const unsigned char* __restrict__ cls_keep,
                                                     int heads, int d) {
     __shared__ float Ks[kAttnMaxS][kHeadDim + 1];
@@ -458,7 +395,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
             o = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0]), __builtin_amdgcn_readfirstlane(j))), Vs[j][lane], o);
         for (int j = 64; j < S; ++j)
             o = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[1]), __builtin_amdgcn_readfirstlane(j - 64))), Vs[j][lane], o);
-        out[(size_t)(r0 + i) * ldo + h * kHeadDim + lane] = o;
+        out_t[tiled_index(r0 + i, h * kHeadDim + lane, d)] = o;    // tiled [M_pad, d]: the A operand of the out_proj product
     }
 }
 
@@ -514,10 +451,10 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
             dk = fmaf(Dm[j * LD + rr], Qs[j * LD + lane], dk);
             dv = fmaf(Pm[j * LD + rr], Os[j * LD + lane], dv);
         }
-        const size_t base = (size_t)(r0 + rr) * ld + h * kHeadDim + lane;
-        dqkv[base] = dq;
-        dqkv[base + d] = dk;
-        dqkv[base + 2 * d] = dv;
+        const int col = h * kHeadDim + lane;       // tiled [M_pad, 3 d]: the A operand of the in_proj^T product
+        dqkv[tiled_index(r0 + rr, col, 3 * d)] = dq;
+        dqkv[tiled_index(r0 + rr, col + d, 3 * d)] = dk;
+        dqkv[tiled_index(r0 + rr, col + 2 * d, 3 * d)] = dv;
     }
 }
 
@@ -543,7 +480,7 @@ __device__ __forceinline__ void ln_stats(const float (&v)[kLnSlots], int nslot, 
 // dx[row] = dres[row] + LayerNorm'(x[row]; gamma)^T da[row]   (dres nullable)
 __global__ __launch_bounds__(256) void k_tt_ln_bwd(const float* __restrict__ da, const float* __restrict__ x,
                                                   const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                  float* __restrict__ dx, int d, int rows) {
+                                                  float* __restrict__ dx, float* __restrict__ dxt, int d, int rows) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int nslot = d >> 6;
@@ -569,10 +506,14 @@ __global__ __launch_bounds__(256) void k_tt_ln_bwd(const float* __restrict__ da,
     sgx = wave_sum(sgx) / (float)d;
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) dx[(size_t)row * d + lane + 64 * k] = rv[k] + rstd * (gv[k] - sg - xv[k] * sgx);
+        if (k < nslot) {
+            const float o = rv[k] + rstd * (gv[k] - sg - xv[k] * sgx);
+            dx[(size_t)row * d + lane + 64 * k] = o;
+            dxt[tiled_index(row, lane + 64 * k, d)] = o;
+        }
 }
 
-// pooled[s] = ln_final(x[CLS row of prompt s]); rows n_seq .. n_pad-1 of pooled are zeroed (GEMM padding).
+// pooled (TILED [n_pad, d]) [s] = ln_final(x[CLS row of prompt s]); rows n_seq .. n_pad-1 are zeroed (GEMM padding).
 __global__ __launch_bounds__(256) void k_tt_lnf_fwd(const float* __restrict__ x, const int* __restrict__ seq_row0,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float* __restrict__ pooled, int d, int n_seq, int n_pad) {
@@ -580,7 +521,7 @@ __global__ __launch_bounds__(256) void k_tt_lnf_fwd(const float* __restrict__ x,
     if (s >= n_pad) return;
     const int nslot = d >> 6;
     if (s >= n_seq) {
-        for (int k = 0; k < nslot; ++k) pooled[(size_t)s * d + lane + 64 * k] = 0.f;
+        for (int k = 0; k < nslot; ++k) pooled[tiled_index(s, lane + 64 * k, d)] = 0.f;
         return;
     }
     const int row = seq_row0[s + 1] - 1;
@@ -592,18 +533,22 @@ __global__ __launch_bounds__(256) void k_tt_lnf_fwd(const float* __restrict__ x,
     ln_stats(xv, nslot, d, mean, rstd);
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) pooled[(size_t)s * d + lane + 64 * k] = fmaf((xv[k] - mean) * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
+        if (k < nslot) pooled[tiled_index(s, lane + 64 * k, d)] = fmaf((xv[k] - mean) * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
 }
 
 // dx[row] = ln_final backward of dpooled[s] on the CLS row of prompt s, zero on every other row.
 __global__ __launch_bounds__(256) void k_tt_lnf_bwd(const float* __restrict__ dpooled, const float* __restrict__ x,
                                                    const int* __restrict__ row_seq, const int* __restrict__ row_src,
-                                                   const float* __restrict__ gamma, float* __restrict__ dx, int d, int M, int M_pad) {
+                                                   const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dxt,
+                                                   int d, int M, int M_pad) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M_pad) return;
     const int nslot = d >> 6;
     if (row >= M || row_src[row] >= 0) {
-        for (int k = 0; k < nslot; ++k) dx[(size_t)row * d + lane + 64 * k] = 0.f;
+        for (int k = 0; k < nslot; ++k) {
+            dx[(size_t)row * d + lane + 64 * k] = 0.f;
+            dxt[tiled_index(row, lane + 64 * k, d)] = 0.f;
+        }
         return;
     }
     const int s = row_seq[row];
@@ -628,7 +573,11 @@ __global__ __launch_bounds__(256) void k_tt_lnf_bwd(const float* __restrict__ dp
     sgx = wave_sum(sgx) / (float)d;
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) dx[(size_t)row * d + lane + 64 * k] = rstd * (gv[k] - sg - xv[k] * sgx);
+        if (k < nslot) {
+            const float o = rstd * (gv[k] - sg - xv[k] * sgx);
+            dx[(size_t)row * d + lane + 64 * k] = o;
+            dxt[tiled_index(row, lane + 64 * k, d)] = o;
+        }
 }
 
 // d prompts_embedding[seq, src] = dx[row] for the token rows (the CLS rows' gradient belongs to the frozen cls_emb).
@@ -652,74 +601,103 @@ using namespace vlsa::tt;
 namespace {
 
 struct Shape {
-    int d, heads, layers, out_dim, M_pad, M, n_seq, ns_pad, MG3, MG1;
+    int d, heads, layers, out_dim, M_pad, M, n_seq, ns_pad;
 };
 
 bool shape_of(const vlsa_tt_model* m, const vlsa_tt_rows* r, Shape& s) {
-    if (!m || !r || !m->layer) return false;
+    if (!m || !m->layer) return false;
     s.d = m->width;
     s.heads = m->heads;
     s.layers = m->layers;
     s.out_dim = m->out_dim;
+    // width: multiple of 128 (the K splits of every product are whole 16-column groups), <= 768 (fused-LayerNorm slab), 64 per head
+    if (s.d < 128 || s.d > 768 || (s.d % 128) || s.heads * kHeadDim != s.d) return false;
+    if (s.layers < 1 || s.out_dim < 64 || (s.out_dim % 64) || s.out_dim > 1024) return false;
+    if (!m->pos_emb || !m->cls_emb || !m->lnf_w || !m->lnf_b || !m->text_proj) return false;
+    if (!r) return true;
     s.M = r->M;
     s.M_pad = r->M_pad;
     s.n_seq = r->n_seq;
     s.ns_pad = (r->n_seq + 47) / 48 * 48;
-    s.MG3 = r->M_pad / 48;
-    s.MG1 = r->M_pad / 16;
-    // width: multiple of 128 (the K splits of every product are whole 16-column groups), <= 768 (fused-LayerNorm slab), 64 per head
-    if (s.d < 128 || s.d > 768 || (s.d % 128) || s.heads * kHeadDim != s.d) return false;
-    if (s.layers < 1 || s.out_dim < 64 || (s.out_dim % 64) || s.out_dim > 1024) return false;
     if (s.M < 1 || s.M_pad < s.M || (s.M_pad % 48) || s.n_seq < 1 || r->max_len < 2 || r->max_len > kAttnMaxS) return false;
     if (!r->row_seq || !r->row_pos || !r->row_src || !r->seq_row0 || !r->cls_keep) return false;
-    if (!m->pos_emb || !m->cls_emb || !m->lnf_w || !m->lnf_b || !m->text_proj) return false;
     return true;
 }
 
-// per-layer region of the workspace (floats): x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]
+// ---- packed (tiled) weights: [forward set | backward set]; a set = per layer {in_proj, out_proj, c_fc, c_proj} + projection --
+inline size_t set_floats(const Shape& s) { return (size_t)s.layers * 12 * s.d * s.d + (size_t)s.d * s.out_dim; }
+struct PackedLayer {
+    const float *in_w, *out_w, *fc_w, *proj_w;
+};
+inline PackedLayer packed_layer(const float* set, const Shape& s, int L) {
+    const size_t dd = (size_t)s.d * s.d;
+    const float* b = set + (size_t)L * 12 * dd;
+    return PackedLayer{b, b + 3 * dd, b + 4 * dd, b + 8 * dd};
+}
+inline const float* packed_proj(const float* set, const Shape& s) { return set + (size_t)s.layers * 12 * s.d * s.d; }
+
+// ---- workspace (floats).  Per-layer region (kept for backward when save != 0, else one region reused):
+//      x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]     (all row-major)
 inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 9; }
-// shared scratch behind the layer regions: x_final | attn [M_pad, d] | h_act [M_pad, 4d] | pooled [ns_pad, d] |
-// backward: dxa, dxb [M_pad, d] | dbig [M_pad, 4d] | dpool [ns_pad, d] | dout_pad [ns_pad, out_dim]
+struct Scratch {   // behind the layer regions; *_t = tiled
+    float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
+    float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *dattn, *dqkv_t;                    // backward
+};
 inline size_t scratch_floats(const Shape& s) {
-    return (size_t)s.M_pad * s.d * (1 + 1 + 4 + 2 + 4) + (size_t)s.ns_pad * s.d * 2 + (size_t)s.ns_pad * s.out_dim;
+    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim);
+}
+inline Scratch scratch_of(float* p, const Shape& s) {
+    const size_t md = (size_t)s.M_pad * s.d;
+    Scratch c;
+    c.x_final = p; p += md;
+    c.xin_t = p; p += md;
+    c.xmid_t = p; p += md;
+    c.attn_t = p; p += md;
+    c.hact_t = p; p += 4 * md;
+    c.dxa = p; p += md;
+    c.dxa_t = p; p += md;
+    c.dxb = p; p += md;
+    c.dxb_t = p; p += md;
+    c.dh_t = p; p += 4 * md;
+    c.da = p; p += md;
+    c.dattn = p; p += md;
+    c.dqkv_t = p; p += 3 * md;
+    c.pooled_t = p; p += (size_t)s.ns_pad * s.d;
+    c.dpool = p; p += (size_t)s.ns_pad * s.d;
+    c.feat = p; p += (size_t)s.ns_pad * s.out_dim;
+    c.dout_t = p;
+    return c;
 }
 
 template <int MT, int NW, int PRO, int GT>
-int launch_nt_g(const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
-                float* Ypre, int N, int K, int M_pad, int epi, const float* ln_w, const float* ln_b, hipStream_t st) {
-    const int MG = M_pad / (16 * MT), NT = N / 32;
-    const size_t lds = (size_t)NW * MT * 8 * 64 * sizeof(float);
-    hipLaunchKernelGGL((k_tt_gemm_nt<MT, NW, PRO, GT>), dim3(NT * MG), dim3(NW * 64), lds, st, A, lda, W, bias, resid, ldr, Y, ldy,
-                       Ypre, N, K, MG, (NT % 8 == 0) ? 1 : 0, epi, ln_w, ln_b);
+int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
+    a.MG = M_pad / (16 * MT);
+    const int NT = a.N / 32;
+    a.xcd_map = (NT % 8 == 0) ? 1 : 0;
+    size_t lds = (size_t)NW * MT * 8 * 64 * sizeof(float);
+    if (PRO == PRO_LN && lds < (size_t)(1024 + 2 * a.K) * sizeof(float)) lds = (size_t)(1024 + 2 * a.K) * sizeof(float);
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm<MT, NW, PRO, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    hipLaunchKernelGGL((k_tt_gemm<MT, NW, PRO, GT>), dim3(NT * a.MG), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 // G1, G2: the group counts of the CONCH-size tower for this product (compile-time specialisations); anything else: runtime G
 template <int MT, int NW, int PRO, int G1, int G2 = G1>
-int launch_nt(const float* A, int lda, const float* W, const float* bias, const float* resid, int ldr, float* Y, int ldy,
-              float* Ypre, int N, int K, int M_pad, int epi, const float* ln_w, const float* ln_b, hipStream_t st) {
-    const int G = K / NW / 16;
-    if (G == G1) return launch_nt_g<MT, NW, PRO, G1>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
-    if (G == G2) return launch_nt_g<MT, NW, PRO, G2>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
-    return launch_nt_g<MT, NW, PRO, 0>(A, lda, W, bias, resid, ldr, Y, ldy, Ypre, N, K, M_pad, epi, ln_w, ln_b, st);
+int launch_gemm(const GemmArgs& a, int M_pad, hipStream_t st) {
+    const int G = a.K / NW / 16;
+    if (G == G1) return launch_gemm_g<MT, NW, PRO, G1>(a, M_pad, st);
+    if (G == G2) return launch_gemm_g<MT, NW, PRO, G2>(a, M_pad, st);
+    return launch_gemm_g<MT, NW, PRO, 0>(a, M_pad, st);
 }
-
-template <int MT, int NW, int GT>
-int launch_nn_g(const float* A, int lda, const float* W, int ldw, float* Y, int ldy, int Kc, int Nout, int M_pad, int epi,
-                const float* H, int ldh, hipStream_t st) {
-    const int MG = M_pad / (16 * MT);
-    const size_t lds = (size_t)NW * MT * 16 * 64 * sizeof(float);
-    static DeviceOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm_nn<MT, NW, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tt_gemm_nn<MT, NW, GT>), dim3((Nout / 64) * MG), dim3(NW * 64), lds, st, A, lda, W, ldw, Y, ldy, Kc, MG, epi, H, ldh);
-    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
-}
-template <int MT, int NW, int G1, int G2 = G1>
-int launch_nn(const float* A, int lda, const float* W, int ldw, float* Y, int ldy, int Kc, int Nout, int M_pad, int epi,
-              const float* H, int ldh, hipStream_t st) {
-    const int G = Kc / NW / 16;
-    if (G == G1) return launch_nn_g<MT, NW, G1>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
-    if (G == G2) return launch_nn_g<MT, NW, G2>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
-    return launch_nn_g<MT, NW, 0>(A, lda, W, ldw, Y, ldy, Kc, Nout, M_pad, epi, H, ldh, st);
+inline GemmArgs gemm_args(const float* A, const float* W, int N, int K) {
+    GemmArgs a{};
+    a.A = A;
+    a.W = W;
+    a.N = N;
+    a.K = K;
+    return a;
 }
 
 #define TT_TRY(expr)                  \
@@ -727,133 +705,191 @@ int launch_nn(const float* A, int lda, const float* W, int ldw, float* Y, int ld
         const int rc_ = (expr);       \
         if (rc_ != VLSA_OK) return rc_; \
     } while (0)
+#define TT_LAUNCHED()                                              \
+    do {                                                           \
+        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;  \
+    } while (0)
+
+int pack_one(const float* W, int rows, int cols, int transpose, float* out, hipStream_t st) {
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(k_tt_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, rows, cols, transpose, out);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
 
 }  // namespace
 
+extern "C" size_t vlsa_tt_packed_bytes(const vlsa_tt_model* m, int with_backward) {
+    Shape s;
+    if (!shape_of(m, nullptr, s)) return 0;
+    return set_floats(s) * (with_backward ? 2 : 1) * sizeof(float);
+}
+
+extern "C" int vlsa_tt_pack_weights(const vlsa_tt_model* m, void* packed, int with_backward, void* stream) {
+    Shape s;
+    if (!shape_of(m, nullptr, s) || !packed) return VLSA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int d = s.d;
+    const size_t dd = (size_t)d * d;
+    float* fwd = static_cast<float*>(packed);
+    float* bwd = fwd + set_floats(s);
+    for (int L = 0; L < s.layers; ++L) {
+        const vlsa_tt_layer& w = m->layer[L];
+        if (!w.in_w || !w.out_w || !w.fc_w || !w.proj_w) return VLSA_EINVAL;
+        float* f = fwd + (size_t)L * 12 * dd;
+        // forward: Y = A W^T with W [N, K] as stored -> tiled [N, K]
+        TT_TRY(pack_one(w.in_w, 3 * d, d, 0, f, st));
+        TT_TRY(pack_one(w.out_w, d, d, 0, f + 3 * dd, st));
+        TT_TRY(pack_one(w.fc_w, 4 * d, d, 0, f + 4 * dd, st));
+        TT_TRY(pack_one(w.proj_w, d, 4 * d, 0, f + 8 * dd, st));
+        if (with_backward) {   // input gradients: dA = dY W = dY (W^T)^T -> the same product with the tiled TRANSPOSE [K, N]
+            float* b = bwd + (size_t)L * 12 * dd;
+            TT_TRY(pack_one(w.in_w, 3 * d, d, 1, b, st));
+            TT_TRY(pack_one(w.out_w, d, d, 1, b + 3 * dd, st));
+            TT_TRY(pack_one(w.fc_w, 4 * d, d, 1, b + 4 * dd, st));
+            TT_TRY(pack_one(w.proj_w, d, 4 * d, 1, b + 8 * dd, st));
+        }
+    }
+    // text_projection [d, out_dim]: forward pooled @ P = pooled (P^T)^T -> tiled P^T [out_dim, d]; backward dout @ P^T -> tiled P [d, out_dim]
+    TT_TRY(pack_one(m->text_proj, d, s.out_dim, 1, fwd + (size_t)s.layers * 12 * dd, st));
+    if (with_backward) TT_TRY(pack_one(m->text_proj, d, s.out_dim, 0, bwd + (size_t)s.layers * 12 * dd, st));
+    return VLSA_OK;
+}
+
 extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_rows* r, int save_for_backward) {
     Shape s;
-    if (!shape_of(m, r, s)) return 0;
+    if (!r || !shape_of(m, r, s)) return 0;
     const size_t regions = save_for_backward ? (size_t)s.layers : 1;
     return (regions * layer_floats(s) + scratch_floats(s)) * sizeof(float);
 }
 
-#ifdef VLSA_TT_DEBUG
-#include <cstdlib>
-static int tt_debug_bits() {
-    const char* e = getenv("VLSA_TT_DEBUG_BITS");
-    return e ? atoi(e) : 0;
-}
-#define TT_DBG tt_debug_bits()
-#else
-#define TT_DBG 0
-#endif
-
-extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const float* emb, int64_t emb_seq_stride,
-                               int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out, void* stream) {
+extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* emb,
+                               int64_t emb_seq_stride, int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out,
+                               void* stream) {
     Shape s;
-    if (!shape_of(m, r, s)) return VLSA_EINVAL;
-    if (!emb || !workspace || !out) return VLSA_EINVAL;
+    if (!r || !shape_of(m, r, s)) return VLSA_EINVAL;
+    if (!packed || !emb || !workspace || !out) return VLSA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int d = s.d, Mp = s.M_pad;
     float* ws = static_cast<float*>(workspace);
     const size_t LF = layer_floats(s);
     const size_t nreg = save_for_backward ? (size_t)s.layers : 1;
-    float* scratch = ws + nreg * LF;
-    float* x_final = scratch;
-    float* attn = x_final + (size_t)Mp * d;
-    float* h_act = attn + (size_t)Mp * d;
-    float* pooled = h_act + (size_t)Mp * 4 * d;
-
+    const Scratch c = scratch_of(ws + nreg * LF, s);
+    const float* wset = static_cast<const float*>(packed);
     auto region = [&](int layer) { return ws + (save_for_backward ? (size_t)layer : 0) * LF; };
-    hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
+
+    hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), c.xin_t, d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
                        r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
-    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    TT_LAUNCHED();
     for (int L = 0; L < s.layers; ++L) {
         const vlsa_tt_layer& w = m->layer[L];
+        const PackedLayer pw = packed_layer(wset, s, L);
         float* x_in = region(L);
         float* qkv = x_in + (size_t)Mp * d;
         float* x_mid = qkv + (size_t)Mp * 3 * d;
         float* h_pre = x_mid + (size_t)Mp * d;
-        float* x_next = (L + 1 < s.layers) ? (save_for_backward ? region(L + 1) : x_in) : x_final;
+        float* x_next = (L + 1 < s.layers) ? (save_for_backward ? region(L + 1) : x_in) : c.x_final;
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
-        TT_TRY((launch_nt<3, 4, PRO_LN, 12>(x_in, d, w.in_w, w.in_b, nullptr, 0, qkv, 3 * d, nullptr, 3 * d, d, Mp, EPI_BIAS, w.ln1_w, w.ln1_b, st)));
-        hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, attn, d, r->seq_row0, r->cls_keep,
+        {
+            GemmArgs a = gemm_args(c.xin_t, pw.in_w, 3 * d, d);
+            a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
+            TT_TRY((launch_gemm<3, 4, PRO_LN, 12>(a, Mp, st)));
+        }
+        hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0, r->cls_keep,
                            s.heads, d);
-        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-        TT_TRY((launch_nt<3, 8, PRO_NONE, 6>(attn, d, w.out_w, w.out_b, x_in, d, x_mid, d, nullptr, d, d, Mp, EPI_BIAS | EPI_RESID, nullptr, nullptr, st)));
-        TT_TRY((launch_nt<3, 4, PRO_LN, 12>(x_mid, d, w.fc_w, w.fc_b, nullptr, 0, h_act, 4 * d, save_for_backward ? h_pre : nullptr, 4 * d, d, Mp,
-                                        EPI_BIAS | EPI_GELU, w.ln2_w, w.ln2_b, st)));
-        TT_TRY((launch_nt<1, 8, PRO_NONE, 24>(h_act, 4 * d, w.proj_w, w.proj_b, x_mid, d, x_next, d, nullptr, d, 4 * d, Mp, EPI_BIAS | EPI_RESID | TT_DBG, nullptr,
-                                          nullptr, st)));
+        TT_LAUNCHED();
+        {
+            GemmArgs a = gemm_args(c.attn_t, pw.out_w, d, d);
+            a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = c.xmid_t; a.epi = EPI_BIAS | EPI_RESID;
+            TT_TRY((launch_gemm<1, 4, PRO_NONE, 12>(a, Mp, st)));
+        }
+        {
+            GemmArgs a = gemm_args(c.xmid_t, pw.fc_w, 4 * d, d);
+            a.bias = w.fc_b; a.Yt = c.hact_t; a.Ypre = save_for_backward ? h_pre : nullptr; a.ldy = 4 * d; a.epi = EPI_BIAS | EPI_GELU;
+            a.ln_w = w.ln2_w; a.ln_b = w.ln2_b;
+            TT_TRY((launch_gemm<3, 4, PRO_LN, 12>(a, Mp, st)));
+        }
+        {
+            GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
+            a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
+            TT_TRY((launch_gemm<1, 8, PRO_NONE, 24>(a, Mp, st)));
+        }
     }
-    hipLaunchKernelGGL(k_tt_lnf_fwd, dim3((s.ns_pad + 3) / 4), dim3(256), 0, st, x_final, r->seq_row0, m->lnf_w, m->lnf_b, pooled, d,
+    hipLaunchKernelGGL(k_tt_lnf_fwd, dim3((s.ns_pad + 3) / 4), dim3(256), 0, st, c.x_final, r->seq_row0, m->lnf_w, m->lnf_b, c.pooled_t, d,
                        s.n_seq, s.ns_pad);
-    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-    // text features = pooled @ text_projection  ([ns_pad, d] x [d, out_dim]); the padded rows land in scratch, then copy out
-    float* feat = pooled + (size_t)s.ns_pad * d * 2;   // dout_pad slot doubles as the padded output
-    TT_TRY((launch_nn<3, 4, 12>(pooled, d, m->text_proj, s.out_dim, feat, s.out_dim, d, s.out_dim, s.ns_pad, 0, nullptr, 0, st)));
-    if (hipMemcpyAsync(out, feat, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
+    TT_LAUNCHED();
+    {   // text features = pooled @ text_projection
+        GemmArgs a = gemm_args(c.pooled_t, packed_proj(wset, s), s.out_dim, d);
+        a.Y = c.feat; a.ldy = s.out_dim;
+        TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, s.ns_pad, st)));
+    }
+    if (hipMemcpyAsync(out, c.feat, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
     return VLSA_OK;
 }
 
-extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const float* dout, void* workspace, float* demb,
-                                int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream) {
+extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* dout, void* workspace,
+                                float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream) {
     Shape s;
-    if (!shape_of(m, r, s)) return VLSA_EINVAL;
-    if (!dout || !workspace || !demb || demb_floats < 0) return VLSA_EINVAL;
+    if (!r || !shape_of(m, r, s)) return VLSA_EINVAL;
+    if (!packed || !dout || !workspace || !demb || demb_floats < 0) return VLSA_EINVAL;
     if (r->max_len > kAttnBwdMaxS) return VLSA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int d = s.d, Mp = s.M_pad;
     float* ws = static_cast<float*>(workspace);
     const size_t LF = layer_floats(s);
-    float* scratch = ws + (size_t)s.layers * LF;
-    float* x_final = scratch;
-    float* attn = x_final + (size_t)Mp * d;          // reused: d(attention output)
-    float* h_act = attn + (size_t)Mp * d;            // reused: d(h_pre) [M_pad, 4d]
-    float* pooled = h_act + (size_t)Mp * 4 * d;
-    float* dpool = pooled + (size_t)s.ns_pad * d;
-    float* dout_pad = dpool + (size_t)s.ns_pad * d;
-    float* dxa = dout_pad + (size_t)s.ns_pad * s.out_dim;
-    float* dxb = dxa + (size_t)Mp * d;
-    float* dbig = dxb + (size_t)Mp * d;               // [M_pad, 4d]: d(ln output) / dqkv (3d)
-    (void)pooled;
+    const Scratch c = scratch_of(ws + (size_t)s.layers * LF, s);
+    const float* bset = static_cast<const float*>(packed) + set_floats(s);
 
-    if (hipMemsetAsync(dout_pad, 0, (size_t)s.ns_pad * s.out_dim * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
-    if (hipMemcpyAsync(dout_pad, dout, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
-    // d pooled = dout @ text_projection^T: text_projection [d, out_dim] read as W[n = d][k = out_dim]
-    if ((s.out_dim / 4) % 16) return VLSA_EUNSUPPORTED;
-    TT_TRY((launch_nt<3, 4, PRO_NONE, 8>(dout_pad, s.out_dim, m->text_proj, nullptr, nullptr, 0, dpool, d, nullptr, d, s.out_dim, s.ns_pad, 0, nullptr,
-                                      nullptr, st)));
-    hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, dpool, x_final, r->row_seq, r->row_src, m->lnf_w, dxa, d, s.M, Mp);
-    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    hipLaunchKernelGGL(k_tt_tile_rows, dim3(s.ns_pad / 16, s.out_dim / 16), dim3(256), 0, st, dout, s.n_seq, s.out_dim, c.dout_t);
+    TT_LAUNCHED();
+    {   // d pooled = dout @ text_projection^T
+        GemmArgs a = gemm_args(c.dout_t, packed_proj(bset, s), d, s.out_dim);
+        a.Y = c.dpool; a.ldy = d;
+        TT_TRY((launch_gemm<3, 4, PRO_NONE, 8>(a, s.ns_pad, st)));
+    }
+    hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.dpool, c.x_final, r->row_seq, r->row_src, m->lnf_w, c.dxa,
+                       c.dxa_t, d, s.M, Mp);
+    TT_LAUNCHED();
     static DeviceOnce once;
     const size_t attn_lds = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
     if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds);
-    float* dx = dxa;       // gradient w.r.t. the layer's output
-    float* dx2 = dxb;
     for (int L = s.layers - 1; L >= 0; --L) {
         const vlsa_tt_layer& w = m->layer[L];
+        const PackedLayer pw = packed_layer(bset, s, L);
         float* x_in = ws + (size_t)L * LF;
         float* qkv = x_in + (size_t)Mp * d;
         float* x_mid = qkv + (size_t)Mp * 3 * d;
         float* h_pre = x_mid + (size_t)Mp * d;
-        // MLP branch: d h_pre = (dx @ W_proj) * gelu'(h_pre);  d ln_2 out = d h_pre @ W_fc;  dx_mid = dx + ln_2'(.)
-        TT_TRY((launch_nn<3, 8, 6>(dx, d, w.proj_w, 4 * d, h_act, 4 * d, d, 4 * d, Mp, EPN_GELU_BWD, h_pre, 4 * d, st)));
-        TT_TRY((launch_nn<1, 8, 24, 18>(h_act, 4 * d, w.fc_w, d, dbig, d, 4 * d, d, Mp, 0, nullptr, 0, st)));
-        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, dbig, x_mid, w.ln2_w, dx, dx2, d, Mp);
-        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-        // attention branch: d attn = dx_mid @ W_out;  dqkv = attention'(.);  d ln_1 out = dqkv @ W_in;  dx_in = dx_mid + ln_1'(.)
-        TT_TRY((launch_nn<1, 4, 12>(dx2, d, w.out_w, d, attn, d, d, d, Mp, 0, nullptr, 0, st)));
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, attn, d, dbig, r->seq_row0,
+        // (dxa, dxa_t) = gradient w.r.t. the layer's output.  MLP branch:
+        {   // d h_pre = (dx @ W_proj) * gelu'(h_pre)
+            GemmArgs a = gemm_args(c.dxa_t, pw.proj_w, 4 * d, d);
+            a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
+            TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, Mp, st)));
+        }
+        {   // d ln_2 out = d h_pre @ W_fc
+            GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
+            a.Y = c.da; a.ldy = d;
+            TT_TRY((launch_gemm<1, 8, PRO_NONE, 24>(a, Mp, st)));
+        }
+        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp);
+        TT_LAUNCHED();
+        // attention branch
+        {   // d attn = dx_mid @ W_out
+            GemmArgs a = gemm_args(c.dxb_t, pw.out_w, d, d);
+            a.Y = c.dattn; a.ldy = d;
+            TT_TRY((launch_gemm<1, 4, PRO_NONE, 12>(a, Mp, st)));
+        }
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d, c.dqkv_t, r->seq_row0,
                            r->cls_keep, s.heads, d);
-        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
-        // rows M .. M_pad-1 of dqkv are never written by the attention kernel: they hold stale finite numbers that only reach
-        // the (discarded) padding rows of the next products
-        TT_TRY((launch_nn<1, 8, 24, 18>(dbig, 3 * d, w.in_w, d, h_act, d, 3 * d, d, Mp, 0, nullptr, 0, st)));
-        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, h_act, x_in, w.ln1_w, dx2, dx, d, Mp);
-        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+        TT_LAUNCHED();
+        {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
+            GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
+            a.Y = c.da; a.ldy = d;
+            TT_TRY((launch_gemm<1, 8, PRO_NONE, 18>(a, Mp, st)));
+        }
+        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp);
+        TT_LAUNCHED();
     }
     if (hipMemsetAsync(demb, 0, (size_t)demb_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
-    hipLaunchKernelGGL(k_tt_scatter, dim3(s.M), dim3(256), 0, st, dx, d, demb, emb_seq_stride, emb_tok_stride, r->row_seq, r->row_src, s.M);
+    hipLaunchKernelGGL(k_tt_scatter, dim3(s.M), dim3(256), 0, st, c.dxa, d, demb, emb_seq_stride, emb_tok_stride, r->row_seq, r->row_src, s.M);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

@@ -126,10 +126,12 @@ class _TextTowerFn(torch.autograd.Function):
             x = x.float().contiguous()
         out = torch.empty(plan.n_seq, enc.output_dim, dtype=torch.float32, device=emb.device)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1),
-                                      ctypes.c_void_p(ws.data_ptr()), save, ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
+        packed = enc._packed_weights(emb.device, with_backward=bool(save))
+        nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(packed.data_ptr()),
+                                      ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), save,
+                                      ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
         if save:
-            ctx.ws, ctx.plan, ctx.enc, ctx.shape = ws, plan, enc, tuple(emb.shape)
+            ctx.ws, ctx.plan, ctx.enc, ctx.shape, ctx.packed = ws, plan, enc, tuple(emb.shape), packed
         ctx.keep = x
         return out
 
@@ -141,10 +143,11 @@ class _TextTowerFn(torch.autograd.Function):
         g = dout.detach().float().contiguous()
         demb = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        nat.check(lib.vlsa_tt_backward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(g.data_ptr()),
-                                       ctypes.c_void_p(ctx.ws.data_ptr()), ctypes.c_void_p(demb.data_ptr()), demb.stride(0),
-                                       demb.stride(1), demb.numel(), s), "vlsa_tt_backward")
-        ctx.ws = None
+        nat.check(lib.vlsa_tt_backward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(ctx.packed.data_ptr()),
+                                       ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(ctx.ws.data_ptr()),
+                                       ctypes.c_void_p(demb.data_ptr()), demb.stride(0), demb.stride(1), demb.numel(), s),
+                  "vlsa_tt_backward")
+        ctx.ws = ctx.packed = None
         return demb, None, None
 
 
@@ -185,6 +188,7 @@ class CONCHPromptEncoder(nn.Module):
         self.text_config = {"max_num_tokens": self.context_length - 1, "embedding_dim": self.token_embedding.embedding_dim,
                             "embedding_dtype": self.token_embedding.weight.dtype}
         self._cm, self._cm_key, self._plans = None, None, {}
+        self._pk, self._pk_key, self._pk_bwd = None, None, False
 
     def reset_parameters(self):
         """TextTransformer.init_parameters (model/conch/transformer.py:376-392)."""
@@ -230,6 +234,27 @@ class CONCHPromptEncoder(nn.Module):
                             ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), ts[4].data_ptr())
         self._cm_arr, self._cm_key = arr, key
         return self._cm
+
+    def _packed_weights(self, device, with_backward: bool) -> torch.Tensor:
+        """The tiled (MFMA-fragment-major) copies of the tower's matrices the product kernels read, rebuilt when a weight's
+        storage or in-place version changes (load_state_dict, .to(device)); the backward set (transposes) only once a
+        gradient is asked for."""
+        mats = [self.text_projection]
+        for blk in self.transformer.resblocks:
+            mats += [blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight]
+        key = tuple((t.data_ptr(), t._version) for t in mats)
+        if self._pk is not None and self._pk_key == key and (self._pk_bwd or not with_backward):
+            return self._pk
+        lib = nat.load()
+        model = self._c_model(device)
+        nbytes = lib.vlsa_tt_packed_bytes(ctypes.byref(model), int(with_backward))
+        if nbytes == 0:
+            raise VlsaNativeError("text tower: unsupported shape (width % 128, width <= 768, 64 features per head, out_dim % 64)")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        nat.check(lib.vlsa_tt_pack_weights(ctypes.byref(model), ctypes.c_void_p(buf.data_ptr()), int(with_backward),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vlsa_tt_pack_weights")
+        self._pk, self._pk_key, self._pk_bwd = buf, key, bool(with_backward)
+        return buf
 
     def _plan(self, pseudo_tokens, device) -> _RowPlan:
         key = (pseudo_tokens.data_ptr(), pseudo_tokens._version, tuple(pseudo_tokens.shape), str(device))
