@@ -143,6 +143,15 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
                       float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
                       void* stream);
 
+/* vlsa_prepare_queries_and_text + vlsa_vlfan_partial + vlsa_vlfan_merge (+ vlsa_attn_normalise when scores and A are given) +
+ * vlsa_head_forward in ONE host call: the per-bag forward of model/vlsa.py:181-198 as the reference's handler issues it, one
+ * bag at a time (runner/vlsa_handler.py:322-330).  Arguments as in the individual entry points; G = vlsa_num_partials(N). */
+int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* Q, int nq, int gated,
+                           float coattn_scale, const float* T, int K, const float* logit_scale, int pool_mode, const float* pool_w,
+                           const float* W, const float* b, int kernel, void* qprep, float* That, float* tnorm, float* pm, float* pl,
+                           float* pacc, int G, float* m2, float* l, float* out, float* scores, float* A, void* head_ws,
+                           float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
+
 /* ---- batched forward: B bags per launch ------------------------------------------------------------------- */
 
 /* One bag of a batch (device-resident array of these is passed to vlsa_vlfan_forward_batch). */
@@ -293,6 +302,18 @@ int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out_scale, flo
  * zero-shot path uses.  workspace: vlsa_topk_workspace_bytes(C, N, k), no initialisation needed. */
 size_t vlsa_topk_workspace_bytes(int C, int64_t N, int k);
 int vlsa_topk_mean_ws(const float* S, int C, int64_t N, int k, float out_scale, void* workspace, float* out, void* stream);
+
+/* The k (<= 32) largest entries of every row of S [C, N], descending, padded with -inf when N < k: vals [C, k].  The per-rank
+ * piece of the patch-sharded zero-shot pooling (each rank's local winners are all-gathered and re-selected with
+ * vlsa_topk_mean on the [C, G * k] candidates).  workspace: vlsa_topk_workspace_bytes(C, N, k). */
+int vlsa_topk_values(const float* S, int C, int64_t N, int k, void* workspace, float* vals, void* stream);
+
+/* The zero-shot pooling of B bags in one launch: scores_desc[bag] = [C, ld] fp32 class scores (vlsa_rows_desc; e.g. the cosines
+ * vlsa_vlfan_partial_batch_scores stores when the K text features are passed as queries with coattn_scale = 1 / log2(e)),
+ * bag_desc gives N per bag; out [B, C] = exp(*logit_scale) * mean of the min(k, N) largest of each row (k <= 0: plain mean,
+ * k <= 32 otherwise; logit_scale NULL: no scaling).  Replaces logit_pooling per bag (model/deepmil.py:16-37, model/vlsa.py:194-196). */
+int vlsa_topk_mean_batch(const void* bag_desc, const void* scores_desc, int B, int C, int k, const float* logit_scale, float* out,
+                         void* stream);
 
 /* out[n, :] = X[n, :] / max(|X[n, :]|, 1e-12) for ALL N patch rows, fp32 out [N, D] (the image_features the reference's
  * zero-shot forward returns, model/vlsa.py:188-189); bf16 or fp32 rows, 16-byte aligned, D % 8 == 0 (bf16) / % 4 (fp32). */

@@ -11,6 +11,7 @@ TOWERS = {
     "conch": dict(width=768, heads=12, layers=12, vocab=32007, ctx=128, out_dim=512),   # conch_ViT-B-16.json text_cfg
     "small": dict(width=128, heads=2, layers=2, vocab=64, ctx=128, out_dim=64),
     "mid": dict(width=256, heads=4, layers=3, vocab=64, ctx=128, out_dim=128),
+    "train": dict(width=128, heads=2, layers=2, vocab=64, ctx=128, out_dim=512),    # text features in the CONCH space [K, 512]
 }
 
 

@@ -77,3 +77,65 @@ def test_module_forward_bags_ret_with_attn_vs_reference_fixture(name):
         cases.check_big(fx, "grad.Q" if gated else "grad.resid", g, atol=2e-5, rtol=2e-3)
     v, attn3 = model.mil_encoder.forward_bags(bags[:2], ret_with_attn=True)
     assert v.shape[0] == 2 and len(attn3) == 2
+
+
+# ---- the other encoders through forward_bags: same numbers as bag-by-bag forward and as the fixtures ----
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pooling", ["logit_top10", "logit_max", "logit_mean", "logit_top3"])
+def test_forward_bags_zeroshot(pooling, dtype):
+    from vlsa_amd.vlsa import VLSA
+    K = 12
+    T = cases.make_params(1, K, 9900)["T"]
+    model = VLSA(dict(name="FeatMIL", pooling=pooling), pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE).cuda().eval()
+    sizes = [500, 5, 9000, 64, 1, 4097]
+    bags = [cases.make_bag(n, 9910 + i).to(dtype) for i, n in enumerate(sizes)]
+    with torch.no_grad():
+        logits, feats, That = model.forward_bags([x.cuda() for x in bags])
+        assert feats is None
+        model.return_patch_features = True
+        _, feats2, _ = model.forward_bags([x.cuda() for x in bags[:2]])
+    assert logits.shape == (len(sizes), K) and len(feats2) == 2 and feats2[0].shape == (500, 512)
+    for i, x in enumerate(bags):
+        ref = O.vlsa_zeroshot_forward(x.float(), T, torch.tensor(cases.LOGIT_SCALE), pooling)[0]
+        assert (logits[i].cpu() - ref[0]).abs().max().item() < TOL, (i, sizes[i])
+
+
+@pytest.mark.parametrize("name", ["zs_top10", "zs_top10_n5", "zs_top3_k12", "zs_mean", "zs_max"])
+def test_forward_bags_zeroshot_vs_reference_fixture(name):
+    from vlsa_amd.vlsa import VLSA
+    case = [c for c in cases.ZEROSHOT_CASES if c[0] == name][0]
+    (_, N, K, pooling, seed) = case
+    fx = H.load_fixture("zeroshot_" + name)
+    X = cases.make_bag(N, seed)
+    T = cases.make_params(1, K, seed + 1000)["T"]
+    model = VLSA(dict(name="FeatMIL", pooling=pooling), pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE).cuda().eval()
+    with torch.no_grad():
+        logits, _, txt = model.forward_bags([X.cuda(), cases.make_bag(333, seed + 5).cuda(), X[None].cuda()])
+    assert np.abs(logits[0].cpu().numpy() - fx["logits"][0]).max() < TOL
+    assert np.abs(logits[2].cpu().numpy() - fx["logits"][0]).max() < TOL
+    assert np.abs(txt.cpu().numpy() - fx["text_features"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["dm_attn", "dm_gattn", "dm_mean", "dm_max"])
+def test_forward_bags_deepmil_vs_reference_fixture(name):
+    from test_gpu_modules_r2 import _load_pool
+    from vlsa_amd.vlsa import VLSA
+    case = [c for c in cases.DEEPMIL_CASES if c[0] == name][0]
+    (_, N, K, pooling, seed) = case
+    fx = H.load_fixture("deepmil_" + name)
+    X = cases.make_bag(N, seed)
+    T = cases.make_params(1, K, seed + 1000)["T"]
+    cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25, pooling=pooling,
+               pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
+    model = VLSA(cfg, pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE)
+    ad = cases.make_adapter_params(seed + 4000)
+    with torch.no_grad():
+        model.mil_encoder.visual_adapter.fc[0].weight.copy_(ad["down"]); model.mil_encoder.visual_adapter.fc[2].weight.copy_(ad["up"])
+    _load_pool(model.mil_encoder.sigma, cases.make_pool_params(pooling, seed + 3000), pooling)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        logits, feats, _ = model.forward_bags([X.cuda(), cases.make_bag(200, seed + 7).cuda(), X.to(torch.bfloat16).cuda().float()])
+        single = model(X[None].cuda())[0]
+    assert np.abs(logits[0].cpu().numpy() - fx["logits"][0]).max() < TOL
+    assert np.abs(feats[0].cpu().numpy() - fx["image_features"][0]).max() < 1e-5
+    assert (logits[0] - single[0]).abs().max().item() < 2e-5

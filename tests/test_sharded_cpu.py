@@ -69,3 +69,47 @@ def test_two_rank_gloo_exchange_matches_single_process(N):
         err_out, err_A, a, b = ret[r]
         assert err_out < 1e-4 and err_A < 1e-5, (r, err_out, err_A)
     assert ret[0][3] == ret[1][2]
+
+
+# ---- zero-shot top-k and attention pooling over N, patch-sharded: exchange + re-selection logic on CPU (gloo) -------------
+def _worker_other(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vlsa_amd import sharded
+        N, K, k = 1000, 4, 10
+        X = cases.make_bag(N, 21)
+        T = cases.make_params(1, K, 22)["T"]
+        a, b = sharded.shard_bounds(N, world, rank)
+        cos = (O.l2_normalize(X[a:b]) @ O.l2_normalize(T).t()).t().contiguous()          # [K, n_loc]
+        vals = torch.full((K, k), float("-inf"))
+        kk = min(k, cos.shape[1])
+        vals[:, :kk] = cos.topk(kk, dim=1).values                                        # what vlsa_topk_values leaves per rank
+        cand = sharded.merge_topk_candidates(sharded.gather_rows(vals))
+        pooled = cand.topk(k, dim=1).values.mean(dim=1)
+        ref_logits = O.vlsa_zeroshot_forward(X, T, torch.tensor(cases.LOGIT_SCALE), "logit_top10")[0]
+        err_zs = (pooled * torch.tensor(cases.LOGIT_SCALE).exp() - ref_logits[0]).abs().max().item()
+        # attention pooling over N: per-rank online-softmax record, one gather, log-sum-exp merge
+        pp = cases.make_pool_params("gated_attention", 23)
+        full = O.gated_attention_pooling(X, pp["wa"], pp["ba"], pp["wg"], pp["bg"], pp["w2"], pp["b2"])
+        raw = full[1][a:b]
+        m = raw.max()
+        w = torch.exp(raw - m)
+        rec = torch.cat([m.reshape(1), w.sum().reshape(1), w @ X[a:b]])
+        g = sharded.gather_rows(rec)
+        mg = g[:, 0].max()
+        f = torch.exp(g[:, 0] - mg)
+        pooled_attn = (f[:, None] * g[:, 2:]).sum(dim=0) / (f * g[:, 1]).sum()
+        ret[rank] = (err_zs, (pooled_attn - full[0]).abs().max().item())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_zeroshot_topk_and_attention_pool_exchange():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_other, args=(world, 29300 + (os.getpid() % 500), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r][0] < 1e-4 and ret[r][1] < 1e-5, ret[r]

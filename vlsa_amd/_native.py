@@ -52,6 +52,8 @@ _SIGNATURES = {
     "vlsa_head_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    "vlsa_vlfan_forward_bag": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
+                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 13),
     "vlsa_batch_max_bags": (c_int, []),
     "vlsa_batch_partials_per_bag": (c_int, [c_int]),
     "vlsa_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -97,6 +99,8 @@ _SIGNATURES = {
     "vlsa_rowdot": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "vlsa_topk_mean_ws": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "vlsa_topk_values": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_topk_mean_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_normalize_many": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "vlsa_topk_mean": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vlsa_tt_workspace_bytes": (c_size_t, [c_void_p, c_void_p, c_int]),

@@ -366,18 +366,17 @@ __global__ __launch_bounds__(256) void k_rowdot(const XT* __restrict__ X, int64_
 // Each thread keeps the k largest of its strided subset (sorted insertion in registers), the 256 lists are
 // merged by k rounds of workgroup-wide arg-max.  k >= N degenerates to the mean of all N.
 constexpr int kTopKMax = 32;
-__global__ __launch_bounds__(256) void k_topk_mean(const float* __restrict__ S, int64_t N, int k, float scale_log2e_inv,
-                                                    float* __restrict__ out) {
+__device__ __forceinline__ void topk_mean_row(const float* __restrict__ s, int64_t N, int k, float scale_log2e_inv,
+                                              float* __restrict__ out_elem) {
     __shared__ float sval[256];
     __shared__ int sidx[256];
     __shared__ float red[4];
-    const int tid = threadIdx.x, cls = blockIdx.x;
-    const float* s = S + (size_t)cls * N;
+    const int tid = threadIdx.x;
     if ((int64_t)k >= N) {  // mean over everything
         float a = 0.f;
         for (int64_t n = tid; n < N; n += 256) a += s[n];
         a = block_sum_256(a, red);
-        if (tid == 0) out[cls] = a / (float)N * scale_log2e_inv;
+        if (tid == 0) *out_elem = a / (float)N * scale_log2e_inv;
         return;
     }
     float top[kTopKMax];
@@ -417,14 +416,43 @@ __global__ __launch_bounds__(256) void k_topk_mean(const float* __restrict__ S, 
         __syncthreads();
         if (tid == winner) ++head;
     }
-    if (tid == 0) out[cls] = sum / (float)k * scale_log2e_inv;
+    if (tid == 0) *out_elem = sum / (float)k * scale_log2e_inv;
+}
+__global__ __launch_bounds__(256) void k_topk_mean(const float* __restrict__ S, int64_t N, int k, float scale_log2e_inv,
+                                                    float* __restrict__ out) {
+    const int cls = blockIdx.x;
+    topk_mean_row(S + (size_t)cls * N, N, k, scale_log2e_inv, out + cls);
+}
+// B bags per launch: workgroup (class, bag) pools row `class` of bag's score matrix ([C, ld] fp32, e.g. the per-class cosines
+// the batched streaming kernel stored); k is clamped to the bag's N (k >= N: plain mean).  out [B, C] *= exp(*logit_scale).
+struct TopkBagDesc {
+    const void* X;
+    int64_t N;
+    int64_t ldx;
+};
+struct TopkRowsDesc {
+    float* ptr;
+    int64_t ld;
+};
+__global__ __launch_bounds__(256) void k_topk_mean_batch(const TopkBagDesc* __restrict__ bags, const TopkRowsDesc* __restrict__ sdesc,
+                                                          int C, int k, const float* __restrict__ logit_scale,
+                                                          float* __restrict__ out) {
+    const int cls = blockIdx.x, bag = blockIdx.y;
+    const int64_t N = bags[bag].N;
+    const TopkRowsDesc sd = sdesc[bag];
+    if (N <= 0 || sd.ptr == nullptr) {
+        if (threadIdx.x == 0) out[(size_t)bag * C + cls] = 0.f;
+        return;
+    }
+    const float sc = logit_scale ? __expf(*logit_scale) : 1.f;
+    topk_mean_row(sd.ptr + (size_t)cls * sd.ld, N, k, sc, out + (size_t)bag * C + cls);
 }
 
 // Stage 1 of the two-stage top-k for long rows: workgroup (chunk b, class) keeps the k largest of ITS contiguous chunk of
 // the class's scores (same per-thread sorted insertion + k arg-max rounds) and writes them, descending, to
 // part[(cls * G + b) * k ..]; k_topk_mean over the [C, G * k] candidates then finishes.  k >= N: partial sums instead.
 __global__ __launch_bounds__(256) void k_topk_partial(const float* __restrict__ S, int64_t N, int k, int G,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, int select_always = 0) {
     __shared__ float sval[256];
     __shared__ int sidx[256];
     __shared__ float red[4];
@@ -432,7 +460,7 @@ __global__ __launch_bounds__(256) void k_topk_partial(const float* __restrict__ 
     const float* s = S + (size_t)cls * N;
     int64_t n0, n1;
     rows_of_block(N, b, G, n0, n1);
-    if ((int64_t)k >= N) {
+    if ((int64_t)k >= N && !select_always) {   // (select_always: the k winners are wanted even when there are fewer than k candidates: -inf padded)
         float a = 0.f;
         for (int64_t n = n0 + tid; n < n1; n += 256) a += s[n];
         a = block_sum_256(a, red);
@@ -688,6 +716,35 @@ extern "C" int vlsa_topk_mean_ws(const float* S, int C, int64_t N, int k, float 
         hipLaunchKernelGGL(k_mean_final, dim3(C), dim3(64), 0, s, part, G, N, out_scale, out);
     else
         hipLaunchKernelGGL(k_topk_mean, dim3(C), dim3(256), 0, s, part, (int64_t)G * k, k, out_scale, out);
+    return st();
+}
+
+// The k largest entries of every row of S [C, N], descending, -inf padded when N < k: vals [C, k].  The per-rank piece of the
+// patch-sharded zero-shot pooling (all-gather local top-k [G, k, K], re-select).  workspace as vlsa_topk_mean_ws.
+extern "C" int vlsa_topk_values(const float* S, int C, int64_t N, int k, void* workspace, float* vals, void* stream) {
+    if (!S || !vals || !workspace || C < 1 || N < 1 || k < 1) return VLSA_EINVAL;
+    if (k > kTopKMax) return VLSA_EUNSUPPORTED;
+    const int G = vlsa_topk_chunks(N);
+    hipStream_t s = (hipStream_t)stream;
+    float* part = static_cast<float*>(workspace);
+    if (G == 1) {
+        hipLaunchKernelGGL(k_topk_partial, dim3(1, C), dim3(256), 0, s, S, N, k, 1, vals, 1);
+        return st();
+    }
+    hipLaunchKernelGGL(k_topk_partial, dim3(G, C), dim3(256), 0, s, S, N, k, G, part, 1);
+    hipLaunchKernelGGL(k_topk_partial, dim3(1, C), dim3(256), 0, s, part, (int64_t)G * k, k, 1, vals, 1);
+    return st();
+}
+
+// Per-class top-k mean for B bags in one launch (model/deepmil.py:16-37 on the [C, N_i] class scores of every bag):
+// out [B, C] = exp(*logit_scale) * mean of the min(k, N_i) largest entries of each row (k <= 0: mean of all N_i).
+extern "C" int vlsa_topk_mean_batch(const void* bag_desc, const void* scores_desc, int B, int C, int k, const float* logit_scale,
+                                    float* out, void* stream) {
+    if (!bag_desc || !scores_desc || !out || B < 1 || C < 1) return VLSA_EINVAL;
+    if (k > kTopKMax) return VLSA_EUNSUPPORTED;
+    const int kk = k <= 0 ? 0x7fffffff : k;      // mean over all patches
+    hipLaunchKernelGGL(k_topk_mean_batch, dim3(C, B), dim3(256), 0, (hipStream_t)stream, static_cast<const TopkBagDesc*>(bag_desc),
+                       static_cast<const TopkRowsDesc*>(scores_desc), C, kk, logit_scale, out);
     return st();
 }
 

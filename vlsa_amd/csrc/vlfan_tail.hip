@@ -504,3 +504,28 @@ extern "C" int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* st
     else return VLSA_EINVAL;
     return launch_status();
 }
+
+// The whole per-bag inference forward as ONE host call (model/vlsa.py:181-198 with cached text features): query + text
+// preparation, the streaming aggregation, the partial merge, optionally the attention weights, pooling + head.  Same five
+// launches as calling the entry points one by one -- what it removes is four Python -> C crossings per bag: the reference's
+// handler calls the model one bag at a time (runner/vlsa_handler.py:322-330) and that path is host-bound.
+extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* Q, int nq, int gated,
+                                      float coattn_scale, const float* T, int K, const float* logit_scale, int pool_mode,
+                                      const float* pool_w, const float* W, const float* b, int kernel, void* qprep, float* That,
+                                      float* tnorm, float* pm, float* pl, float* pacc, int G, float* m2, float* l, float* out,
+                                      float* scores, float* A, void* head_ws, float* pooled, float* v, float* vhat, float* vnorm,
+                                      float* logits, float* incidence, void* stream) {
+    const int P = gated ? nq - 1 : nq;
+    int rc = vlsa_prepare_queries_and_text(Q, nq, D, gated, coattn_scale, qprep, T, K, That, tnorm, stream);
+    if (rc != VLSA_OK) return rc;
+    rc = vlsa_vlfan_partial(X, x_dtype, N, ldx, D, qprep, P, kernel, pm, pl, pacc, scores, stream);
+    if (rc != VLSA_OK) return rc;
+    rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 1, m2, l, out, stream);
+    if (rc != VLSA_OK) return rc;
+    if (scores && A) {
+        rc = vlsa_attn_normalise(scores, P, N, m2, l, A, stream);
+        if (rc != VLSA_OK) return rc;
+    }
+    return vlsa_head_forward(out, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, pooled, v, vhat, vnorm, logits,
+                             incidence, stream);
+}

@@ -267,23 +267,14 @@ class VlfanInferencePlan:
             for name, t in outs.items():
                 k[name] = _p(t)
         nq = self.P + 1 if self.gated else self.P
-        c = nat.check
-        c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, k["qprep"], _p(T), self.K,
-                                            k["That"], k["tnorm"], s), "prepare_queries_and_text")
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
-        c(lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, k["qprep"], self.P,
-                                 self.kernel, k["pm"], k["pl"], k["pacc"], k["scores"], s),
-          "vlfan_partial")
-        c(lib.vlsa_vlfan_merge(k["pm"], k["pl"], k["pacc"], self.G, self.P, self.D, 1, k["m2"],
-                               k["l"], k["out"], s), "vlfan_merge")
-        if self.scores is not None:
-            c(lib.vlsa_attn_normalise(k["scores"], self.P, self.N, k["m2"], k["l"], k["A"], s),
-              "attn_normalise")
-        c(lib.vlsa_head_forward(k["out"], self.P, self.D, self.pool, _p(pool_w),
-                                None if self.identity_head else _p(W), None if self.identity_head else _p(b),
-                                k["That"], self.K, _p(logit_scale), k["ws"], k["pooled"], k["v"],
-                                k["vhat"], k["vnorm"], k["logits"], k["incidence"], s),
-          "head_forward")
+        # one Python -> C crossing for the five launches (this path is host-bound: the handler calls it bag by bag)
+        nat.check(lib.vlsa_vlfan_forward_bag(_p(X), dt, self.N, X.stride(0), self.D, _p(Q), nq, int(self.gated), self.scale, _p(T),
+                                             self.K, _p(logit_scale), self.pool, _p(pool_w),
+                                             None if self.identity_head else _p(W), None if self.identity_head else _p(b),
+                                             self.kernel, k["qprep"], k["That"], k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G,
+                                             k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"], k["v"], k["vhat"],
+                                             k["vnorm"], k["logits"], k["incidence"], s), "vlsa_vlfan_forward_bag")
         return outs["logits"] if outs and "logits" in outs else self.logits
 
     def run_partial_only(self, X: torch.Tensor):
@@ -784,3 +775,31 @@ class VlfanBatchPlan:
                                                            _p(self.ws), self.reserved_cus, self.groups,
                                                            _p(self.attn.desc) if self.want_attn else None, _stream()),
                   "vlfan_partial_batch")
+
+
+def zeroshot_pool_bags(bags, T: torch.Tensor, logit_scale: torch.Tensor, k: Optional[int]) -> torch.Tensor:
+    """Zero-shot bag logits [B, K] for a list of up to 64 bags (bf16 or fp32 [N_i, 512], one dtype): the K text features go
+    through the persistent multi-bag streaming kernel as queries (scale 1 / log2(e): the stored scores ARE the cosines), then
+    ONE launch pools every (class, bag) row (top-k mean, k clamped to N_i; None: mean).  model/vlsa.py:185-196 per bag."""
+    _need_gpu(T, logit_scale, *bags)
+    lib, s = nat.load(), _stream()
+    K = T.shape[0]
+    table = _BagTable(bags)
+    B, dev = table.B, table.desc.device
+    out = torch.empty(B, K, dtype=torch.float32, device=dev)
+    sizes = [x.shape[0] for x in table.bags]
+    ls = _f32c(logit_scale).reshape(1)
+    for k0 in range(0, K, nat.MAX_P):
+        Tk = T[k0:k0 + nat.MAX_P]
+        Pk = Tk.shape[0]
+        qp = prepare_queries(Tk, False, 1.0 / 1.4426950408889634)
+        sc = AttnBuffers(sizes, Pk, dev)
+        ws = torch.empty(lib.vlsa_batch_workspace_bytes(B, Pk, table.D), dtype=torch.uint8, device=dev)
+        nat.check(lib.vlsa_vlfan_partial_batch_scores(_p(table.desc), B, table.dt, table.D, _p(qp.buf), Pk, _p(ws), 0,
+                                                      choose_groups(sizes, 0), _p(sc.desc), s), "vlsa_vlfan_partial_batch_scores")
+        part = out if (k0 == 0 and Pk == K) else torch.empty(B, Pk, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_topk_mean_batch(_p(table.desc), _p(sc.desc), B, Pk, 0 if k is None else int(k), _p(ls), _p(part), s),
+                  "vlsa_topk_mean_batch")
+        if part is not out:
+            out[:, k0:k0 + Pk] = part
+    return out

@@ -281,3 +281,113 @@ class ShardedVlfanBatchPlan:
         if self._pending is not None:
             self._drain()
         return self.local.logits
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The other encoders, patch-sharded: zero-shot top-k pooling and (gated-)attention pooling over N
+# ------------------------------------------------------------------------------------------------------------------
+def gather_rows(local: torch.Tensor, group=None) -> torch.Tensor:
+    """One all-gather of equal-sized per-rank tensors: [..] -> [world, ..] (identical on every rank)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=group)
+    return out
+
+
+def merge_topk_candidates(gathered: torch.Tensor) -> torch.Tensor:
+    """[world, C, k] per-rank winners -> [C, world * k] candidate rows for the final re-selection."""
+    world, C, k = gathered.shape
+    return gathered.permute(1, 0, 2).reshape(C, world * k).contiguous()
+
+
+def sharded_zeroshot_logits(X_local: torch.Tensor, T: torch.Tensor, logit_scale: torch.Tensor, pooling: str, N_total: int,
+                            group=None) -> torch.Tensor:
+    """Zero-shot bag logits [1, K] of a patch-sharded bag (model/vlsa.py:188-196 with the identity FeatMIL encoder +
+    logit_pooling, model/deepmil.py:16-37).  Every rank scores ITS patches against the K text features in the streaming
+    kernel, keeps the k largest cosines per class (or the per-class sum for 'logit_mean'), ONE all-gather moves
+    ``world x K x k`` floats, every rank re-selects the k winners and averages them.  Identical on every rank."""
+    from .deepmil import _parse_logit_pooling
+    import torch.distributed as dist
+    lib = nat.load()
+    topk = _parse_logit_pooling(pooling)
+    K = T.shape[0]
+    X2 = VF._bag2d(X_local)
+    n_loc = X2.shape[0]
+    dev = X2.device
+    k = N_total if topk is None else min(topk, N_total)
+    scale = logit_scale.detach().float().exp()
+    if n_loc > 0:
+        cos = VF.class_cosines(X2, T.detach())                                    # [K, n_loc]
+    if k >= N_total:                                                              # mean over every patch of the bag
+        part = cos.sum(dim=1) if n_loc > 0 else torch.zeros(K, device=dev)
+        tot = gather_rows(part, group).sum(dim=0)
+        return (scale * tot / float(N_total))[None, :]
+    vals = torch.full((K, k), float("-inf"), dtype=torch.float32, device=dev)   # an empty shard contributes no candidate
+    if n_loc > 0:
+        ws = torch.empty(max(4, lib.vlsa_topk_workspace_bytes(K, n_loc, k)), dtype=torch.uint8, device=dev)
+        nat.check(lib.vlsa_topk_values(VF._p(cos), K, n_loc, k, VF._p(ws), VF._p(vals), VF._stream()), "vlsa_topk_values")
+    cand = merge_topk_candidates(gather_rows(vals, group))                        # [K, world * k], >= k finite entries
+    return (scale * VF.topk_mean(cand, k))[None, :]
+
+
+def sharded_scored_pool(X_local: torch.Tensor, scores_local: Optional[torch.Tensor], group=None):
+    """softmax_N(scores) @ X over a patch-sharded bag (model/layers.py:115-116,146-147; scores None: the mean over N,
+    model/deepmil.py:57-58,271-272): the local online-softmax partial is folded into one record [m | l | acc(D)], ONE
+    all-gather, log-sum-exp merge.  Returns (pooled [D] identical on every rank, (m2, l) global normalisers [16] each --
+    this rank's attention weights are exp2(scores_local * log2(e) - m2[0]) / l[0])."""
+    import torch.distributed as dist
+    X2 = VF._bag2d(X_local)
+    D = X2.shape[1]
+    dev = X2.device
+    if X2.shape[0] > 0:
+        lib = nat.load()
+        N = X2.shape[0]
+        G = int(lib.vlsa_pool_num_partials(N))
+        pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pacc = torch.empty(G, 1, D, dtype=torch.float32, device=dev)
+        sc = None if scores_local is None else VF._f32c(scores_local).reshape(-1)
+        nat.check(lib.vlsa_scored_pool_partial(VF._p(X2), VF._dt(X2), N, X2.stride(0), D, VF._p(sc), VF._p(pm), VF._p(pl), VF._p(pacc),
+                                               VF._stream()), "vlsa_scored_pool_partial")
+        m2, l, acc = VF.vlfan_merge(pm, pl, pacc, normalise=False)
+    else:   # an empty shard: the neutral element of the merge
+        m2 = torch.full((nat.P_STRIDE,), float("-inf"), device=dev)
+        l = torch.zeros(nat.P_STRIDE, device=dev)
+        acc = torch.zeros(1, D, device=dev)
+    rec = torch.cat([m2, l, acc.reshape(-1)])
+    g = gather_rows(rec, group)
+    world = g.shape[0]
+    m2g, lg, out = VF.vlfan_merge(g[:, :nat.P_STRIDE].contiguous(), g[:, nat.P_STRIDE:REC_HDR].contiguous(),
+                                  g[:, REC_HDR:].reshape(world, 1, D).contiguous(), normalise=True)
+    return out[0], (m2g, lg)
+
+
+def sharded_deepmil_forward(enc, X_local: torch.Tensor, group=None, ret_with_attn: bool = False):
+    """``DeepMIL.forward`` (model/deepmil.py:261-292) on a patch-sharded bag in eval mode: the raw (gated-)attention scores of
+    this rank's patches (fused MFMA kernel for bf16 bags), the sharded softmax pooling above, the replicated head.  Returns the
+    bag vector [1, C] (identical on every rank) and, if asked, this rank's columns of what the reference returns as attention
+    (raw scores for 'attention', softmax weights for 'gated_attention')."""
+    import torch.distributed as dist
+    from .layers import Attention_Pooling
+    if enc.feat_proj is not None:
+        X_local = enc.feat_proj(X_local)
+    X2 = VF._bag2d(X_local)
+    attn = None
+    with torch.no_grad():
+        if enc.sigma == "max":
+            loc = VF.colmax(X2) if X2.shape[0] > 0 else torch.full((X2.shape[1],), float("-inf"), device=X2.device)
+            feat = gather_rows(loc, group).max(dim=0).values
+        elif enc.sigma == "mean":
+            feat, _ = sharded_scored_pool(X2, None, group)
+        else:
+            a = enc._attention_scores(X2) if X2.shape[0] > 0 else torch.empty(0, device=X2.device)
+            feat, (m2, l) = sharded_scored_pool(X2, a, group)
+            if ret_with_attn:
+                attn = a if isinstance(enc.sigma, Attention_Pooling) else torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]
+        out_feat = feat[None, :]
+        if enc.pred_head == "Adapter":
+            logit = VF.adapter_head(out_feat, enc.visual_adapter.fc[0].weight, enc.visual_adapter.fc[2].weight, enc.keep_ratio)[None, :]
+        else:
+            logit = enc.g(out_feat)
+    return (logit, attn[None, :] if attn is not None else None) if ret_with_attn else logit

@@ -250,6 +250,12 @@ class VLSA(nn.Module):
         ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512
                                                           and x.shape[0] > 0 for x in flat))
         if not ok:
+            same = (len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)
+                    and flat[0].dtype in (torch.bfloat16, torch.float32))
+            if same and isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max") and text_features.shape[0] <= 64:
+                return self._forward_bags_zeroshot(flat, text_features)
+            if same and isinstance(enc, mil_encoders.DeepMIL) and enc.feat_proj is None:
+                return self._forward_bags_deepmil(flat, text_features)
             if (isinstance(enc, VLFAN) and enc.feat_proj is None and len(flat) > 0
                     and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)):
                 # pooling over the queries by a module (attention / gated attention): batched HIP aggregation, then the
@@ -290,6 +296,40 @@ class VLSA(nn.Module):
             feats.append(outs["vhat"])
         res = (logits[0], feats[0], That) if len(logits) == 1 else (torch.cat(logits), torch.cat(feats), That)
         return res + (used,) if want_attn else res
+
+    def _forward_bags_zeroshot(self, flat, text_features):
+        """Identity FeatMIL + logit pooling for a list of bags (the reference's eval loop is encoder-agnostic,
+        runner/vlsa_handler.py:315-345): per chunk of 64 bags one persistent streaming launch that stores the per-class
+        cosines and one launch that pools them -- instead of ~8 launches per bag.  The unit-norm patch features the reference
+        hands back per bag ([N_i, D] fp32 each) are only produced when ``return_patch_features`` is set to True explicitly."""
+        from .deepmil import _parse_logit_pooling
+        k = _parse_logit_pooling(self.image_encoder_cfg["pooling"])
+        T = text_features.detach().float().contiguous()
+        logits = torch.cat([VF.zeroshot_pool_bags(flat[i:i + 64], T, self.logit_scale.detach(), k) for i in range(0, len(flat), 64)])
+        That, _ = VF.normalize_rows(T)
+        feats = [VF.normalize_many(x) for x in flat] if getattr(self, "return_patch_features", None) is True else None
+        return logits, feats, That
+
+    def _forward_bags_deepmil(self, flat, text_features):
+        """DeepMIL encoder over a list of bags: per bag the N-sized part (attention scores + softmax-weighted row sum, 3-4
+        launches), then ONE batched tail for all bags (head, normalise, cosine logits on [B, 512])."""
+        enc = self.mil_encoder
+        pooled = []
+        for x in flat:
+            if enc.sigma == "mean":
+                pooled.append(VF.scored_pool(x, None))
+            elif enc.sigma == "max":
+                pooled.append(VF.colmax(x))
+            else:
+                pooled.append(VF.scored_pool(x, enc._attention_scores(x)))
+        f = torch.stack(pooled)                                                      # [B, 512]
+        if enc.pred_head == "Adapter":
+            v = enc.keep_ratio * f + (1 - enc.keep_ratio) * enc.visual_adapter(f)
+        else:
+            v = enc.g(f)
+        That = F.normalize(text_features.detach().float(), dim=-1)
+        feats = F.normalize(v, dim=-1)
+        return self.logit_scale.exp() * feats @ That.t(), feats, That
 
     def _forward_zeroshot(self, X, text_features):
         """Identity FeatMIL: per-patch cosine logits pooled over the patches (model/vlsa.py:194-196)."""
