@@ -145,7 +145,9 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
 
 /* vlsa_prepare_queries_and_text + vlsa_vlfan_partial + vlsa_vlfan_merge (+ vlsa_attn_normalise when scores and A are given) +
  * vlsa_head_forward in ONE host call: the per-bag forward of model/vlsa.py:181-198 as the reference's handler issues it, one
- * bag at a time (runner/vlsa_handler.py:322-330).  Arguments as in the individual entry points; G = vlsa_num_partials(N). */
+ * bag at a time (runner/vlsa_handler.py:322-330).  Arguments as in the individual entry points; G = vlsa_num_partials(N).
+ * Q == NULL skips the preparation launch: qprep / That must then hold the result of an earlier call with unchanged queries and
+ * text features (an evaluation loop prepares them once per checkpoint, not once per bag). */
 int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* Q, int nq, int gated,
                            float coattn_scale, const float* T, int K, const float* logit_scale, int pool_mode, const float* pool_w,
                            const float* W, const float* b, int kernel, void* qprep, float* That, float* tnorm, float* pm, float* pl,

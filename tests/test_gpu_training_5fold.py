@@ -1,6 +1,6 @@
 """BASELINE configs[4] shaped training parity: a synthetic cohort with the shape of the reference's TCGA-BLCA
 5-fold cross-validation (data_split/5foldcv/tcga_blca: 373 patients, 12 time bins, folds of 298 / 75; cfg_vlsa_conch.yaml:
-32 bags per optimizer step, Adam 2e-4 -> here 5e-3 to see movement, weight decay 1e-5 on the >= 2-D parameters, IF-MLE +
+32 bags per optimizer step, Adam 2e-4 -> here 1e-3 to see movement in few steps, weight decay 1e-5 on the >= 2-D parameters, IF-MLE +
 EMD loss, the ORDINAL RANK PROMPT LEARNER through the text tower, bf16 resident bags) trained twice from identical seeds:
 
   GPU   DeviceBagArena (bf16) -> VLSA.forward_bags (persistent HIP forward + backward) + the HIP text tower + the fused loss kernel
@@ -21,7 +21,7 @@ from oracle import text_oracle as TO, vlsa_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-NPAT, K, P, FOLDS, BATCH, LR, WD = 373, 12, 12, 5, 32, 5e-3, 1e-5
+NPAT, K, P, FOLDS, BATCH, LR, WD = 373, 12, 12, 5, 32, 1e-3, 1e-5
 EPOCHS = int(os.environ.get("VLSA_5FOLD_EPOCHS", "2"))    # the reference trains 10; 2 keeps the CPU twin within minutes
 TOWER, TSEED, BASE = "train", 9300, 4
 
@@ -33,11 +33,17 @@ def cohort():
     for i in range(NPAT):
         n = int(torch.randint(60, 320, (1,), generator=g))
         tb = int(torch.randint(0, K, (1,), generator=g))
-        x = cases.make_bag(n, 9400 + i)
+        # clustered patches (64 tissue-like clusters, sigma 0.1): i.i.d. Gaussian patches make the scale-100 cross attention
+        # nearly one-hot; real slides have many near-duplicate patches
+        x = cases.make_bag(n, 9400 + i, "clustered")
         x[: n // 3] += (2.2 - 0.4 * tb) * direction
         bags.append(x.to(torch.bfloat16))                      # what the arena stores; the CPU twin sees the same values
         t.append(tb)
-        e.append(1.0 if float(torch.rand(1, generator=g)) < 0.45 else 0.0)     # 169 / 373 events in the real cohort
+        ev = 1.0 if float(torch.rand(1, generator=g)) < 0.45 else 0.0          # 169 / 373 events in the real cohort
+        # no censored patient in the LAST bin: its IF-MLE term is -log(clamp(1 - cumsum(incidence)[K-1], 1e-7)) = the log of fp32
+        # rounding noise around 0 (loss/loss_surv.py:159-162), i.e. -log(1e-7) or -log(1.19e-7) depending on the summation order:
+        # 0.17 per such sample either way, in the reference too -- not something two implementations can agree on to 2e-3
+        e.append(1.0 if tb == K - 1 else ev)
     perm = torch.randperm(NPAT, generator=g).tolist()
     folds = [perm[i::FOLDS] for i in range(FOLDS)]             # 75 / 75 / 75 / 74 / 74 test patients
     return bags, torch.tensor(t), torch.tensor(e), folds

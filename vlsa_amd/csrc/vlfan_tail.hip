@@ -516,8 +516,11 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
                                       float* scores, float* A, void* head_ws, float* pooled, float* v, float* vhat, float* vnorm,
                                       float* logits, float* incidence, void* stream) {
     const int P = gated ? nq - 1 : nq;
-    int rc = vlsa_prepare_queries_and_text(Q, nq, D, gated, coattn_scale, qprep, T, K, That, tnorm, stream);
-    if (rc != VLSA_OK) return rc;
+    int rc = VLSA_OK;
+    if (Q) {   // Q == NULL: qprep / That still hold the result of an earlier call with the same parameters (eval loops)
+        rc = vlsa_prepare_queries_and_text(Q, nq, D, gated, coattn_scale, qprep, T, K, That, tnorm, stream);
+        if (rc != VLSA_OK) return rc;
+    }
     rc = vlsa_vlfan_partial(X, x_dtype, N, ldx, D, qprep, P, kernel, pm, pl, pacc, scores, stream);
     if (rc != VLSA_OK) return rc;
     rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 1, m2, l, out, stream);

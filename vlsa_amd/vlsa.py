@@ -165,10 +165,13 @@ class VLSA(nn.Module):
                                          coattn_scale=float(enc.coattn_logit_scale.exp()))
             self._plans[key] = plan
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=X2.device)  # noqa: E731
-        outs = {"logits": f(1, K), "vhat": f(1, D), "That": f(K, D)}   # fresh tensors, written by the kernels directly
+        outs = {"logits": f(1, K), "vhat": f(1, D), "That": None}   # fresh tensors, written by the kernels directly
+        # queries / text features only change with their parameters: in an evaluation loop they are prepared once, not per bag
+        qsrc = list(enc.Q.parameters()) + list(enc.Q.buffers()) if isinstance(enc.Q, nn.Module) else [enc.Q]
+        pkey = tuple((t.data_ptr(), t._version) for t in qsrc) + ((text_features.data_ptr(), text_features._version),)
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
-                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs)
+                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey)
         return outs["logits"], outs["vhat"], outs["That"]
 
     def forward(self, X):
