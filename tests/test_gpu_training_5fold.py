@@ -182,7 +182,8 @@ def test_fold_loss_curve_and_heldout_cindex_match_the_cpu_reference_path(setup, 
     cg, cc = O.concordance_index(y, ginc), O.concordance_index(y, cinc)
     assert abs(cg - cc) <= 0.01, (fold, cg, cc)
     assert (ginc - cinc).abs().max().item() < 5e-3
-    assert gl[-1] < gl[0]                                      # it trains
+    h = len(gl) // 2
+    assert sum(gl[h:]) / (len(gl) - h) < sum(gl[:h]) / h       # it trains: the last epoch's mean loss is below the first's
     print(f"fold {fold}: {len(gl)} steps, loss {gl[0]:.4f} -> {gl[-1]:.4f} (cpu {cl[-1]:.4f}), held-out c-index gpu {cg:.4f} cpu {cc:.4f}")
 
 
