@@ -327,7 +327,8 @@ int vlsa_normalize_many(const void* X, int x_dtype, int64_t N, int64_t ldx, int 
  *   plain:  a[n] = w2 .  tanh(Wa x_n + ba)                          + c        (Wg = bg = NULL, gated = 0)
  * vlsa_prepare_gated_weights packs the weights once (bf16 hi + lo split, MFMA-fragment order) into `prep`
  * (vlsa_gated_prep_bytes); vlsa_gated_scores streams the bag once: the [N, dim_hid] hidden activations stay in registers.
- * Feed a[] to vlsa_scored_pool_partial for softmax_N(a) @ X.  bf16 bags, dim_in == 512, dim_hid == 256
+ * Feed a[] to vlsa_scored_pool_partial for softmax_N(a) @ X.  bf16 bags (consumed exactly) or fp32 bags (the reference's
+ * own feature format; split into bf16 hi + lo on the fly, 1.5x the MFMA work); dim_in == 512, dim_hid == 256
  * (VLSA_EUNSUPPORTED otherwise: the host then uses library GEMMs + vlsa_attn_scores).
  */
 size_t vlsa_gated_prep_bytes(int gated);

@@ -29,12 +29,13 @@ def _ref(X, Wa, ba, Wg, bg, w2, c):
     return O.attention_pooling(Xf, Wa, ba, w2, c)[1]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 20000, 32768, 32769, 50001])
-def test_fused_scores_vs_torch(N, gated):
+@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 16384, 16385, 20000, 32768, 32769, 50001])
+def test_fused_scores_vs_torch(N, gated, dtype):
     from vlsa_amd import functional as F
     dev = torch.device("cuda", 0)
-    X = cases.make_bag(N, 3000 + N, "clustered" if N % 2 else "iid").to(torch.bfloat16)
+    X = cases.make_bag(N, 3000 + N, "clustered" if N % 2 else "iid").to(dtype)     # fp32: NOT bf16-representable values
     W = _weights(3100 + N, gated, scale=3.0)          # pre-activations of a few units: tanh / sigmoid well exercised
     ref = _ref(X, *W)
     fs = F.FusedAttnScores()
@@ -44,7 +45,7 @@ def test_fused_scores_vs_torch(N, gated):
     assert got.shape == (N,)
     assert (got.cpu() - ref).abs().max().item() < TOL
     # strided rows (a view into a wider matrix) and a second call re-using the packed weights
-    wide = torch.zeros(N, 640, dtype=torch.bfloat16, device=dev)
+    wide = torch.zeros(N, 640, dtype=dtype, device=dev)
     wide[:, :512] = X.to(dev)
     got2 = fs(wide[:, :512], *Wd)
     assert torch.equal(got2, got)
@@ -55,10 +56,11 @@ def test_fused_scores_vs_torch(N, gated):
     assert (got3.cpu() - _ref(X, *W2)).abs().max().item() < TOL
 
 
-def test_saturating_activations():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_saturating_activations(dtype):
     from vlsa_amd import functional as F
     dev = torch.device("cuda", 0)
-    X = (cases.make_bag(300, 3200) * 40).to(torch.bfloat16)       # |pre-activation| up to ~100: tanh -> +-1, sigmoid -> 0 / 1
+    X = (cases.make_bag(300, 3200) * 40).to(dtype)       # |pre-activation| up to ~100: tanh -> +-1, sigmoid -> 0 / 1
     W = _weights(3201, True, scale=3.0)
     got = F.FusedAttnScores()(X.to(dev), *[t.to(dev) for t in W])
     assert torch.isfinite(got).all()
@@ -75,6 +77,6 @@ def test_deepmil_bf16_bag_uses_fused_scores(pooling):
     with torch.no_grad():
         out_b, attn_b = m(X[None], ret_with_attn=True)               # bf16 bag: fused MFMA scores
         assert hasattr(m, "_fused_scores")
-        out_f, attn_f = m(X.float()[None], ret_with_attn=True)       # same values as fp32: library GEMMs + HIP elementwise
+        out_f, attn_f = m(X.float()[None], ret_with_attn=True)       # same values as fp32: the fp32 variant of the fused kernel
     assert (out_b - out_f).abs().max().item() < TOL * max(1.0, out_f.abs().max().item())
     assert (attn_b - attn_f).abs().max().item() < TOL * max(1.0, attn_f.abs().max().item())

@@ -10,8 +10,9 @@ for gated in (True, False):
     Wg = torch.randn(256, 512, device=dev) / 22 if gated else None; bg = torch.randn(256, device=dev) * 0.05 if gated else None
     w2 = torch.randn(1, 256, device=dev) / 16; c = torch.randn(1, device=dev)
     fs = F.FusedAttnScores()
-    for n in (50000, 20000, 10000, 2798, 400000):
-        bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(4 if n > 100000 else 16)]
+    for n, dt in ((50000, torch.bfloat16), (20000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (400000, torch.bfloat16),
+                  (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
+        bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(4 if n > 100000 else 16)]
         for i in range(60): fs(bags[i % len(bags)], Wa, ba, Wg, bg, w2, c)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -20,5 +21,6 @@ for gated in (True, False):
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 200
         fl = 2.0 * n * 512 * 256 * (2 if gated else 1)
-        print(f"gated={gated} N={n:7d}: {us:8.2f} us/bag  algorithmic {fl / us / 1e6:7.1f} TFLOP/s  executed (hi+lo) {2 * fl / us / 1e6:7.1f} TFLOP/s "
-              f"= {2 * fl / us / 1e6 / 2500 * 100:5.1f}% of 2.5 PFLOP/s   X stream {n * 1024 / us / 1e6:5.2f} TB/s")
+        terms = 2 if dt == torch.bfloat16 else 3
+        print(f"gated={gated} {str(dt)[6:]:8s} N={n:7d}: {us:8.2f} us/bag  algorithmic {fl / us / 1e6:7.1f} TFLOP/s  = {fl / us / 1e6 / 2500 * 100:4.1f}% of 2.5 PFLOP/s; executed ({terms} split terms) "
+              f"{terms * fl / us / 1e6:7.1f} TFLOP/s = {terms * fl / us / 1e6 / 2500 * 100:5.1f}%")

@@ -47,6 +47,9 @@ constexpr int kXBuf = kRows * 64;                 // one K step of the tile: 256
 constexpr int kXOff = 0;
 constexpr int kScrOff = kXOff + 2 * kXBuf;        // 32 KiB
 constexpr int kLds = kScrOff + 8 * kRows * 4;     // + 8 KiB
+// fp32 bags: every step's chunk is published as TWO bf16 images (hi, lo = the 2-term split of the fp32 values): 4 buffers
+constexpr int kScrOff32 = kXOff + 4 * kXBuf;      // 64 KiB
+constexpr int kLds32 = kScrOff32 + 8 * kRows * 4;
 }  // namespace gs
 
 struct GatedPrepLayout {
@@ -120,11 +123,18 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <bool GATED, bool FULL>
-__global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__ X, long long N, long long ldx,
+// XF32: fp32 bags (the reference's own feature format, dataset/PatchWSI.py:205-215).  The thread splits its 16 fp32 values of a
+// step into bf16 hi + lo on the fly and publishes both images; per accumulator the step then issues X_hi W_hi + X_hi W_lo +
+// X_lo W_hi (the lo x lo term is 2^-16 relative and dropped): 1.5x the MFMA work of a bf16 bag, no [N, 256] activations in
+// memory, no library GEMM.  (XF32 always takes the two-deep weight ring: 256-register budget.)
+// RT = row tiles of 16 patches per workgroup (16; 8 for gated fp32 bags: 64 instead of 128 accumulator registers leave room for
+// the fp32 staging registers -- with 16 the kernel spilled).
+template <bool GATED, bool FULL, bool XF32, int RT = 16>
+__global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
                                                        const unsigned char* __restrict__ prep, float* __restrict__ a_out,
                                                        int rows_per_tile) {
     using namespace gs;
+    constexpr bool DEEP = FULL && !XF32;   // four-deep weight ring
     constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
     constexpr int NB = GATED ? 2 : 1;     // branches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
     // rows_per_tile (a multiple of 16, <= 256) is chosen by the host so that the launch is a whole number of full rounds of
     // the 256 CUs: a 50k-patch bag runs as 2 x 241 tiles of 208 rows instead of 2 x 196 tiles of 256 (1.5 rounds rounded up)
     // FULL: 256-row tiles, everything static (large bags); otherwise the row-tile count is a run-time, wave-uniform value
-    const int nrt = FULL ? 16 : (rows_per_tile >> 4);
+    const int nrt = FULL ? RT : (rows_per_tile >> 4);
     const long long row0 = (long long)(blockIdx.x >> 1) * rows_per_tile;
     const int nrows = (int)((N - row0) < rows_per_tile ? (N - row0) : rows_per_tile);
     const GatedPrepLayout L(GATED ? 1 : 0);
@@ -146,19 +156,26 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
     const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + w) * kSteps * NF * 1024 + lane * 16;
     const int xr = tid >> 1, xc = (tid & 1) * 2;                  // this thread's row and first 16-B chunk of the X chunk
     const bool xok = xr < nrows;
-    const __bf16* xsrc = X + (row0 + xr) * ldx + xc * 8;          // + 32 ks
+    const __bf16* xsrc = XF32 ? nullptr : static_cast<const __bf16*>(Xv) + (row0 + xr) * ldx + xc * 8;          // + 32 ks
+    const float* xsrc32 = XF32 ? static_cast<const float*>(Xv) + (row0 + xr) * ldx + xc * 8 : nullptr;
     // 16-B chunk c of row r is stored at position c ^ f(r), f(r) = (-(r >> 2)) & 3: ds_read_b128 is serviced in the lane groups
     // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), and with this f the 16 lanes of every
     // group hit 16 different 4-bank sets
     const int fx = (0 - (xr >> 2)) & 3;
     const int x_dst0 = xr * 64 + ((xc ^ fx) << 4), x_dst1 = xr * 64 + (((xc + 1) ^ fx) << 4);
     const int a_off = i16 * 64 + ((g ^ ((0 - (i16 >> 2)) & 3)) << 4);    // A fragment of row tile rt: + rt * 1024
-    struct XPair { bf16x8 lo, hi; };
+    // the thread's 16 values of a step: two 16-byte bf16 chunks c0, c1 (bf16 bags), or four float4 (fp32 bags)
+    struct XPair { bf16x8 lo, hi; f32x4 f[XF32 ? 4 : 1]; };
     auto load_x = [&](int ks) -> XPair {
         XPair r = {};
         if (xok) {
-            r.lo = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks);
-            r.hi = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8);
+            if constexpr (XF32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r.f[q] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4 * q);
+            } else {
+                r.lo = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks);
+                r.hi = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8);
+            }
         }
         return r;
     };
@@ -172,9 +189,9 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
     const float bav = reinterpret_cast<const float*>(prep + L.ba)[h];
     const float bgv = GATED ? reinterpret_cast<const float*>(prep + L.bg)[h] : 0.f;
     const float w2v = reinterpret_cast<const float*>(prep + L.w2)[h];
-    f32x4 acc[16][NB];
+    f32x4 acc[RT][NB];
 #pragma unroll
-    for (int rt = 0; rt < 16; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const float bb = b == 0 ? bav : bgv;
@@ -186,25 +203,43 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
     X0 = load_x(0);
     load_b(0, B0);
     X1 = load_x(1);
-    if (FULL) {
+    if (DEEP) {
         load_b(1, B1);
         load_b(2, B2);
     }
 
     // one K step: publish this step's X share, barrier, start the loads of later steps, 16 A reads, 64 (32) MFMAs
     auto step = [&](int s, bf16x8 (&cur)[NF], bf16x8 (&nxt)[NF], XPair& xcur) {
-        unsigned char* xb = smem + kXOff + (s & 1) * kXBuf;
-        *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = xcur.lo;
-        *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = xcur.hi;
+        unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * kXBuf;     // fp32 bags: hi image, lo image behind it
+        if constexpr (XF32) {
+            bf16x8 h0, h1, l0, l1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v0 = xcur.f[e >> 2][e & 3], v1 = xcur.f[2 + (e >> 2)][e & 3];
+                const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
+                h0[e] = a0; l0[e] = (__bf16)(v0 - (float)a0);
+                h1[e] = a1; l1[e] = (__bf16)(v1 - (float)a1);
+            }
+            *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = h0;
+            *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = h1;
+            *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst0) = l0;
+            *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst1) = l1;
+        } else {
+            *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = xcur.lo;
+            *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = xcur.hi;
+        }
         __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
-        if (s + (FULL ? 3 : 1) < kSteps) load_b(s + (FULL ? 3 : 1), nxt);
+        if (s + (DEEP ? 3 : 1) < kSteps) load_b(s + (DEEP ? 3 : 1), nxt);
         if (s + 2 < kSteps) xcur = load_x(s + 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RT / 4; ++q) {
             if (4 * q >= nrt) break;         // uniform
-            bf16x8 A[4];
+            bf16x8 A[4], AL[XF32 ? 4 : 1];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (4 * q + r4) * 1024 + a_off);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (4 * q + r4) * 1024 + a_off);
+                if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + kXBuf + (4 * q + r4) * 1024 + a_off);
+            }
             if (4 * q + 4 <= nrt) {
                 // hi terms of the 4 NB accumulators of this group, then the lo terms: MFMAs on one accumulator are 4 NB apart
 #pragma unroll
@@ -214,6 +249,13 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
 #pragma unroll
                         for (int b = 0; b < NB; ++b)
                             acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + term], acc[4 * q + r4][b], 0, 0, 0);
+                if constexpr (XF32) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
+                }
             } else {                          // the last, partly filled group of row tiles
 #pragma unroll
                 for (int r4 = 0; r4 < 3; ++r4)
@@ -222,6 +264,8 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
                         for (int b = 0; b < NB; ++b) {
                             acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
                             acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + 1], acc[4 * q + r4][b], 0, 0, 0);
+                            if constexpr (XF32)
+                                acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
                         }
                     }
             }
@@ -229,7 +273,7 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
     };
 #pragma unroll 1
     for (int s = 0; s < kSteps; s += 4) {
-        if (FULL) {
+        if (DEEP) {
             step(s, B0, B3, X0);
             step(s + 1, B1, B0, X1);
             step(s + 2, B2, B1, X0);
@@ -244,9 +288,9 @@ __global__ __launch_bounds__(512) void k_gated_scores(const __bf16* __restrict__
 
     // ---- epilogue: activations, gate, w2, sum over this wave's 16 hidden units, then over the 8 waves, then (atomically) over
     // the two workgroups that share the row tile
-    float_mag* scr = reinterpret_cast<float_mag*>(smem + kScrOff);
+    float_mag* scr = reinterpret_cast<float_mag*>(smem + (XF32 ? kScrOff32 : kScrOff));
 #pragma unroll
-    for (int rt = 0; rt < 16; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
         if (rt < nrt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -282,32 +326,45 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
 extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
                                  void* stream) {
     if (!X || !prep || !a || N < 1 || ldx < D) return VLSA_EINVAL;
-    if (D != gs::kD || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * 2) % 16) || ldx * 2 * gs::kRows >= (1ll << 31)) return VLSA_EINVAL;
+    if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    const bool f32 = x_dtype == VLSA_DT_F32;
+    const long long esz = f32 ? 4 : 2;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * esz) % 16) || ldx * esz * gs::kRows >= (1ll << 31)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
-        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
     }
     // rows per tile.  One round of the 256 CUs covers 2 halves x 128 tiles: bags that fit (N <= 32768) use the smallest multiple
     // of 16 rows that still fits one round (a 2 798-patch bag runs as 2 x 88 tiles of 32 rows instead of 2 x 11 of 256);
     // larger bags use the static 256-row kernel (predicated tiles measured slower there than the rounding loss).
-    int rows_per_tile = gs::kRows;
-    if (N <= 128 * gs::kRows) {
+    const int max_rows = (f32 && gated) ? 128 : gs::kRows;     // gated fp32: 8 row tiles per workgroup (register budget)
+    int rows_per_tile = max_rows;
+    if (N <= 128 * (int64_t)max_rows) {
         rows_per_tile = (int)(((N + 127) / 128 + 15) / 16 * 16);
-        if (rows_per_tile > gs::kRows) rows_per_tile = gs::kRows;
+        if (rows_per_tile > max_rows) rows_per_tile = max_rows;
     }
-    const bool full = rows_per_tile == gs::kRows;
+    const bool full = rows_per_tile == max_rows;
     const unsigned int tiles = (unsigned int)((N + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
-    const __bf16* Xp = static_cast<const __bf16*>(X);
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-#define VLSA_GS(G, F) hipLaunchKernelGGL((k_gated_scores<G, F>), dim3(tiles), dim3(512), gs::kLds, st, Xp, (long long)N, (long long)ldx, pp, a, rows_per_tile)
-    if (gated) { if (full) VLSA_GS(true, true); else VLSA_GS(true, false); }
-    else       { if (full) VLSA_GS(false, true); else VLSA_GS(false, false); }
+#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile)
+    if (f32) {
+        if (gated) {
+            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile);
+            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile);
+        } else { if (full) VLSA_GS(false, true, true); else VLSA_GS(false, false, true); }
+    } else {
+        if (gated) { if (full) VLSA_GS(true, true, false); else VLSA_GS(true, false, false); }
+        else       { if (full) VLSA_GS(false, true, false); else VLSA_GS(false, false, false); }
+    }
 #undef VLSA_GS
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                             if (row0 + 16 * h + 4 * g + r >= nrows) T[h][r] = -INFINITY;
                 }
                 if constexpr (kScores) {  // the four column-quarter waves hold identical scores: waves cw = 0 / 1 store half h = cw
-                    if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = cw == 0 ? T[0] : T[1];
+                    if (srow != nullptr) __builtin_nontemporal_store(cw == 0 ? T[0] : T[1], reinterpret_cast<f32x4*>(srow + row0));   // written once, read once by the normalise launch
                 }
                 const float tmax = fmaxf(fmaxf(fmaxf(T[0][0], T[0][1]), fmaxf(T[0][2], T[0][3])),
                                          fmaxf(fmaxf(T[1][0], T[1][1]), fmaxf(T[1][2], T[1][3])));

@@ -609,7 +609,7 @@ def attn_scores(H: torch.Tensor, Hg: Optional[torch.Tensor], b1, bg, w2, b2) -> 
 
 
 class FusedAttnScores:
-    """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 bag in ONE MFMA kernel
+    """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 or fp32 bag in ONE MFMA kernel
     (vlsa_gated_scores; model/layers.py:85-153): the [N, 256] hidden activations never reach memory.  Holds the weights
     packed in MFMA-fragment order (bf16 hi + lo split) and re-packs them when a parameter changes."""
 
@@ -618,7 +618,8 @@ class FusedAttnScores:
 
     @staticmethod
     def supported(X2: torch.Tensor, dim_in: int, dim_hid: int) -> bool:
-        return X2.is_cuda and X2.dtype == torch.bfloat16 and dim_in == 512 and dim_hid == 256 and X2.shape[0] > 0
+        return (X2.is_cuda and X2.dtype in (torch.bfloat16, torch.float32) and dim_in == 512 and dim_hid == 256
+                and X2.shape[0] > 0)
 
     def __call__(self, X2, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
         lib = nat.load()
@@ -634,7 +635,7 @@ class FusedAttnScores:
             self._key, self._prep = key, prep
         N = X2.shape[0]
         a = torch.empty(N, dtype=torch.float32, device=X2.device)
-        nat.check(lib.vlsa_gated_scores(_p(X2), nat.DT_BF16, N, X2.stride(0), X2.shape[1], _p(self._prep), int(gated), _p(a),
+        nat.check(lib.vlsa_gated_scores(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(self._prep), int(gated), _p(a),
                                         _stream()), "vlsa_gated_scores")
         return a
 
