@@ -15,4 +15,9 @@ for pooling in ("logit_mean", "logit_max", "logit_top10"):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for i in range(200): net(bags[i % 8])
             torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 200 * 1e6
-        print(f"{pooling:12s} N={n:6d} {str(dt)[6:]:9s}: {us:7.1f} us/bag  {n / us:8.1f} M patches/s")
+            flat = [b[0] for b in bags] * 4                        # 32 bags through forward_bags: one score launch + one pooling launch
+            for i in range(10): net.forward_bags(flat)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(40): net.forward_bags(flat)
+            torch.cuda.synchronize(); usb = (time.perf_counter() - t0) / 40 / 32 * 1e6
+        print(f"{pooling:12s} N={n:6d} {str(dt)[6:]:9s}: net(X) {us:7.1f} us/bag  {n / us:8.1f} M patches/s   forward_bags(32) {usb:7.2f} us/bag  {n / usb:8.1f} M patches/s")

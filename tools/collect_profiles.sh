@@ -1,37 +1,50 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): full GPU test suite, bench line, rocprofv3 kernel stats of the bench command,
-# and separate PMC passes (HBM traffic) for the streaming kernel.  Outputs under gpurun_out/r01/.
+# Run ON THE GPU BOX (via gpurun): full GPU test suite, bench lines, rocprofv3 kernel stats of the bench command, separate PMC
+# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r02/ (copied into profiles/ afterwards).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r01; mkdir -p $O
-(timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
+O=gpurun_out/r02; mkdir -p $O
+(timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --streams 1 > $O/bench_streams1.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-extra --streams 1 > $O/bench_profiled_streams1.json 2>/dev/null
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_sq -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_lds -- python tools/run_batch.py 32 50000 > /dev/null 2>&1
+pmc() { # tag, counters..., -- command
+  tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2>&1
+}
+pmc fetch FETCH_SIZE -- python tools/run_batch.py 32 50000
+pmc write WRITE_SIZE -- python tools/run_batch.py 32 50000
+pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_batch.py 32 50000
+pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE -- python tools/run_batch.py 32 50000
+pmc gs_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_gated.py 50000
+pmc gs_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS SQ_WAVES GRBM_GUI_ACTIVE -- python tools/run_gated.py 50000
+pmc gs_mem FETCH_SIZE -- python tools/run_gated.py 50000
 python - <<PY
 import csv, glob, collections, json
-out = {}
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
-    fs = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)
-    if not fs: continue
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
-        if "partial_dma_batch" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        v = v[8:] or v            # skip warm-up launches
-        out[k] = sum(v) / len(v)
-json.dump(out, open("$O/pmc_batch_kernel.json", "w"), indent=1)
-print(out)
+def collect(tags, pat):
+    out = {}
+    for tag in tags:
+        fs = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
+        if not fs: continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if pat in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            v = v[8:] or v            # skip warm-up launches
+            out[k] = sum(v) / len(v)
+    return out
+json.dump(collect(("fetch", "write", "sq", "lds"), "partial_dma_batch"), open("$O/pmc_batch_kernel.json", "w"), indent=1)
+json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "k_gated_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)
 PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/text -- python tools/bench_text.py > /dev/null 2>&1
+cp $(find $O/text -name "*kernel_stats.csv" | head -1) $O/text_kernel_stats.csv
+python tools/bench_text.py --cpu > $O/bench_text.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python tools/prof_train.py > /dev/null 2>&1
-cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats.csv
+cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_batch_kernel_stats.csv
+python tools/bench_attn.py > $O/bench_attn.txt 2>&1
 python tools/bench_train.py > $O/bench_train.txt 2>&1
-python tools/bench_ingest.py > $O/bench_ingest.txt 2>&1
 python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1
 python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
 python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1
@@ -39,5 +52,5 @@ python tools/bench_module.py > $O/bench_module.txt 2>&1
 python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2>/dev/null
-rm -rf $O/train $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
-cat $O/pytest_gpu.txt; cat $O/bench.json | cut -c1-600
+rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
+cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; cut -c1-200 $O/bench_driver_args.json; cat $O/pmc_gated_scores.json | head -30
