@@ -128,14 +128,27 @@ struct GemmArgs {
 // straight-line code and the s_waitcnt pass keeps the prefetched loads in flight; with a runtime trip count it parks the
 // ring behind `s_waitcnt vmcnt(0)` + register moves at every basic-block edge.  The CONCH sizes are instantiated, anything
 // else takes the runtime path.
-template <int MT, int NW, int PRO, int GT>
+#ifdef VLSA_TT_DEBUG
+__device__ long long tt_stamps[16];
+#define TT_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        if (PRO == PRO_LN && blockIdx.x == 5 && threadIdx.x == 0) tt_stamps[k] = __builtin_readcyclecounter();   \
+    } while (0)
+#else
+#define TT_STAMP(k) do {} while (0)
+#endif
+// NTW = 16-column tiles per workgroup (2 or 3).  The grid should not exceed the 256 CUs by a fraction: 288 or 384 workgroups
+// of equal work run as long as 512 (the CUs that get two share their matrix pipes), so the wide products use 48-column
+// tiles: QKV 4 x 48 = 192 workgroups, c_fc 4 x 64 = 256 (measured: 24 -> 14 us per launch).
+template <int MT, int NW, int PRO, int GT, int NTW = 2>
 __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float red[];
-    constexpr int Q = MT * 8;              // accumulator registers per lane
+    constexpr int Q = MT * NTW * 4;        // accumulator registers per lane
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int K = p.K, N = p.N, MG = p.MG, epi = p.epi;
+    TT_STAMP(0);
     int ntile, mg;
     {
         const int b = blockIdx.x;
@@ -148,23 +161,33 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             mg = b % MG;
         }
     }
-    const int n0 = ntile * 32, m0 = mg * (16 * MT);
+    const int n0 = ntile * (16 * NTW), m0 = mg * (16 * MT);
     const int KW = K / NW, kbeg = w * KW, KG = K >> 4;
     const int G = GT > 0 ? GT : (KW >> 4);
     const float* Ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) Ap[t] = p.A + ((size_t)((m0 >> 4) + t) * KG + (kbeg >> 4)) * 256 + lane * 4;
-    const float* Wp[2];
+    const float* Wp[NTW];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) Wp[u] = p.W + ((size_t)((n0 >> 4) + u) * KG + (kbeg >> 4)) * 256 + lane * 4;
+    for (int u = 0; u < NTW; ++u) Wp[u] = p.W + ((size_t)((n0 >> 4) + u) * KG + (kbeg >> 4)) * 256 + lane * 4;
 
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NTW];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NTW; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int PF = MT == 1 ? 8 : 6;    // weight (and, without LayerNorm, activation) register ring: groups in flight
+#ifdef VLSA_TT_DEBUG
+    const int dbg = epi >> 8;
+    if (dbg & 4) return;                                    // launch + set-up only
+    const int gstep = (dbg & 2) ? 0 : 256;                  // every group re-reads tile 0 (L1 resident)
+#define TT_GSTEP gstep
+#define TT_NOMFMA (dbg & 1)
+#else
+#define TT_GSTEP 256
+#define TT_NOMFMA 0
+#endif
     if constexpr (PRO == PRO_LN) {
         // ---- LayerNorm fused into the operand load: this wave's [16 MT rows] x [KW columns] slab of A in registers ------
         // the affine parameters go through LDS (first loads issued; reading them back later is an LDS access that does not
@@ -180,16 +203,17 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) slab[t][jj] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * jj);
+                for (int t = 0; t < MT; ++t) slab[t][jj] = *reinterpret_cast<const f32x4*>(Ap[t] + TT_GSTEP * jj);
             }
-        f32x4 rb[PF][2];
+        f32x4 rb[PF][NTW];
 #pragma unroll
         for (int sI = 0; sI < PF; ++sI)
             if (sI < G) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
+                for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + TT_GSTEP * sI);
             }
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler would otherwise sink the prefetch next to its uses)
+        TT_STAMP(1);
         if (tid * 4 < K) {
             *reinterpret_cast<f32x4*>(sgam + tid * 4) = gld;
             *reinterpret_cast<f32x4*>(sgam + K + tid * 4) = bld;
@@ -205,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             s = quad_rows_sum(s);
             if (g == 0) st[w * (16 * MT) + 16 * t + r] = s;
         }
+        TT_STAMP(2);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -213,6 +238,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             for (int ww = 0; ww < NW; ++ww) s += st[ww * (16 * MT) + 16 * t + r];
             mean[t] = s / (float)K;
         }
+        TT_STAMP(3);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -237,6 +263,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             for (int ww = 0; ww < NW; ++ww) s += st[ww * (16 * MT) + 16 * t + r];
             rstd[t] = 1.f / sqrtf(s / (float)K + kLnEps);
         }
+        TT_STAMP(4);
         // normalise the slab in place (affine parameters from LDS); the MFMA loop below then runs on registers + the ring
         const float* gw = sgam + kbeg + 4 * g;
         const float* gb = sgam + K + kbeg + 4 * g;
@@ -251,53 +278,61 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
                     for (int i = 0; i < 4; ++i) slab[t][jj][i] = fmaf((slab[t][jj][i] - mean[t]) * rstd[t], gam[i], bet[i]);
             }
         __builtin_amdgcn_sched_barrier(0);
+        TT_STAMP(5);
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
                 const int sI = jj % PF;
-                f32x4 b[2];
+                f32x4 b[NTW];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) b[u] = rb[sI][u];
+                for (int u = 0; u < NTW; ++u) b[u] = rb[sI][u];
                 if (jj + PF < G) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
+                    for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + TT_GSTEP * (jj + PF));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (TT_NOMFMA) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t][0] += slab[t][jj];
+#pragma unroll
+                    for (int u = 0; u < NTW; ++u) acc[0][u] += b[u];
+                } else
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
+                        for (int u = 0; u < NTW; ++u)
                             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(slab[t][jj][i], b[u][i], acc[t][u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        TT_STAMP(6);
         __syncthreads();                    // every wave is done with gamma / beta in the buffer the reduction reuses
     } else {
         // register ring PF groups deep: the loads of group jj + PF are issued when group jj is consumed (vmcnt returns in order)
-        f32x4 ra[PF][MT], rb[PF][2];
+        f32x4 ra[PF][MT], rb[PF][NTW];
 #pragma unroll
         for (int sI = 0; sI < PF; ++sI)
             if (sI < G) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * sI);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
+                for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
             }
         // keep the machine scheduler from sinking the prefetch loads next to their uses (it minimises register pressure and
         // would leave ~2 groups in flight): nothing moves across these fences
         __builtin_amdgcn_sched_barrier(0);
         auto stage = [&](int sI, int jj) __attribute__((always_inline)) {
-            f32x4 a[MT], b[2];
+            f32x4 a[MT], b[NTW];
 #pragma unroll
             for (int t = 0; t < MT; ++t) a[t] = ra[sI][t];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) b[u] = rb[sI][u];
+            for (int u = 0; u < NTW; ++u) b[u] = rb[sI][u];
             if (jj + PF < G) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * (jj + PF));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
+                for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -305,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], b[u][i], acc[t][u], 0, 0, 0);
+                    for (int u = 0; u < NTW; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i], b[u][i], acc[t][u], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         if constexpr (GT > 0) {
@@ -324,15 +359,16 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NTW; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) red[(w * Q + (t * 2 + u) * 4 + v) * 64 + lane] = acc[t][u][v];
+            for (int v = 0; v < 4; ++v) red[(w * Q + (t * NTW + u) * 4 + v) * 64 + lane] = acc[t][u][v];
     __syncthreads();
+    TT_STAMP(7);
     for (int q = w; q < Q; q += NW) {       // accumulator register q of every lane: summed and stored by wave q % NW
         float val = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) val += red[(ww * Q + q) * 64 + lane];
-        const int t = q >> 3, u = (q >> 2) & 1, v = q & 3;
+        const int t = q / (NTW * 4), u = (q >> 2) % NTW, v = q & 3;
         const int row = m0 + 16 * t + 4 * g + v, col = n0 + 16 * u + r;
         if (epi & EPI_BIAS) val += p.bias[col];
         if (epi & EPI_GELU) {
@@ -344,6 +380,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
         if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
+    TT_STAMP(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -371,9 +408,9 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
     for (int i = w; i < S; i += 4) {
         const float q = Qs[i][lane];
         const bool is_cls = i == S - 1;
-        float s[2], p[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        float s[2] = {-INFINITY, -INFINITY}, p[2];
+        const int halves = S > 64 ? 2 : 1;                 // prompts are short: the second key chunk is rarely needed (uniform)
+        for (int half = 0; half < halves; ++half) {
             const int j = lane + 64 * half;
             const int jc = j < S ? j : S - 1;          // every lane computes (no cross-lane reads under a divergent branch)
             float dot = 0.f;
@@ -381,7 +418,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
             for (int c = 0; c < kHeadDim; ++c)
                 dot = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), c)), Ks[jc][c], dot);
             const bool ok = j < S && (is_cls ? cls_keep[r0 + jc] != 0 : j <= i);
-            s[half] = ok ? dot : -INFINITY;
+            if (half == 0) s[0] = ok ? dot : -INFINITY; else s[1] = ok ? dot : -INFINITY;
         }
         const float m = wave_max(fmaxf(s[0], s[1]));
         p[0] = s[0] == -INFINITY ? 0.f : __expf(s[0] - m);
@@ -669,21 +706,44 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     return c;
 }
 
-template <int MT, int NW, int PRO, int GT>
+template <int MT, int NW, int PRO, int GT, int NTW = 2>
 int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
     a.MG = M_pad / (16 * MT);
-    const int NT = a.N / 32;
+    const int NT = a.N / (16 * NTW);
     a.xcd_map = (NT % 8 == 0) ? 1 : 0;
-    size_t lds = (size_t)NW * MT * 8 * 64 * sizeof(float);
+    size_t lds = (size_t)NW * MT * NTW * 4 * 64 * sizeof(float);
     if (PRO == PRO_LN && lds < (size_t)(1024 + 2 * a.K) * sizeof(float)) lds = (size_t)(1024 + 2 * a.K) * sizeof(float);
     if (lds > 64 * 1024) {
         static DeviceOnce once;
-        if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm<MT, NW, PRO, GT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm<MT, NW, PRO, GT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL((k_tt_gemm<MT, NW, PRO, GT>), dim3(NT * a.MG), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_tt_gemm<MT, NW, PRO, GT, NTW>), dim3(NT * a.MG), dim3(NW * 64), lds, st, a);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 // G1, G2: the group counts of the CONCH-size tower for this product (compile-time specialisations); anything else: runtime G
+// wide products (N a multiple of 48): 48-column workgroup tiles, see k_tt_gemm
+template <int MT, int NW, int PRO, int G1>
+int launch_gemm_wide(const GemmArgs& a, int M_pad, hipStream_t st) {
+    const int G = a.K / NW / 16;
+    if (a.N % 48 == 0) {
+        if (G == G1) return launch_gemm_g<MT, NW, PRO, G1, 3>(a, M_pad, st);
+        return launch_gemm_g<MT, NW, PRO, 0, 3>(a, M_pad, st);
+    }
+    if (G == G1) return launch_gemm_g<MT, NW, PRO, G1, 2>(a, M_pad, st);
+    return launch_gemm_g<MT, NW, PRO, 0, 2>(a, M_pad, st);
+}
+template <int MT, int NW, int PRO, int G1, int G2>
+int launch_gemm_wide2(const GemmArgs& a, int M_pad, hipStream_t st) {
+    const int G = a.K / NW / 16;
+    if (a.N % 48 == 0) {
+        if (G == G1) return launch_gemm_g<MT, NW, PRO, G1, 3>(a, M_pad, st);
+        if (G == G2) return launch_gemm_g<MT, NW, PRO, G2, 3>(a, M_pad, st);
+        return launch_gemm_g<MT, NW, PRO, 0, 3>(a, M_pad, st);
+    }
+    if (G == G1) return launch_gemm_g<MT, NW, PRO, G1, 2>(a, M_pad, st);
+    if (G == G2) return launch_gemm_g<MT, NW, PRO, G2, 2>(a, M_pad, st);
+    return launch_gemm_g<MT, NW, PRO, 0, 2>(a, M_pad, st);
+}
 template <int MT, int NW, int PRO, int G1, int G2 = G1>
 int launch_gemm(const GemmArgs& a, int M_pad, hipStream_t st) {
     const int G = a.K / NW / 16;
@@ -717,6 +777,20 @@ int pack_one(const float* W, int rows, int cols, int transpose, float* out, hipS
 }
 
 }  // namespace
+
+#ifdef VLSA_TT_DEBUG
+extern "C" int vlsa_tt_debug_stamps(long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(vlsa::tt::tt_stamps), sizeof(long long) * 16) == hipSuccess ? 0 : -3;
+}
+#include <cstdlib>
+static int tt_debug_bits() {
+    const char* e = getenv("VLSA_TT_DEBUG_BITS");
+    return e ? (atoi(e) << 8) : 0;
+}
+#define TT_DBG_BITS tt_debug_bits()
+#else
+#define TT_DBG_BITS 0
+#endif
 
 extern "C" size_t vlsa_tt_packed_bytes(const vlsa_tt_model* m, int with_backward) {
     Shape s;
@@ -791,8 +865,8 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
         {
             GemmArgs a = gemm_args(c.xin_t, pw.in_w, 3 * d, d);
-            a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
-            TT_TRY((launch_gemm<3, 4, PRO_LN, 12>(a, Mp, st)));
+            a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS | TT_DBG_BITS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
+            TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0, r->cls_keep,
                            s.heads, d);
@@ -800,18 +874,18 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(c.attn_t, pw.out_w, d, d);
             a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = c.xmid_t; a.epi = EPI_BIAS | EPI_RESID;
-            TT_TRY((launch_gemm<1, 4, PRO_NONE, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<1, 4, PRO_NONE, 12>(a, Mp, st)));
         }
         {
             GemmArgs a = gemm_args(c.xmid_t, pw.fc_w, 4 * d, d);
             a.bias = w.fc_b; a.Yt = c.hact_t; a.Ypre = save_for_backward ? h_pre : nullptr; a.ldy = 4 * d; a.epi = EPI_BIAS | EPI_GELU;
             a.ln_w = w.ln2_w; a.ln_b = w.ln2_b;
-            TT_TRY((launch_gemm<3, 4, PRO_LN, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
         {
             GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
             a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
-            TT_TRY((launch_gemm<1, 8, PRO_NONE, 24>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 24>(a, Mp, st)));
         }
     }
     hipLaunchKernelGGL(k_tt_lnf_fwd, dim3((s.ns_pad + 3) / 4), dim3(256), 0, st, c.x_final, r->seq_row0, m->lnf_w, m->lnf_b, c.pooled_t, d,
@@ -863,12 +937,12 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d h_pre = (dx @ W_proj) * gelu'(h_pre)
             GemmArgs a = gemm_args(c.dxa_t, pw.proj_w, 4 * d, d);
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
-            TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<3, 4, PRO_NONE, 12>(a, Mp, st)));
         }
         {   // d ln_2 out = d h_pre @ W_fc
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
             a.Y = c.da; a.ldy = d;
-            TT_TRY((launch_gemm<1, 8, PRO_NONE, 24>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 24>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp);
         TT_LAUNCHED();
@@ -876,7 +950,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d attn = dx_mid @ W_out
             GemmArgs a = gemm_args(c.dxb_t, pw.out_w, d, d);
             a.Y = c.dattn; a.ldy = d;
-            TT_TRY((launch_gemm<1, 4, PRO_NONE, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<1, 4, PRO_NONE, 12>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d, c.dqkv_t, r->seq_row0,
                            r->cls_keep, s.heads, d);
@@ -884,7 +958,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
             a.Y = c.da; a.ldy = d;
-            TT_TRY((launch_gemm<1, 8, PRO_NONE, 18>(a, Mp, st)));
+            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 18>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp);
         TT_LAUNCHED();
