@@ -244,13 +244,14 @@ def main():
                                          "note": "25 600 FLOP per patch (SURVEY.md 8(d)); the split-bf16 repeats are not counted"}}
             # HBM traffic and matrix-pipe occupancy of this kernel / launch configuration from the committed PMC passes
             # (separate `--pmc` runs of tools/run_batch.py 32 50000; FETCH_SIZE x 2 = the guide's gfx950 16-B/lane
-            # correction; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)).
+            # correction; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs) = how busy the matrix pipes were).
             pmc, src = load_pmc()
             if pmc and rows_local == 50_000 and dist is None:
                 try:
                     roof["traffic"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
                     roof["traffic_source"] = f"{src} (rocprofv3 --pmc, 32 x 50k bags per launch)"
-                    cyc = pmc.get("GRBM_GUI_ACTIVE") or pmc["SQ_BUSY_CYCLES"] / 32.0   # SQ_BUSY_CYCLES sums the 32 shader engines
+                    # kernel duration in shader cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_BUSY_CYCLES over the 32 shader engines
+                    cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else pmc["SQ_BUSY_CYCLES"] / 32.0
                     roof["mfma_util"] = round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
                 except Exception:
                     pass
