@@ -68,18 +68,19 @@ class PlainPromptLearner(nn.Module):
         if init_prompt_path is not None:
             init_context, init_rank_names = _read_init_prompt(init_prompt_path, ctx_idx, rank_idx)
         dim, dt = self.cfg_embedding_dim, self.cfg_embedding_dtype
+        dev = token_embedding.weight.device          # the learner is built where the token embedding lives (CPU or GPU)
         # ---- context: embeddings of the tokenised init text, or N(0, 0.02) ---------------------------------------------
         if init_context is not None:
             ids, n = tokenizer(init_context.replace("_", " "), return_raw_tokens=True, return_num_tokens=True)
             num_context_tokens = int(n)
             with torch.no_grad():
-                ctx = token_embedding(ids).detach().clone()
+                ctx = token_embedding(ids.to(dev)).detach().clone()
             assert ctx.shape[0] == num_context_tokens
             if rank_specific_context:
                 ctx = ctx[None].repeat(num_ranks, 1, 1)
         else:
             shape = (num_ranks, num_context_tokens, dim) if rank_specific_context else (num_context_tokens, dim)
-            ctx = torch.empty(shape, dtype=dt)
+            ctx = torch.empty(shape, dtype=dt, device=dev)
             nn.init.normal_(ctx, std=0.02)
         self.context_embeds = nn.Parameter(ctx)
         # ---- rank names: embeddings of the (right-padded) raw token rows, or N(0, 0.02) ---------------------------------
@@ -92,13 +93,13 @@ class PlainPromptLearner(nn.Module):
             if max(counts) > self.cfg_max_num_tokens - num_context_tokens - 3:      # <sot>, <full stop>, <eot>
                 raise ValueError(f"The rank name is too long: {names[counts.index(max(counts))]}.")
             with torch.no_grad():
-                rk = token_embedding(ids).detach().clone()
+                rk = token_embedding(ids.to(dev)).detach().clone()
             assert rk.shape[1] == max(counts)
         else:
             counts = list(num_tokens_per_rank)
             if self.cfg_max_num_tokens < num_context_tokens + max(counts) + 3:
                 raise ValueError(f"The value of `max_num_tokens_per_rank` ({max(counts)}) is too large.")
-            rk = torch.empty((num_embed_ranks, max(counts), dim), dtype=dt)
+            rk = torch.empty((num_embed_ranks, max(counts), dim), dtype=dt, device=dev)
             nn.init.normal_(rk, std=0.02)
         self.rank_embeds = nn.Parameter(rk)
         assert len(rk) == num_embed_ranks
@@ -114,7 +115,7 @@ class PlainPromptLearner(nn.Module):
         for i, nt in enumerate(self.num_tokens_per_rank):
             n = 1 + num_context_tokens + nt + 2
             pseudo[i, :n] = torch.arange(1, n + 1)
-        self.register_buffer("pseudo_sentence_tokens", pseudo, persistent=False)
+        self.register_buffer("pseudo_sentence_tokens", pseudo.to(dev), persistent=False)
         # ---- sentence template: pad everywhere, <sot> first, "." and <eot> closing the sentence --------------------------
         with torch.no_grad():
             row = tokenizer("X.", return_raw_tokens=False, return_num_tokens=False)
@@ -143,8 +144,8 @@ class PlainPromptLearner(nn.Module):
                 seq = c_idx[:C // 2] + r_idx + c_idx[C // 2:]
             order[i, :len(seq)] = torch.tensor(seq, dtype=torch.long)
             valid[i, :len(seq)] = True
-        self.register_buffer("_order", order, persistent=False)
-        self.register_buffer("_valid", valid, persistent=False)
+        self.register_buffer("_order", order.to(dev), persistent=False)
+        self.register_buffer("_valid", valid.to(dev), persistent=False)
 
     def _rank_rows(self) -> torch.Tensor:
         return self.rank_embeds                       # [num_ranks, T, dim]
@@ -181,7 +182,8 @@ class RankPromptLearner(PlainPromptLearner):
                     rank_tokens_position, init_prompt_path, init_prompt_context_idx, init_prompt_rank_idx, rank_specific_context,
                     init_context, init_rank_names, uniform_rank_length=True)
         self.num_base_ranks = num_base_ranks
-        self.register_buffer("interpolation_weights", self.create_interpolation_weights(num_base_ranks, num_ranks, interpolation_type),
+        self.register_buffer("interpolation_weights",
+                             self.create_interpolation_weights(num_base_ranks, num_ranks, interpolation_type).to(self.rank_embeds.device),
                              persistent=False)
 
     def create_interpolation_weights(self, num_base_ranks, num_ranks, interpolation_type):
