@@ -147,7 +147,8 @@ int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const floa
  * vlsa_head_forward in ONE host call: the per-bag forward of model/vlsa.py:181-198 as the reference's handler issues it, one
  * bag at a time (runner/vlsa_handler.py:322-330).  Arguments as in the individual entry points; G = vlsa_num_partials(N).
  * Q == NULL skips the preparation launch: qprep / That must then hold the result of an earlier call with unchanged queries and
- * text features (an evaluation loop prepares them once per checkpoint, not once per bag). */
+ * text features (an evaluation loop prepares them once per checkpoint, not once per bag).  pool_mode < 0 stops after the
+ * merge (out [P, D] is the result): for the attention query poolings, followed by vlsa_query_pool_attention + vlsa_head_forward. */
 int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* Q, int nq, int gated,
                            float coattn_scale, const float* T, int K, const float* logit_scale, int pool_mode, const float* pool_w,
                            const float* W, const float* b, int kernel, void* qprep, float* That, float* tnorm, float* pm, float* pl,
@@ -290,6 +291,15 @@ int vlsa_colmax(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float
  */
 int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const float* b1, const float* bg,
                      const float* w2, const float* b2, float* a, void* stream);
+
+/* Replaces forward_query_pooling with query_pooling = 'attention' | 'gated_attention' (model/deepmil.py:101-105,133-150: the
+ * ABMIL modules of model/layers.py:85-153 applied to the P aggregated rows) for B bags in two launches: rows [B, P, D] ->
+ * pooled [B, D] = softmax_P(a) @ rows, a_p = w2 . (tanh(Wa r_p + ba) [* sigmoid(Wg r_p + bg)]) + c; scores [B, P] (nullable) = a
+ * (want_raw: Attention_Pooling's default return) or softmax_P(a) (Gated_Attention_Pooling's).  Wa, Wg [hid, D]; Wg / bg NULL:
+ * ungated.  workspace: B * ((hid + 3) / 4) * 16 floats.  Feed pooled to vlsa_head_forward(..., VLSA_POOL_GIVEN). */
+int vlsa_query_pool_attention(const float* rows, int B, int P, int D, const float* Wa, const float* ba, const float* Wg,
+                              const float* bg, const float* w2, const float* c, int hid, int want_raw, void* workspace,
+                              float* pooled, float* scores, void* stream);
 
 /* out[n] = x_n . v  -- the N-sized piece of the attention-pooling backward. */
 int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out, void* stream);

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "vlsa_colmax": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_attn_scores": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
+    "vlsa_query_pool_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_rowdot": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "vlsa_topk_mean_ws": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -347,6 +347,82 @@ __global__ __launch_bounds__(256) void k_attn_scores(const float* __restrict__ H
     }
 }
 
+// ---- (gated-)attention pooling over the P <= 16 aggregated rows of VLFAN (query_pooling = 'attention' | 'gated_attention',
+// model/deepmil.py:101-105,133-150 -> model/layers.py:103-122,137-153), B bags per launch.  Two launches instead of ~10 torch ops on a
+// [P, 512] matrix (those paths were host-bound: 236-282 us per bag).
+// Stage 1: workgroup (hidden chunk of 4 units, bag): wave w owns hidden unit h = 4 * chunk + w: its rows of Wa (and Wg) in
+// registers, the bag's P rows through LDS; part[bag][chunk][p] = sum over the 4 units of w2[h] * tanh(.) (* sigmoid(.)).
+__global__ __launch_bounds__(256) void k_qpool_scores(const float* __restrict__ rows, int P, int D, const float* __restrict__ Wa,
+                                                       const float* __restrict__ ba, const float* __restrict__ Wg,
+                                                       const float* __restrict__ bg, const float* __restrict__ w2, int hid,
+                                                       float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];   // [P][D]
+    __shared__ float sred[4][VLSA_MAX_P];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int chunk = blockIdx.x, bag = blockIdx.y, nchunk = gridDim.x;
+    const float* r = rows + (size_t)bag * P * D;
+    for (int i = tid; i < P * D; i += 256) srow[i] = r[i];
+    __syncthreads();
+    const int h = 4 * chunk + w;
+    float acc[VLSA_MAX_P];
+#pragma unroll
+    for (int p = 0; p < VLSA_MAX_P; ++p) acc[p] = 0.f;
+    if (h < hid) {
+        float da[VLSA_MAX_P], dg[VLSA_MAX_P];
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p) da[p] = dg[p] = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float wa = Wa[(size_t)h * D + c], wg = Wg ? Wg[(size_t)h * D + c] : 0.f;
+#pragma unroll
+            for (int p = 0; p < VLSA_MAX_P; ++p)
+                if (p < P) {
+                    const float x = srow[p * D + c];
+                    da[p] = fmaf(wa, x, da[p]);
+                    dg[p] = fmaf(wg, x, dg[p]);
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p)
+            if (p < P) {
+                const float za = wave_sum(da[p]) + ba[h];
+                float e = tanhf(za);
+                if (Wg) e *= 1.f / (1.f + expf(-(wave_sum(dg[p]) + bg[h])));
+                acc[p] = w2[h] * e;
+            }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p)
+            if (p < P) sred[w][p] = acc[p];
+    }
+    __syncthreads();
+    if (tid < P) part[((size_t)bag * nchunk + chunk) * VLSA_MAX_P + tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+}
+// Stage 2: one workgroup per bag: raw[p] = sum of the chunk partials + c; attn = softmax_P(raw); pooled = attn @ rows.
+// scores_out [B, P]: the raw scores (want_raw) or the softmax weights -- what the two reference modules hand back by default.
+__global__ __launch_bounds__(256) void k_qpool_finish(const float* __restrict__ rows, int P, int D, const float* __restrict__ part,
+                                                       int nchunk, const float* __restrict__ c, int want_raw,
+                                                       float* __restrict__ pooled, float* __restrict__ scores_out) {
+    __shared__ float sa[VLSA_MAX_P];
+    const int tid = threadIdx.x, bag = blockIdx.x;
+    if (tid < P) {
+        float s = 0.f;
+        for (int k = 0; k < nchunk; ++k) s += part[((size_t)bag * nchunk + k) * VLSA_MAX_P + tid];
+        sa[tid] = s + c[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY, sum = 0.f;
+    for (int p = 0; p < P; ++p) mx = fmaxf(mx, sa[p]);
+    for (int p = 0; p < P; ++p) sum += expf(sa[p] - mx);
+    if (scores_out && tid < P) scores_out[(size_t)bag * P + tid] = want_raw ? sa[tid] : expf(sa[tid] - mx) / sum;
+    const float* r = rows + (size_t)bag * P * D;
+    for (int col = tid; col < D; col += 256) {
+        float o = 0.f;
+        for (int p = 0; p < P; ++p) o = fmaf(expf(sa[p] - mx) / sum, r[p * D + col], o);
+        pooled[(size_t)bag * D + col] = o;
+    }
+}
+
 // ---- out[n] = x_n . v  (pooling backward: d a_n = A_n (x_n . dpooled - pooled . dpooled))
 template <typename XT>
 __global__ __launch_bounds__(256) void k_rowdot(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
@@ -664,6 +740,22 @@ extern "C" int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int 
     int64_t nb = (N + 3) / 4;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_attn_scores, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, H, Hg, N, hid, b1, bg, w2, b2, a);
+    return st();
+}
+
+// (Gated_)Attention_Pooling over the P aggregated rows of B bags (VLFAN query pooling): rows [B, P, D] -> pooled [B, D],
+// scores [B, P] (raw scores if want_raw -- Attention_Pooling's default return -- else the softmax weights).  Wg / bg NULL: ungated.
+// workspace: B * ceil(hid / 4) * 16 floats.
+extern "C" int vlsa_query_pool_attention(const float* rows, int B, int P, int D, const float* Wa, const float* ba, const float* Wg,
+                                         const float* bg, const float* w2, const float* c, int hid, int want_raw, void* workspace,
+                                         float* pooled, float* scores, void* stream) {
+    if (!rows || !Wa || !ba || !w2 || !c || !workspace || !pooled || (Wg && !bg)) return VLSA_EINVAL;
+    if (B < 1 || P < 1 || P > VLSA_MAX_P || D < 1 || D > VLSA_MAX_D || hid < 1) return VLSA_EINVAL;
+    const int nchunk = (hid + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_qpool_scores, dim3(nchunk, B), dim3(256), (size_t)P * D * sizeof(float), s, rows, P, D, Wa, ba, Wg, bg, w2, hid, part);
+    hipLaunchKernelGGL(k_qpool_finish, dim3(B), dim3(256), 0, s, rows, P, D, part, nchunk, c, want_raw, pooled, scores);
     return st();
 }
 

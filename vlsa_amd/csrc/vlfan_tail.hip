@@ -529,6 +529,7 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
         rc = vlsa_attn_normalise(scores, P, N, m2, l, A, stream);
         if (rc != VLSA_OK) return rc;
     }
+    if (pool_mode < 0) return VLSA_OK;   // aggregation only: the caller pools the P rows itself (attention poolings) and calls the head
     return vlsa_head_forward(out, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, pooled, v, vhat, vnorm, logits,
                              incidence, stream);
 }

@@ -142,6 +142,10 @@ class VLFAN(nn.Module):
         """[B, P, C] aggregated rows -> ([B, C] pooled, scores of the pooling module or None)  (model/deepmil.py:133-150)"""
         pool = self.query_pooling
         if isinstance(pool, nn.Module):                       # Attention_Pooling / Gated_Attention_Pooling over the P rows
+            needs_graph = torch.is_grad_enabled() and (X.requires_grad or any(p.requires_grad for p in pool.parameters()))
+            dropout_on = pool.training and isinstance(pool, Gated_Attention_Pooling) and pool.fc1[2].p > 0
+            if X.is_cuda and not needs_graph and not dropout_on and X.shape[1] <= 16 and X.shape[2] <= 1024:
+                return VF.query_pool_attention(X, pool)       # inference: two HIP launches instead of ~10 torch ops on [P, 512]
             return pool(X)
         if isinstance(pool, nn.Parameter):                    # 'weight': learnable convex combination of the P rows
             mix = torch.softmax(pool, dim=-1)                 # [1, P]
@@ -159,6 +163,8 @@ class VLFAN(nn.Module):
             mode, pw = self.query_pooling, None
         elif isinstance(self.query_pooling, nn.Parameter):
             mode, pw = "weight", self.query_pooling
+        elif not (self.query_pooling.training and isinstance(self.query_pooling, Gated_Attention_Pooling) and self.query_pooling.fc1[2].p > 0):
+            mode, pw = "module", self.query_pooling       # (gated-)attention over the P rows: vlsa_query_pool_attention
         else:
             return None
         if isinstance(self.visual_adapter, nn.Linear):

@@ -256,7 +256,7 @@ class VlfanInferencePlan:
 
     def run(self, X: torch.Tensor, Q: torch.Tensor, T: torch.Tensor, logit_scale: torch.Tensor,
             W: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None,
-            pool_w: Optional[torch.Tensor] = None, outs: Optional[dict] = None, params_key=None):
+            pool_w: Optional[torch.Tensor] = None, outs: Optional[dict] = None, params_key=None, query_pool_module=None):
         """params_key: a hashable that changes whenever Q or T change (parameter versions); when it equals the previous
         call's, the query / text preparation launch is skipped and the plan's prepared block is reused (outs['That'], if
         given, is then filled by a copy of the cached unit text features).
@@ -277,11 +277,16 @@ class VlfanInferencePlan:
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
         # one Python -> C crossing for the five launches (this path is host-bound: the handler calls it bag by bag)
         nat.check(lib.vlsa_vlfan_forward_bag(_p(X), dt, self.N, X.stride(0), self.D, None if reuse else _p(Q), nq, int(self.gated), self.scale, _p(T),
-                                             self.K, _p(logit_scale), self.pool, _p(pool_w),
+                                             self.K, _p(logit_scale), -1 if query_pool_module is not None else self.pool, _p(pool_w),
                                              None if self.identity_head else _p(W), None if self.identity_head else _p(b),
                                              self.kernel, k["qprep"], k["That"], k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G,
                                              k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"], k["v"], k["vhat"],
                                              k["vnorm"], k["logits"], k["incidence"], s), "vlsa_vlfan_forward_bag")
+        if query_pool_module is not None:   # (gated-)attention pooling over the P rows, then the head on the pooled row
+            pooled, self.pool_scores = query_pool_attention(self.out[None], query_pool_module)
+            nat.check(lib.vlsa_head_forward(_p(pooled), 1, self.D, nat.POOL_GIVEN, None, None if self.identity_head else _p(W),
+                                            None if self.identity_head else _p(b), k["That"], self.K, _p(logit_scale), k["ws"],
+                                            k["pooled"], k["v"], k["vhat"], k["vnorm"], k["logits"], k["incidence"], s), "vlsa_head_forward")
         if outs and "That" in outs:
             if not reuse or getattr(self, "_That_out", None) is None:
                 self._That_out = self.That.clone()   # one copy per parameter version, handed out (read-only) to every bag
@@ -815,3 +820,28 @@ def zeroshot_pool_bags(bags, T: torch.Tensor, logit_scale: torch.Tensor, k: Opti
         if part is not out:
             out[:, k0:k0 + Pk] = part
     return out
+
+
+def query_pool_attention(rows: torch.Tensor, module) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(Gated_)Attention_Pooling over the P aggregated rows of B bags in two launches (inference): rows [B, P, D] fp32 ->
+    (pooled [B, D], scores [B, P]) with the module's own return convention (raw scores for Attention_Pooling, softmax weights
+    for Gated_Attention_Pooling; model/layers.py:103-122,137-153).  `module` carries the parameters."""
+    _need_gpu(rows)
+    lib = nat.load()
+    rows = _f32c(rows)
+    B, P, D = rows.shape
+    gated = hasattr(module, "fc1")
+    if gated:
+        la, lg, l2 = module.fc1[0], module.score[0], module.fc2
+        Wg, bg = _f32c(lg.weight), _f32c(lg.bias)
+    else:
+        la, l2 = module.attention[0], module.attention[2]
+        Wg = bg = None
+    hid = la.weight.shape[0]
+    ws = torch.empty(B * ((hid + 3) // 4) * nat.P_STRIDE, dtype=torch.float32, device=rows.device)
+    pooled = torch.empty(B, D, dtype=torch.float32, device=rows.device)
+    scores = torch.empty(B, P, dtype=torch.float32, device=rows.device)
+    nat.check(lib.vlsa_query_pool_attention(_p(rows), B, P, D, _p(_f32c(la.weight)), _p(_f32c(la.bias)), _p(Wg), _p(bg),
+                                            _p(_f32c(l2.weight).reshape(-1)), _p(_f32c(l2.bias).reshape(-1)), hid, int(not gated),
+                                            _p(ws), _p(pooled), _p(scores), _stream()), "vlsa_query_pool_attention")
+    return pooled, scores

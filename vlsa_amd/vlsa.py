@@ -158,11 +158,14 @@ class VLSA(nn.Module):
             return None
         key = (N, D, P, K, X2.dtype, X2.device, enc.gated_query, mode, W is None)
         plan = self._plans.get(key)
+        qmod = pw if mode == "module" else None
+        if qmod is not None:
+            pw = None
         if plan is None:
             if len(self._plans) > 64:
                 self._plans.clear()
-            plan = VF.VlfanInferencePlan(N, D, P, K, X2.device, gated=enc.gated_query, pool=mode, identity_head=W is None,
-                                         coattn_scale=float(enc.coattn_logit_scale.exp()))
+            plan = VF.VlfanInferencePlan(N, D, P, K, X2.device, gated=enc.gated_query, pool="mean" if qmod is not None else mode,
+                                         identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()))
             self._plans[key] = plan
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=X2.device)  # noqa: E731
         outs = {"logits": f(1, K), "vhat": f(1, D), "That": None}   # fresh tensors, written by the kernels directly
@@ -171,7 +174,8 @@ class VLSA(nn.Module):
         pkey = tuple((t.data_ptr(), t._version) for t in qsrc) + ((text_features.data_ptr(), text_features._version),)
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
-                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey)
+                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey,
+                 query_pool_module=qmod)
         return outs["logits"], outs["vhat"], outs["That"]
 
     def forward(self, X):
@@ -235,7 +239,7 @@ class VLSA(nn.Module):
         spec = enc.fused_head_spec()
         flat = [VF._bag2d(x) for x in bags]
         ok = (len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat))
-        if grad or spec is None or not ok:
+        if grad or spec is None or spec[0] == "module" or not ok:
             with torch.set_grad_enabled(grad):
                 text_n = F.normalize(text_features, dim=-1)
                 feats, attn = enc.forward_bags(bags, ret_with_attn=True)
@@ -250,8 +254,8 @@ class VLSA(nn.Module):
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         flat = [VF._bag2d(x) for x in bags]
-        ok = (spec is not None and len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512
-                                                          and x.shape[0] > 0 for x in flat))
+        ok = (spec is not None and spec[0] != "module" and len(flat) > 0
+              and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat))
         if not ok:
             same = (len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)
                     and flat[0].dtype in (torch.bfloat16, torch.float32))
