@@ -232,11 +232,12 @@ int vlsa_vlfan_forward_batch_attn(const void* bag_desc, int B, int x_dtype, int 
  * Backward of the aggregation for a BATCH of bags w.r.t. the (shared) effective queries -- one training step of the
  * reference back-propagates 32 bags through the same queries (runner/vlsa_handler.py:260-289, model/deepmil.py:187-200).
  * dout, out: [B, P, D]; m2, l: [B, 16] (the batched forward's outputs).  ONE persistent launch streams all bags and writes
- * 256 partial sums of  sum_bags de  into pm (= 0), pl (= 1) [256, 16] and pacc [256, P, D]; reduce them with
- * vlsa_vlfan_merge(..., G = 256, normalise = 0).  bwd_prep: scratch of vlsa_bwd_batch_prep_bytes(B, D).
+ * G = vlsa_bwd_batch_partials() partial sums of  sum_bags de  into pm (= 0), pl (= 1) [G, 16] and pacc [G, P, D]; reduce them
+ * with vlsa_vlfan_merge(..., G, normalise = 0).  bwd_prep: scratch of vlsa_bwd_batch_prep_bytes(B, D).
  * bf16 bags, D == 512 and P <= 12 (VLSA_EUNSUPPORTED otherwise: loop vlsa_vlfan_backward over the bags instead).
  * groups: bags in flight as in vlsa_vlfan_partial_batch_ex (0 = min(B, 8)).
  */
+int vlsa_bwd_batch_partials(void);
 size_t vlsa_bwd_batch_prep_bytes(int B, int D);
 int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
                               float coattn_scale, const float* dout, const float* out, const float* m2, const float* l,

@@ -9,7 +9,8 @@ base = torch.randn(32 * n, 512, device=dev).to(torch.bfloat16)
 bags = [base[i * n:(i + 1) * n] for i in range(32)]
 Q = torch.randn(12, 512, device=dev, requires_grad=True)
 G = torch.randn(32, 12, 512, device=dev)
-for i in range(12):
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+for i in range(iters):
     out = F.vlfan_cross_attention_bags(bags, Q)
     (out * G).sum().backward()
 torch.cuda.synchronize()

@@ -5,9 +5,13 @@
 // Because the queries are shared, the per-bag contributions simply add: the accumulators live in registers across ALL
 // bags and every workgroup writes ONE partial at the very end (no per-bag epilogue at all).  Per bag only the upstream
 // gradient fragments (3-term bf16 split of dout), m2, 1/l and delta are reloaded.
+// Workgroup = FOUR waves = the four column quarters of one 32-row tile, 512 workgroups = two per CU.  (Round 1 ran eight
+// waves = two row groups per workgroup: the workgroup-wide barriers of the exchange kept the two waves of every SIMD in lock
+// step -- both issue their MFMAs at the same time, then idle together.  Two independent workgroups drift apart and one's
+// exchange / softmax phase overlaps the other's MFMA phase: 309 -> 290 us per 32 x 50k bags on the same box.)
 // The two partial tiles a wave must share per 32-row tile (scores and dout . x) are exchanged in a compact
-// [2 h][4 g][12 p] layout to stay inside 160 KiB of LDS, hence P <= 12 here (the reference's datasets use 7..12
-// prototypes); larger P goes through the per-bag kernel.
+// [2 h][4 g][12 p] layout so that a workgroup stays inside 80 KiB of LDS, hence P <= 12 here (the reference's datasets use
+// 7..12 prototypes); larger P goes through the per-bag kernel.
 #include "vlsa_common.h"
 
 namespace vlsa {
@@ -29,14 +33,14 @@ namespace bb {
 constexpr int kTile = 32;
 constexpr int kSlot = kTile * 256;
 constexpr int kWaveRing = 2 * kSlot;
-constexpr int kRingBytes = 8 * kWaveRing;         // 128 KiB
+constexpr int kRingBytes = 4 * kWaveRing;         // 64 KiB: four waves
 constexpr int kMaxP = 12;
 constexpr int kTileBytes = 2 * 4 * kMaxP * 16;    // one compact [2 h][4 g][12 p] x f32x4 tile = 1536 B
 constexpr int kExchWave = 2 * kTileBytes + 128;   // S tile + dA tile + 32 row sums of squares = 3200 B
 constexpr int kExchGroup = 4 * kExchWave;
-constexpr int kTabOff = kRingBytes + 2 * kExchGroup;
+constexpr int kTabOff = kRingBytes + kExchGroup;
 constexpr int kMaxBags = 64;
-constexpr int kLdsBytes = kTabOff + kMaxBags * 32;  // 158,720 B
+constexpr int kLdsBytes = kTabOff + kMaxBags * 32;  // 80,384 B: two workgroups per CU
 }  // namespace bb
 
 __device__ __forceinline__ int wswz(int row, int byte_off) { return row * 256 + (byte_off ^ ((row & 7) << 5)); }
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_prepare_backward_batch(const float* __r
 // S = number of workgroup groups: bag t is streamed by the Gb = G / S workgroups of group t % S only, so S bags are in
 // flight at once, every workgroup sees S times more rows per bag (fewer bag epilogues, better tile quantisation) and a
 // bag leaves Gb instead of G partials behind.
-__global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDesc* __restrict__ bags, int B,
+__global__ __launch_bounds__(256, 2) void k_vlfan_backward_dma_batch(const BagDesc* __restrict__ bags, int B,
                                                                      const __bf16* __restrict__ qsplit,
                                                                      const __bf16* __restrict__ dsplit, int P,
                                                                      const float* __restrict__ m2, const float* __restrict__ l,
@@ -87,13 +91,13 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = w >> 2, cw = w & 3;
+    const int cw = w;
     const int g = lane >> 4, i16 = lane & 15;
     const int Gb = gridDim.x / S;            // workgroups (and partials) per bag
     const int grp = blockIdx.x / Gb, b = blockIdx.x % Gb, G = Gb;
 
     unsigned char* ring = smem + w * kWaveRing;
-    unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
+    unsigned char* exch = smem + kRingBytes;
     int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
     const bool pok = i16 < P;
     // compact exchange slot of query p = i16 inside its g block, rotated by 4 g: ds_read_b128 is serviced in the lane groups
@@ -105,13 +109,13 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
         const BagDesc d = bags[tid];
         // 64-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
         // unit rotates with the bag index so that the extra iterations even out over the batch
-        const unsigned long long units = (unsigned long long)((d.N + 63) >> 6);
+        const unsigned long long units = (unsigned long long)((d.N + 31) >> 5);
         const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
         const unsigned int vb = (unsigned int)((b + (tid / S) * 37) % G);  // virtual workgroup index for this bag
         const bool mine = (tid % S) == grp;
         const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
-        const long long rbeg = (long long)(ubeg << 6);
-        long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 6);
+        const long long rbeg = (long long)(ubeg << 5);
+        long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 5);
         if (rend > d.N) rend = d.N;
         const int nrows = (mine && rend > rbeg) ? (int)(rend - rbeg) : 0;
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 2ull;
@@ -178,22 +182,21 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
     };
     // this row group's next own tile after (bag, tile): same bag if it has one, else the first of a later bag
     auto next_of = [&](int bag, int tile, int ntiles_bag, int& nb, int& nt) {
-        if (tile + 2 < ntiles_bag) {
+        if (tile + 1 < ntiles_bag) {
             nb = bag;
-            nt = tile + 2;
+            nt = tile + 1;
             return;
         }
         nb = bag + 1;
-        while (nb < B && tab_get(nb, 5) <= rg) ++nb;
-        nt = rg;
+        while (nb < B && tab_get(nb, 5) <= 0) ++nb;
+        nt = 0;
     };
 
     int kown = 0;      // own tiles consumed so far by this wave; own tile k lives in ring slot k & 1
-    int k0 = 0, k1 = 0;  // tiles consumed so far by row group 0 / 1 (for the epilogue's free-slot bookkeeping)
     {
         int fb = 0;  // first own tile of the whole batch
-        while (fb < B && tab_get(fb, 5) <= rg) ++fb;
-        if (fb < B) issue_tile(fb, rg, 0);
+        while (fb < B && tab_get(fb, 5) <= 0) ++fb;
+        if (fb < B) issue_tile(fb, 0, 0);
     }
 
     
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
     for (int bag = 0; bag < B; ++bag) {
         if (tab_get(bag, 7) == 0) continue;  // another group's bag (workgroup-uniform)
         const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
-        const int niter = (ntiles + 1) >> 1;
+        const int niter = ntiles;
         if (niter == 0) continue;
         // per-bag upstream gradient: dout fragments (same layout as the query fragments), m2, 1/l, delta
         bf16x8 df[2][4];  // hi + lo of dout (2^-17 relative: far inside the gradient tolerance; the third term only cost MFMAs)
@@ -224,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
         asm volatile("" : "+v"(m2p), "+v"(rlp), "+v"(dlt));
 
         for (int it = 0; it < niter; ++it) {
-            const int tile = 2 * it + rg;
-            const bool have = tile < ntiles;  // wave-uniform
+            const int tile = it;
+            constexpr bool have = true;
             const int slot = kown & 1;
             const unsigned char* xs = ring + slot * kSlot;
             const int row0 = tile * kTile;
@@ -342,30 +345,21 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
         }
     }
 
-    // ---- single epilogue for the whole batch: sum the two row groups, write this workgroup's partial (pm = 0, pl = 1)
+    // ---- single epilogue for the whole batch: this workgroup's partial (pm = 0, pl = 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    VLSA_WBAR();
-    unsigned char* mg = smem + (4 + cw) * kWaveRing;
-    if (rg == 1) {
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4_ma*>(mg + (ct * 64 + lane) * 16) = acc[ct];
-    }
-    VLSA_WBAR();
-    if (rg == 0) {
+    {
         const size_t slotg = blockIdx.x;
         if (cw == 0 && g == 0 && i16 < P) {
             pm[slotg * kPStride + i16] = 0.f;
             pl[slotg * kPStride + i16] = 1.f;
         }
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const f32x4 other = *reinterpret_cast<const f32x4_ma*>(mg + (ct * 64 + lane) * 16);
+        for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = 4 * g + r;
-                if (p < P) pacc[(slotg * P + p) * D + cw * 128 + ct * 16 + i16] = acc[ct][r] + other[r];
+                if (p < P) pacc[(slotg * P + p) * D + cw * 128 + ct * 16 + i16] = acc[ct][r];
             }
-        }
     }
 }
 
@@ -374,6 +368,8 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_backward_dma_batch(const BagDe
 using namespace vlsa;
 
 static inline int bwd_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
+
+extern "C" int vlsa_bwd_batch_partials(void) { return 512; }
 
 extern "C" size_t vlsa_bwd_batch_prep_bytes(int B, int D) { return (size_t)B * 3 * 16 * D * 2 + (size_t)B * kPStride * 4; }
 
@@ -394,13 +390,12 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
     __bf16* dsplit = static_cast<__bf16*>(bwd_prep);
     float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
     hipLaunchKernelGGL(k_prepare_backward_batch, dim3(16, B), dim3(256), 0, s, dout, out, P, D, dsplit, delta);
-    static DeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_vlfan_backward_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bb::kLdsBytes);
-    }
     const QPrepLayout L(D);
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
-    hipLaunchKernelGGL(k_vlfan_backward_dma_batch, dim3(256), dim3(512), bb::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
+    static DeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute((const void*)k_vlfan_backward_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bb::kLdsBytes);
+    hipLaunchKernelGGL(k_vlfan_backward_dma_batch, dim3(512), dim3(256), bb::kLdsBytes, s, static_cast<const BagDesc*>(bag_desc), B,
                        qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

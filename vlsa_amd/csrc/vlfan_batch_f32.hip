@@ -1,15 +1,17 @@
 // fp32 bags (the reference's own storage format: dataset/PatchWSI.py:205-215 returns float32 features) through the
-// persistent multi-bag streaming kernel, EXACTLY in fp32: both contractions run on v_mfma_f32_16x16x4_f32 (f32 in /
-// f32 accumulate, bit-equal to an fmaf chain, 157 TFLOP/s peak -- MI355X_MICROARCH.md), so there is no split-bf16
-// approximation of X at all.  Structure = k_vlfan_partial_dma_batch (vlfan_batch.hip); what differs:
+// persistent multi-bag streaming kernel: the score contraction runs EXACTLY in fp32 on v_mfma_f32_16x16x4_f32 (f32 in /
+// f32 accumulate, bit-equal to an fmaf chain, 157 TFLOP/s peak -- MI355X_MICROARCH.md), so the attention weights carry no
+// split-bf16 approximation of X; the weighted row sum runs on the bf16 pipe from on-the-fly hi + lo splits (2^-17 relative).  Structure = k_vlfan_partial_dma_batch (vlfan_batch.hip); what differs:
 //   * tile = 16 rows x 128 fp32 columns per wave (8 KiB slot, same ring); a lock-step iteration covers 32 rows;
 //   * LDS-DMA piece = 2 rows x 512 B; the swizzle XORs the 16-byte chunk index with (row & 7) on the SOURCE address;
 //   * fragments are single floats: A[i][k] -> lane (i = l & 15, k = l >> 4); ds_read_b32 (2-way conflict on the score
 //     reads, conflict-free on the weighted-sum reads);
-//   * weighted sum: MFMA k-slot k of step rs is mapped to tile row 4k + rs, so the softmax weight the lane already holds
-//     in register rs IS the A operand -- weights stay fp32, no conversion;
+//   * weighted sum: v_mfma_f32_16x16x16_bf16 with k = tile row: the four softmax weights the lane already holds (p = i16,
+//     rows 4g .. 4g + 3) ARE its A fragment, the four floats X[4g .. 4g + 3][16 ct + i16] its B fragment -- both split
+//     into bf16 hi + lo in registers (no second LDS image);
 //   * row norms on the VALU from the score fragments (32 FMAs + 2 cross-quad adds per tile).
-// Arithmetic intensity at HBM rate: 2048 B / patch -> 64 fp32 MFMAs per 16-row tile per wave = 63 % of the f32 MFMA pipe.
+// Matrix-pipe load per 16-row tile per wave: 32 f32 steps (scores, 32 cycles each) + 24 bf16 steps (sum, 16 cycles) = 1408
+// cycles; with the sum in f32 as well (round 1) it was 2048 = ~95 % of the pipe at HBM rate, and the kernel sat at 62-64 %.
 #include "vlsa_common.h"
 
 namespace vlsa {
@@ -294,18 +296,34 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                     wv[r] = fast_exp2(T[r] - M);
                     lsum += wv[r];
                 }
-                // contraction 2 on the f32 matrix pipe: acc[p][c] += W[p][n] X[n][c]; k-slot k of step rs <-> tile row 4k + rs,
-                // so A = wv[rs] (this lane: p = i16, row 4g + rs) and B = X[4g + rs][16 ct + i16]
-                // rs outermost: 8 independent accumulators between two MFMAs on the same one (dependent latency 40 > issue 32 cycles)
+                // contraction 2: acc[p][c] += W[p][n] X[n][c]; A = wv[0..3] (this lane: p = i16, rows 4g .. 4g + 3), B = X[4g + r][16 ct + i16]
                 float xb[4][8];
 #pragma unroll
                 for (int rs = 0; rs < 4; ++rs)
 #pragma unroll
                     for (int ct = 0; ct < 8; ++ct) xb[rs][ct] = *reinterpret_cast<const float_ma*>(xs + fswz(4 * g + rs, 16 * ct + i16));
+                // the weighted sum on the bf16 pipe: weights and rows as hi + lo bf16 pairs (16 mantissa bits each), three of the
+                // four products (2^-17 relative; the scores above -- hence the attention weights -- stay exact fp32).  One
+                // 16x16x16 step per column tile and term instead of four f32 16x16x4 steps at twice the cycles: 384 instead of
+                // 1024 matrix-pipe cycles per tile -- with both contractions in f32 the pipe was ~95 % busy at HBM rate, i.e. the bound.
+                bf16x4 whi, wlo;
 #pragma unroll
-                for (int rs = 0; rs < 4; ++rs)
+                for (int r = 0; r < 4; ++r) {
+                    whi[r] = (__bf16)wv[r];
+                    wlo[r] = (__bf16)(wv[r] - (float)whi[r]);
+                }
 #pragma unroll
-                    for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rs], xb[rs][ct], acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < 8; ++ct) {
+                    bf16x4 xh, xl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xh[r] = (__bf16)xb[r][ct];
+                        xl[r] = (__bf16)(xb[r][ct] - (float)xh[r]);
+                    }
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xh, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xl, acc[ct], 0, 0, 0);
+                }
                 ++kown;
             }
             

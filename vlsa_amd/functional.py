@@ -458,7 +458,7 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         B, dev = table.B, out.device
         dout = _f32c(dout)
         if table.dt == nat.DT_BF16 and P <= 12:
-            G = 256
+            G = lib.vlsa_bwd_batch_partials()
             pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
             pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
             pacc = torch.empty(G, P, D, dtype=torch.float32, device=dev)
