@@ -204,11 +204,22 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         float M = -INFINITY, lsum = 0.f;
-        float* srow = nullptr;   // kScores: this lane's query row of the bag's score matrix, at this workgroup's first row
+        // kScores: the score store is transposed across the wave so that ONE instruction writes whole 128-byte lines: lane l of
+        // wave cw (0 / 1) stores rows 4 (l & 7) .. + 3 of the tile for query 8 cw + (l >> 3) -- 8 lanes x 16 B = the 32 rows of a
+        // query, contiguous -- as ordinary write-back stores: the lines are complete, so L2 takes them without a fill, and the
+        // in-place normalise launch that follows finds part of them still cached.  (Round-2 history: the lane's own f32x4 put
+        // the two 64-byte halves of every line into different waves' stores, and nontemporal stores were the lesser evil:
+        // 62.9 % of the 1072 B/patch roofline; whole lines + write-back: 65.7-68.5 %.  Deferring the store behind the next tile's
+        // DMA -- vmcnt retires in order -- changed nothing.  What remains is traffic, not stalls: scores out, scores in, A out
+        // = 144 B/patch really move where the roofline counts 48.)
+        float* srow = nullptr;   // this lane's store address for tile row 0 of the workgroup's range
+        bool has_scores = false; // wave-uniform: this bag stores scores and this wave is one of the two that do
         if constexpr (kScores) {
             const unsigned long long sp = (unsigned long long)(unsigned int)tab_get(bag, 8) |
                                           ((unsigned long long)(unsigned int)tab_get(bag, 9) << 32);
-            if (sp != 0 && cw < 2 && i16 < P) srow = reinterpret_cast<float*>(sp) + (size_t)i16 * tab_get(bag, 10) + 16 * cw + 4 * g;
+            const int sp_q = 8 * cw + (lane >> 3);
+            has_scores = sp != 0 && cw < 2 && 8 * cw < P;
+            if (has_scores && sp_q < P) srow = reinterpret_cast<float*>(sp) + (size_t)sp_q * tab_get(bag, 10) + 4 * (lane & 7);
         }
 
         for (int it = 0; it < niter; ++it) {
@@ -300,7 +311,20 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                             if (row0 + 16 * h + 4 * g + r >= nrows) T[h][r] = -INFINITY;
                 }
                 if constexpr (kScores) {  // the four column-quarter waves hold identical scores: waves cw = 0 / 1 store half h = cw
-                    if (srow != nullptr) __builtin_nontemporal_store(cw == 0 ? T[0] : T[1], reinterpret_cast<f32x4*>(srow + row0));   // written once, read once by the normalise launch
+                    if (has_scores) {
+                        // value of (query q, rows 16 h + 4 gs ..) lives in lane 16 gs + q, register T[h]
+                        const int c = lane & 7;
+                        const int src = (16 * (c & 3) + ((8 * cw + (lane >> 3)) & 15)) << 2;
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t0 = T[0][r], t1 = T[1][r];   // (no __builtin_bit_cast on the vector element itself: hipcc 7.0 then reads element 0 for every r)
+                            const float a0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(t0)));
+                            const float a1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(t1)));
+                            v[r] = (c & 4) ? a1 : a0;
+                        }
+                        if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = v;
+                    }
                 }
                 const float tmax = fmaxf(fmaxf(fmaxf(T[0][0], T[0][1]), fmaxf(T[0][2], T[0][3])),
                                          fmaxf(fmaxf(T[1][0], T[1][1]), fmaxf(T[1][2], T[1][3])));
