@@ -293,6 +293,20 @@ int vlsa_colmax(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, float
 int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const float* b1, const float* bg,
                      const float* w2, const float* b2, float* a, void* stream);
 
+/*
+ * Feat_Projecter over all N patch rows of a bag: Y = LayerNorm(X W^T + b) * gamma + beta, W [512, 512]
+ * (reference model/layers.py:65-82, applied by the encoders when use_feat_proj=True: model/deepmil.py:176-179,267-268).
+ * vlsa_prepare_featproj packs the weights (bf16 hi + lo split, MFMA fragment order) into `prep`
+ * (vlsa_featproj_prep_bytes() bytes) once per parameter version; vlsa_feat_project runs ONE kernel per bag: X bf16 or fp32
+ * [N, ldx] (16-byte aligned rows), Y fp32 [N, ldy]; eps = the LayerNorm epsilon.  dim_in = dim_out = D = 512
+ * (VLSA_EUNSUPPORTED otherwise: run the two torch modules).  b / gamma / beta may be NULL (0 / 1 / 0).
+ */
+size_t vlsa_featproj_prep_bytes(void);
+int vlsa_prepare_featproj(const float* W, const float* b, const float* gamma, const float* beta, int dim_in, int dim_out,
+                          void* prep, void* stream);
+int vlsa_feat_project(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
+                      int64_t ldy, void* stream);
+
 /* Replaces forward_query_pooling with query_pooling = 'attention' | 'gated_attention' (model/deepmil.py:101-105,133-150: the
  * ABMIL modules of model/layers.py:85-153 applied to the P aggregated rows) for B bags in two launches: rows [B, P, D] ->
  * pooled [B, D] = softmax_P(a) @ rows, a_p = w2 . (tanh(Wa r_p + ba) [* sigmoid(Wg r_p + bg)]) + c; scores [B, P] (nullable) = a

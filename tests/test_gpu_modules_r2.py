@@ -73,9 +73,12 @@ def test_feat_projecter_forward_and_gradients(case):
         _load_pool(enc.sigma, cases.make_pool_params(pooling, seed + 3000), pooling)
     model = model.cuda().eval()
     Xd = X[None].cuda()
-    with torch.no_grad():                      # inference: projecter by torch, aggregation by the HIP kernels
+    with torch.no_grad():                      # inference: projecter (vlsa_feat_project) and aggregation by the HIP kernels
         logits, img, _ = model(Xd)
         lb, _, _ = model.forward_bags([Xd, Xd])
+    assert hasattr(enc.feat_proj, "_fused")    # the fused Feat_Projecter kernel ran
+    if enc_name == "VLFAN" and isinstance(pooling, str) and pooling in ("mean", "max"):
+        assert any(isinstance(k, tuple) and k and k[0] == "batch" for k in model._plans)   # ... in front of the batched fused path
     assert np.abs(logits.cpu().numpy() - fx["logits"]).max() < TOL
     assert np.abs(img.cpu().numpy() - fx["image_features"]).max() < 1e-5
     assert np.abs(lb.cpu().numpy() - fx["logits"]).max() < TOL

@@ -156,9 +156,8 @@ class VLFAN(nn.Module):
 
     # -- fused inference support -------------------------------------------------------------------------
     def fused_head_spec(self):
-        """(pool mode, pool weight, W, b) if pooling + adapter can run in the fused HIP head, else None."""
-        if self.feat_proj is not None:
-            return None
+        """(pool mode, pool weight, W, b) if pooling + adapter can run in the fused HIP head, else None.  A Feat_Projecter
+        does not stand in the way: the inference routes project the bag first (``project``: one fused HIP launch per bag)."""
         if isinstance(self.query_pooling, str):
             mode, pw = self.query_pooling, None
         elif isinstance(self.query_pooling, nn.Parameter):
@@ -170,6 +169,14 @@ class VLFAN(nn.Module):
         if isinstance(self.visual_adapter, nn.Linear):
             return mode, pw, self.visual_adapter.weight, self.visual_adapter.bias
         return mode, pw, None, None
+
+    def project(self, X):
+        """The bag as the cross attention sees it: Feat_Projecter(X) when use_feat_proj=True (model/deepmil.py:176-179)."""
+        return X if self.feat_proj is None else self.feat_proj(X)
+
+    def _projecter_trains(self) -> bool:
+        return (self.feat_proj is not None and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.feat_proj.parameters()))
 
     def forward(self, X, ret_with_attn=False):
         assert X.shape[0] == 1
@@ -193,18 +200,22 @@ class VLFAN(nn.Module):
             return visual_features, attn
         return visual_features
 
-    def forward_bags(self, bags, ret_with_attn=False):
+    def forward_bags(self, bags, ret_with_attn=False, projected=False):
         """Differentiable forward over a list of bags (each [1, N_i, C] or [N_i, C]) sharing this encoder: the cross
         attention of all bags runs in the persistent multi-bag kernels (forward and backward), the P x C tail as batched
         torch ops.  Equals ``torch.cat([self(x) for x in bags])``; one training step of the reference
         (runner/vlsa_handler.py:260-289) is 32 such bags.  Returns visual features [B, C]; with ``ret_with_attn`` also the
         per-bag attention exactly as ``forward(x, ret_with_attn=True)`` hands it out: a list of ``A`` [1, P, N_i], or of
-        ``(A, pool_scores)`` when the query pooling is a module (model/deepmil.py:206-215)."""
-        if self.feat_proj is not None:
+        ``(A, pool_scores)`` when the query pooling is a module (model/deepmil.py:206-215).  ``projected``: the bags already
+        went through ``project``."""
+        if self._projecter_trains() or any(torch.is_grad_enabled() and x.requires_grad for x in bags):
+            # gradients have to reach the projecter / the bags: bag by bag through the differentiable torch route of forward()
             rs = [self.forward(x if x.dim() == 3 else x[None], ret_with_attn=ret_with_attn) for x in bags]
             if ret_with_attn:
                 return torch.cat([r[0] for r in rs]), [r[1] for r in rs]
             return torch.cat(rs)
+        if self.feat_proj is not None and not projected:
+            bags = [self.feat_proj(x) for x in bags]          # frozen / inference: one fused HIP launch per bag, fp32 out
         Q = self.get_query()
         scale = float(self.coattn_logit_scale.exp())
         outs, attn = [], []

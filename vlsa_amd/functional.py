@@ -645,6 +645,37 @@ class FusedAttnScores:
         return a
 
 
+class FusedFeatProjecter:
+    """Feat_Projecter (Linear(512, 512) + LayerNorm, model/layers.py:65-82) over all patch rows of a bf16 or fp32 bag in ONE
+    MFMA kernel (vlsa_feat_project): fp32 [N, 512] out, the pre-activations never reach memory.  Holds the weights packed
+    in MFMA-fragment order (bf16 hi + lo split) and re-packs them when a parameter changes.  Inference only (no dX / dW)."""
+
+    def __init__(self):
+        self._key, self._prep = None, None
+
+    @staticmethod
+    def supported(X2: torch.Tensor, linear, norm) -> bool:
+        return (X2.is_cuda and X2.dim() == 2 and X2.dtype in (torch.bfloat16, torch.float32) and X2.shape[0] > 0
+                and linear.in_features == 512 and linear.out_features == 512 and tuple(norm.normalized_shape) == (512,))
+
+    def __call__(self, X2: torch.Tensor, W, b, gamma, beta, eps: float) -> torch.Tensor:
+        lib = nat.load()
+        X2 = _bag2d(X2)
+        params = [t for t in (W, b, gamma, beta) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in params) + (X2.device,)
+        if key != self._key:
+            prep = torch.empty(lib.vlsa_featproj_prep_bytes(), dtype=torch.uint8, device=X2.device)
+            keep = [None if t is None else _f32c(t).reshape(-1) for t in (W, b, gamma, beta)]
+            nat.check(lib.vlsa_prepare_featproj(*[_p(t) for t in keep], W.shape[1], W.shape[0], _p(prep), _stream()),
+                      "vlsa_prepare_featproj")
+            self._key, self._prep = key, prep
+        N = X2.shape[0]
+        Y = torch.empty(N, 512, dtype=torch.float32, device=X2.device)
+        nat.check(lib.vlsa_feat_project(_p(X2), _dt(X2), N, X2.stride(0), 512, _p(self._prep), float(eps), _p(Y), 512, _stream()),
+                  "vlsa_feat_project")
+        return Y
+
+
 def topk_mean(S: torch.Tensor, k: int, out_scale: float = 1.0) -> torch.Tensor:
     """Per-class mean of the k largest entries of S[C, N] (k >= N: plain mean), times out_scale."""
     _need_gpu(S)

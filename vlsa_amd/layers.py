@@ -30,7 +30,22 @@ class Feat_Projecter(nn.Module):
         super().__init__()
         self.projecter = nn.Sequential(nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
 
+    def _needs_autograd(self, x) -> bool:
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, x):
+        lin, norm = self.projecter[0], self.projecter[1]
+        if x.is_cuda and x.dim() in (2, 3) and not self._needs_autograd(x):
+            # inference on the device: ONE fused HIP kernel per bag (vlsa_feat_project), fp32 out for bf16 or fp32 bags
+            from . import functional as VF
+            x2 = x.reshape(-1, x.shape[-1])
+            if VF.FusedFeatProjecter.supported(x2, lin, norm) and norm.elementwise_affine:
+                if not hasattr(self, "_fused"):
+                    self._fused = VF.FusedFeatProjecter()
+                y = self._fused(x2, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps)
+                return y.reshape(*x.shape[:-1], 512)
+        if x.dtype != lin.weight.dtype:
+            x = x.to(lin.weight.dtype)          # bf16 bags of the resident arena: the modules compute in the parameters' dtype
         if x.dim() == 3:
             b, n, d = x.shape
             return self.projecter(x.reshape(-1, d)).reshape(b, n, -1)

@@ -148,6 +148,7 @@ class VLSA(nn.Module):
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         if spec is None or X.dim() != 3 or X.shape[0] != 1 or not X.is_cuda or X.shape[1] == 0:
             return None
+        X = enc.project(X)          # use_feat_proj=True: the fused Feat_Projecter launch first (no grad is needed here)
         mode, pw, W, b = spec
         X2 = VF._bag2d(X)
         N, D = X2.shape
@@ -254,6 +255,11 @@ class VLSA(nn.Module):
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
         flat = [VF._bag2d(x) for x in bags]
+        projected = False
+        if (getattr(enc, "feat_proj", None) is not None and isinstance(enc, (VLFAN, mil_encoders.DeepMIL)) and len(flat) > 0
+                and all(x.is_cuda and x.shape[0] > 0 for x in flat)):
+            flat = [enc.feat_proj(x) for x in flat]    # use_feat_proj=True: one fused HIP launch per bag, fp32 [N, 512] out
+            projected = True
         ok = (spec is not None and spec[0] != "module" and len(flat) > 0
               and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat))
         if not ok:
@@ -261,14 +267,14 @@ class VLSA(nn.Module):
                     and flat[0].dtype in (torch.bfloat16, torch.float32))
             if same and isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max") and text_features.shape[0] <= 64:
                 return self._forward_bags_zeroshot(flat, text_features)
-            if same and isinstance(enc, mil_encoders.DeepMIL) and enc.feat_proj is None:
+            if same and isinstance(enc, mil_encoders.DeepMIL) and (enc.feat_proj is None or projected):
                 return self._forward_bags_deepmil(flat, text_features)
-            if (isinstance(enc, VLFAN) and enc.feat_proj is None and len(flat) > 0
+            if (isinstance(enc, VLFAN) and (enc.feat_proj is None or projected) and len(flat) > 0
                     and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)):
                 # pooling over the queries by a module (attention / gated attention): batched HIP aggregation, then the
                 # module, the adapter and the cosine logits as batched torch ops on [B, P, 512]
                 That = F.normalize(text_features, dim=-1)
-                feats = F.normalize(enc.forward_bags(flat), dim=-1)
+                feats = F.normalize(enc.forward_bags(flat, projected=projected), dim=-1)
                 return self.logit_scale.exp() * feats @ That.t(), feats, That
             outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), outs[0][2]
