@@ -15,6 +15,7 @@ def timeit(f, reps=100):
     return (time.perf_counter() - t0) / reps * 1e6
 T = torch.randn(K, 512)
 for dt in (torch.bfloat16, torch.float32):
+    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
     X = torch.randn(1, n, 512, device=dev).to(dt)
     rows = []
     for qp in ("mean", "max", "weight", "attention", "gated_attention"):

@@ -5,6 +5,7 @@ import torch
 from vlsa_amd import functional as F
 dev = "cuda"
 for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
+    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
     bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(8)]
     Q = torch.randn(12, 512, device=dev, requires_grad=True)
     G = torch.randn(12, 512, device=dev)
@@ -21,6 +22,7 @@ for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (10000, torch.flo
 
 # 32 bags per optimizer step through the persistent batch kernels (forward + backward)
 for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (10000, torch.float32)):
+    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
     base = torch.randn(32 * n + 4096, 512, device=dev).to(dt)
     bags = [base[i * n:(i + 1) * n] for i in range(32)]
     Q = torch.randn(12, 512, device=dev, requires_grad=True)

@@ -9,6 +9,7 @@ for pooling in ("logit_mean", "logit_max", "logit_top10"):
     cfg = dict(name="FeatMIL", dim_in=512, pooling=pooling)
     net = VLSA(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
     for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (2798, torch.float32)):
+        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
         bags = [torch.randn(1, n, 512, device=dev).to(dt) for _ in range(8)]
         with torch.no_grad():
             for i in range(40): net(bags[i % 8])

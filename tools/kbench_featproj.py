@@ -21,6 +21,7 @@ def timed(fn, reps=50):
 
 
 for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
+    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
     X = torch.randn(n, 512, device=dev).to(dt)
     with torch.no_grad():
         t_hip = timed(lambda: m(X))

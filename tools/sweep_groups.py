@@ -8,6 +8,7 @@ Q = torch.randn(12, 512, device=dev); T = torch.randn(4, 512, device=dev)
 W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)
 for dt in (torch.bfloat16, torch.float32):
     for n, B in ((2798, 64), (2798, 32), (10000, 32), (20000, 32), (50000, 32)):
+        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
         if dt == torch.float32 and n == 50000:
             B = 16
         base = torch.randn(B * n, 512, device=dev).to(dt)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                                                                      const float* __restrict__ qeff, const float* __restrict__ qmeta, int P,
                                                                      float* __restrict__ pm, float* __restrict__ pl,
                                                                      float* __restrict__ pacc, int S,
-                                                                     const RowsDesc* __restrict__ sdesc) {
+                                                                     const RowsDesc* __restrict__ sdesc, const BagDesc one) {
     using namespace bf;
     constexpr int D = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
 
     // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
     if (tid < B) {
-        const BagDesc d = bags[tid];
+        const BagDesc d = bags ? bags[tid] : one;   // bags == null: ONE bag, described in the kernel arguments (single-slide calls)
         // 32-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
         // unit rotates with the bag index so that the extra iterations even out over the batch
         const unsigned long long units = (unsigned long long)((d.N + 31) >> 5);
@@ -411,10 +411,23 @@ int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff
     if (scores_desc)
         hipLaunchKernelGGL(k_vlfan_partial_f32_batch<true>, dim3(workgroups), dim3(512), bf::kLdsBytes, s,
                            static_cast<const BagDesc*>(bag_desc), B, qeff, qmeta, P, pm, pl, pacc, S,
-                           static_cast<const RowsDesc*>(scores_desc));
+                           static_cast<const RowsDesc*>(scores_desc), BagDesc{nullptr, 0, 0});
     else
         hipLaunchKernelGGL(k_vlfan_partial_f32_batch<false>, dim3(workgroups), dim3(512), bf::kLdsBytes, s,
                            static_cast<const BagDesc*>(bag_desc), B, qeff, qmeta, P, pm, pl, pacc, S,
-                           static_cast<const RowsDesc*>(nullptr));
+                           static_cast<const RowsDesc*>(nullptr), BagDesc{nullptr, 0, 0});
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// ONE fp32 bag through the same kernel (the drop-in's bag-by-bag calls, runner/vlsa_handler.py:322-330): G workgroups, G partials
+// in the layout of the single-bag kernels (pm / pl [G, 16], pacc [G, P, 512]); the bag is described in the kernel arguments, so
+// no descriptor table has to be uploaded.  No score output (its rows would need the padded pitch of vlsa_rows_desc).
+int vlsa_launch_partial_f32_one(const float* X, int64_t N, int64_t ldx, const float* qeff, const float* qmeta, int P, float* pm,
+                                float* pl, float* pacc, int G, hipStream_t s) {
+    static DeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute((const void*)k_vlfan_partial_f32_batch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bf::kLdsBytes);
+    hipLaunchKernelGGL(k_vlfan_partial_f32_batch<false>, dim3(G), dim3(512), bf::kLdsBytes, s, static_cast<const BagDesc*>(nullptr), 1,
+                       qeff, qmeta, P, pm, pl, pacc, 1, static_cast<const RowsDesc*>(nullptr), BagDesc{X, N, ldx});
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

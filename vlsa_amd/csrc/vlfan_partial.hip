@@ -503,6 +503,9 @@ static int launch_mfma(const XT* X, int64_t N, int64_t ldx, const __bf16* qsplit
 int vlsa_launch_partial_dma(const __bf16* X, int64_t N, int64_t ldx, const __bf16* qsplit_scaled, int P, float* pm,
                             float* pl, float* pacc, float* scores, int G, hipStream_t s);
 
+int vlsa_launch_partial_f32_one(const float* X, int64_t N, int64_t ldx, const float* qeff, const float* qmeta, int P, float* pm,
+                                float* pl, float* pacc, int G, hipStream_t s);  // vlfan_batch_f32.hip
+
 extern "C" int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep,
                                   int P, int kernel, float* pm, float* pl, float* pacc, float* scores,
                                   void* stream) {
@@ -514,6 +517,7 @@ extern "C" int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t
     const int G = vlsa_num_partials(N);
     // the DMA kernel addresses a workgroup's rows through a 32-bit buffer descriptor
     const bool dma_ok = D == 512 && x_dtype == VLSA_DT_BF16 && ((N / G + 64) * ldx * 2) < (int64_t)0x7fff0000;
+    const bool auto_kernel = kernel == VLSA_KERNEL_AUTO;
     if (kernel == VLSA_KERNEL_AUTO)
         kernel = (D != 512) ? VLSA_KERNEL_GENERIC : (dma_ok ? VLSA_KERNEL_DMA : VLSA_KERNEL_MFMA);
     if (kernel == VLSA_KERNEL_MFMA && D != 512) return VLSA_EUNSUPPORTED;
@@ -523,6 +527,10 @@ extern "C" int vlsa_vlfan_partial(const void* X, int x_dtype, int64_t N, int64_t
     const unsigned char* qp = static_cast<const unsigned char*>(qprep);
     hipStream_t s = (hipStream_t)stream;
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(qp + L.qsplit);
+    if (auto_kernel && x_dtype == VLSA_DT_F32 && D == 512 && !scores && N > 0 && ((N / G + 64) * ldx * 4) < (int64_t)0x7fff0000)
+        // fp32 rows without a score output: the exact-f32 LDS-DMA streaming kernel of the batched path with one bag (vlfan_batch_f32.hip)
+        return vlsa_launch_partial_f32_one((const float*)X, N, ldx, reinterpret_cast<const float*>(qp + L.qeff),
+                                           reinterpret_cast<const float*>(qp + L.qnorm), P, pm, pl, pacc, G, s);
     if (kernel == VLSA_KERNEL_DMA)
         return vlsa_launch_partial_dma((const __bf16*)X, N, ldx, qsplit, P, pm, pl, pacc, scores, G, s);
     if (kernel == VLSA_KERNEL_MFMA) {
