@@ -294,6 +294,20 @@ int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const 
                      const float* w2, const float* b2, float* a, void* stream);
 
 /*
+ * The DeepMIL encoder's N-sized part for a BATCH of bags (the reference's evaluation loop is encoder-agnostic,
+ * runner/vlsa_handler.py:315-345; model/deepmil.py:261-292 per bag): ONE launch for the raw (gated-)attention scores of all
+ * bags (vlsa_gated_scores_batch; weights packed by vlsa_prepare_gated_weights) and ONE for the softmax-weighted row sums
+ * (vlsa_scored_pool_partial_batch -> G partials per bag in the P = 1 partial layout, folded by vlsa_vlfan_merge_batch_strided).
+ * bag_desc: device table of vlsa_bag_desc; B <= 64; D == 512; bf16 or fp32 bags (one dtype per batch).
+ *   tile_start [B + 1] int32 (device): first row tile of every bag for tiles of rows_per_tile rows (multiple of 16, <= 256, <= 128
+ *   for gated fp32 bags); n_tiles = tile_start[B].   a: all bags' scores, bag b at a + a_off[b] (int64, device), a_floats long.
+ */
+int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
+                            int n_tiles, int rows_per_tile, float* a, const int64_t* a_off, int64_t a_floats, void* stream);
+int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const float* scores, const int64_t* a_off,
+                                   int G, float* pm, float* pl, float* pacc, void* stream);
+
+/*
  * Feat_Projecter over all N patch rows of a bag: Y = LayerNorm(X W^T + b) * gamma + beta, W [512, 512]
  * (reference model/layers.py:65-82, applied by the encoders when use_feat_proj=True: model/deepmil.py:176-179,267-268).
  * vlsa_prepare_featproj packs the weights (bf16 hi + lo split, MFMA fragment order) into `prep`

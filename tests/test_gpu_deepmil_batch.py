@@ -1,0 +1,69 @@
+"""DeepMIL over a BATCH of bags: one score launch (vlsa_gated_scores_batch) + one pooling launch
+(vlsa_scored_pool_partial_batch) per <= 64 bags vs the CPU oracle's restatement of model/layers.py:103-122 / 137-153 per bag
+(pinned to the reference by the deepmil_dm_* fixtures, which tests/test_gpu_batch_attn.py replays through forward_bags)."""
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _weights(seed, gated, scale=3.0):
+    g = cases.gen(seed)
+    u = lambda *s, b: (torch.rand(*s, generator=g) * 2 - 1) * b  # noqa: E731
+    Wa, ba = u(256, 512, b=scale / 512 ** 0.5), u(256, b=0.05)
+    Wg, bg = (u(256, 512, b=scale / 512 ** 0.5), u(256, b=0.05)) if gated else (None, None)
+    return Wa, ba, Wg, bg, u(1, 256, b=1 / 16), u(1, b=0.06)
+
+
+def _oracle(X, W):
+    from oracle import vlsa_oracle as O
+    Wa, ba, Wg, bg, w2, c = W
+    if Wg is not None:
+        return O.gated_attention_pooling(X, Wa, ba, Wg, bg, w2, c)[:2]      # (pooled [d], raw scores [n])
+    return O.attention_pooling(X, Wa, ba, w2, c)[:2]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("sizes", [[5000, 64, 2798, 33, 1, 4097], [300], [63, 65, 127, 129, 8192, 31, 32, 10_000, 17],
+                                   [50_001, 20_000, 257, 40_000]])
+def test_pool_bags_vs_oracle(sizes, gated, dtype):
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    bags = [cases.make_bag(n, 6000 + i + n, "clustered" if i % 2 else "iid").to(dtype) for i, n in enumerate(sizes)]
+    W = _weights(6100 + len(sizes), gated)
+    fs = F.FusedAttnScores()
+    Wd = [None if t is None else t.to(dev) for t in W]
+    dbags = [x.to(dev) for x in bags]
+    for _ in range(2):                                        # second call: packed weights and staging buffer re-used
+        pooled, a, offs = fs.pool_bags(dbags, *Wd)
+    torch.cuda.synchronize()
+    assert pooled.shape == (len(sizes), 512) and a.shape == (sum(sizes),)
+    for i, x in enumerate(bags):
+        ref_pooled, ref_a = _oracle(x.float(), W)
+        got_a = a[offs[i]:offs[i + 1]].cpu()
+        assert (got_a - ref_a.reshape(-1)).abs().max().item() < TOL, (i, sizes[i])
+        assert (pooled[i].cpu() - ref_pooled.reshape(-1)).abs().max().item() < TOL, (i, sizes[i])
+        single = fs(dbags[i], *Wd)                            # the single-bag launch computes the same scores
+        assert (single.cpu() - got_a).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("pooling", ["attention", "gated_attention", "mean", "max"])
+def test_deepmil_forward_bags_equals_per_bag_forward(pooling):
+    from vlsa_amd.vlsa import VLSA
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25, pooling=pooling,
+               pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
+    model = VLSA(cfg, pretrained_text_features=torch.randn(4, 512), logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
+    sizes = [700 + 37 * i for i in range(70)]                 # > 64 bags: two chunks
+    bags = [cases.make_bag(n, 6200 + i, "clustered").to(torch.bfloat16).to(dev) for i, n in enumerate(sizes)]
+    with torch.no_grad():
+        logits, feats, _ = model.forward_bags(bags)
+        for i in (0, 1, 63, 64, 69):
+            lg, ft, _ = model(bags[i][None])
+            assert (logits[i] - lg[0]).abs().max().item() < 5e-5
+            assert (feats[i] - ft[0]).abs().max().item() < 1e-5

@@ -17,5 +17,14 @@ for pooling, branches in (("attention", 1), ("gated_attention", 2)):
             for i in range(200): m(bags[i % 8])
             torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 200 * 1e6
+        # the same encoder over 32 bags per call: one score launch + one pooling launch (DeepMIL.pool_bags) + batched head
+        flat = [b[0] for b in (bags * 4)]
+        with torch.no_grad():
+            for i in range(5): m.visual_adapter(m.pool_bags(flat))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(20): m.visual_adapter(m.pool_bags(flat))
+            torch.cuda.synchronize()
+        usb = (time.perf_counter() - t0) / 20 / 32 * 1e6
         fl = 2.0 * n * 512 * 256 * branches
-        print(f"{pooling:16s} N={n:6d} {str(dt)[6:]:9s}: {us:8.1f} us/bag  {n / us:8.1f} M patches/s  projections {fl / us / 1e6:7.1f} TFLOP/s")
+        print(f"{pooling:16s} N={n:6d} {str(dt)[6:]:9s}: {us:8.1f} us/bag  {n / us:8.1f} M patches/s  projections {fl / us / 1e6:7.1f} TFLOP/s   pool_bags(32) {usb:7.2f} us/bag ({fl / usb / 1e6:6.1f} TFLOP/s)")

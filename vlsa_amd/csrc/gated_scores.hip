@@ -129,10 +129,23 @@ __device__ __forceinline__ float row16_sum(float v) {
 // memory, no library GEMM.  (XF32 always takes the two-deep weight ring: 256-register budget.)
 // RT = row tiles of 16 patches per workgroup (16; 8 for gated fp32 bags: 64 instead of 128 accumulator registers leave room for
 // the fp32 staging registers -- with 16 the kernel spilled).
+// Several bags per launch (the DeepMIL encoder over a batch of slides, runner/vlsa_handler.py:315-345): bags != null, row tile
+// t of the launch belongs to the bag b with tile_start[b] <= t < tile_start[b + 1]; its scores go to a_out + a_off[b].
+struct GsBag {
+    const void* X;
+    long long N, ldx;
+};
+struct GsBatch {
+    const GsBag* bags;
+    const int* tile_start;      // [B + 1], tile_start[0] = 0
+    const long long* a_off;     // [B] offset (floats) of bag b's scores in a_out
+    int B;                      // <= 64
+};
+
 template <bool GATED, bool FULL, bool XF32, int RT = 16>
 __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
                                                        const unsigned char* __restrict__ prep, float* __restrict__ a_out,
-                                                       int rows_per_tile) {
+                                                       int rows_per_tile, const GsBatch bt) {
     using namespace gs;
     constexpr bool DEEP = FULL && !XF32;   // four-deep weight ring
     constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
@@ -146,7 +159,18 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     // the 256 CUs: a 50k-patch bag runs as 2 x 241 tiles of 208 rows instead of 2 x 196 tiles of 256 (1.5 rounds rounded up)
     // FULL: 256-row tiles, everything static (large bags); otherwise the row-tile count is a run-time, wave-uniform value
     const int nrt = FULL ? RT : (rows_per_tile >> 4);
-    const long long row0 = (long long)(blockIdx.x >> 1) * rows_per_tile;
+    int tile = blockIdx.x >> 1;
+    if (bt.bags != nullptr) {   // one vector load of the (<= 65-entry) tile table + a ballot instead of a dependent scalar search
+        const int ts = lane < bt.B ? bt.tile_start[lane] : 0x7fffffff;
+        const int b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ts <= tile)) - 1;
+        const GsBag bag = bt.bags[b];
+        Xv = bag.X;
+        N = bag.N;
+        ldx = bag.ldx;
+        a_out += bt.a_off[b];
+        tile -= bt.tile_start[b];
+    }
+    const long long row0 = (long long)tile * rows_per_tile;
     const int nrows = (int)((N - row0) < rows_per_tile ? (N - row0) : rows_per_tile);
     const GatedPrepLayout L(GATED ? 1 : 0);
 
@@ -355,16 +379,56 @@ extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile)
+#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0})
     if (f32) {
         if (gated) {
-            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile);
-            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile);
+            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0});
+            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0});
         } else { if (full) VLSA_GS(false, true, true); else VLSA_GS(false, false, true); }
     } else {
         if (gated) { if (full) VLSA_GS(true, true, false); else VLSA_GS(true, false, false); }
         else       { if (full) VLSA_GS(false, true, false); else VLSA_GS(false, false, false); }
     }
 #undef VLSA_GS
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// B bags in ONE launch.  bag_desc: device table of vlsa_bag_desc {X, N, ldx}; tile_start [B + 1] (device, int32): first row tile
+// of every bag for tiles of `rows_per_tile` rows (a multiple of 16, <= 256; <= 128 for gated fp32 bags), n_tiles = tile_start[B];
+// a: one buffer holding all bags' scores, bag b at a + a_off[b] (device, int64), a_floats = its length (zeroed here).
+extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated,
+                                       const int* tile_start, int n_tiles, int rows_per_tile, float* a, const int64_t* a_off,
+                                       int64_t a_floats, void* stream) {
+    if (!bag_desc || !prep || !a || !tile_start || !a_off || B < 1 || B > 64 || n_tiles < 1 || a_floats < 1) return VLSA_EINVAL;
+    if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    const bool f32 = x_dtype == VLSA_DT_F32;
+    const int max_rows = (f32 && gated) ? 128 : gs::kRows;
+    if (rows_per_tile < 16 || rows_per_tile > max_rows || (rows_per_tile % 16)) return VLSA_EINVAL;
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<true, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+        (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(a, 0, (size_t)a_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
+    const bool full = rows_per_tile == max_rows;
+    const unsigned int tiles = (unsigned int)n_tiles * gs::kHalves;
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B};
+#define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
+    if (f32) {
+        if (gated) { if (full) VLSA_GSB(true, true, true, 8); else VLSA_GSB(true, false, true, 8); }
+        else       { if (full) VLSA_GSB(false, true, true, 16); else VLSA_GSB(false, false, true, 16); }
+    } else {
+        if (gated) { if (full) VLSA_GSB(true, true, false, 16); else VLSA_GSB(true, false, false, 16); }
+        else       { if (full) VLSA_GSB(false, true, false, 16); else VLSA_GSB(false, false, false, 16); }
+    }
+#undef VLSA_GSB
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

@@ -80,18 +80,34 @@ __global__ __launch_bounds__(256) void k_scored_pool_partial(const XT* __restric
 // Fast path of the scored pooling (rows 16-byte aligned, D a multiple of the vector width): a lane owns NC chunks of 16
 // bytes of a row (chunk c covers elements [(64 c + lane) VEC, +VEC)), so a wave reads a row with NC fully coalesced
 // 16-byte loads; 4 rows per wave are in flight before the (sequential) online-softmax update.  Same outputs as above.
+// Several bags per launch: grid (G, B); bags != null: workgroup (g, bag) pools rows_of_block(N_bag, g, G) of bag blockIdx.y with
+// the scores at scores + a_off[bag] and writes partial bag * G + g.
+struct PoolBag {
+    const void* X;
+    long long N, ldx;
+};
 template <typename XT, int NC>
 __global__ __launch_bounds__(256) void k_scored_pool_partial_vec(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
                                                                   const float* __restrict__ scores, float* __restrict__ pm,
-                                                                  float* __restrict__ pl, float* __restrict__ pacc, int G) {
+                                                                  float* __restrict__ pl, float* __restrict__ pacc, int G,
+                                                                  const PoolBag* __restrict__ bags,
+                                                                  const long long* __restrict__ a_off) {
     constexpr int VEC = 16 / (int)sizeof(XT);
     constexpr int U = 4;
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (bags != nullptr) {
+        const PoolBag bag = bags[blockIdx.y];
+        X = static_cast<const XT*>(bag.X);
+        N = bag.N;
+        ldx = bag.ldx;
+        if (scores != nullptr) scores += a_off[blockIdx.y];
+    }
     int64_t rbeg, rend;
     rows_of_block(N, b, G, rbeg, rend);
+    b += blockIdx.y * G;   // partial slot
     float acc[NC * VEC], M = -INFINITY, l = 0.f;
 #pragma unroll
     for (int i = 0; i < NC * VEC; ++i) acc[i] = 0.f;
@@ -682,7 +698,8 @@ static int launch_scored(const XT* X, int64_t N, int64_t ldx, int D, const float
 #define VLSA_SPV(NCV)                                                                                                   \
     {                                                                                                                   \
         const size_t lds = (8 + (size_t)4 * NCV * 64 * VEC) * sizeof(float);                                            \
-        hipLaunchKernelGGL((k_scored_pool_partial_vec<XT, NCV>), dim3(G), dim3(256), lds, s, X, N, ldx, D, scores, pm, pl, pacc, G); \
+        hipLaunchKernelGGL((k_scored_pool_partial_vec<XT, NCV>), dim3(G), dim3(256), lds, s, X, N, ldx, D, scores, pm, pl, pacc, G, \
+                           static_cast<const PoolBag*>(nullptr), static_cast<const long long*>(nullptr));                    \
     }
         if (NC == 1) VLSA_SPV(1) else if (NC == 2) VLSA_SPV(2) else if (NC == 3) VLSA_SPV(3) else VLSA_SPV(4)
 #undef VLSA_SPV
@@ -700,6 +717,28 @@ extern "C" int vlsa_scored_pool_partial(const void* X, int x_dtype, int64_t N, i
     if (x_dtype == VLSA_DT_F32) return launch_scored<float>((const float*)X, N, ldx, D, scores, pm, pl, pacc, G, (hipStream_t)stream);
     if (x_dtype == VLSA_DT_BF16) return launch_scored<__bf16>((const __bf16*)X, N, ldx, D, scores, pm, pl, pacc, G, (hipStream_t)stream);
     return VLSA_EINVAL;
+}
+
+// B bags (D = 512, 16-byte aligned rows) in one launch: G partials per bag in the P = 1 layout of the VLFAN partials -- pm / pl
+// [B * G, 16], pacc [B * G, 512] -- to be folded by vlsa_vlfan_merge_batch_strided (softmax-weighted row sum per bag; scores NULL:
+// plain mean).  scores: one buffer, bag b at scores + a_off[b].
+extern "C" int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const float* scores,
+                                              const int64_t* a_off, int G, float* pm, float* pl, float* pacc, void* stream) {
+    if (!bag_desc || !pm || !pl || !pacc || B < 1 || G < 1 || (scores && !a_off)) return VLSA_EINVAL;
+    if (D != 512 || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const PoolBag* bags = static_cast<const PoolBag*>(bag_desc);
+    const long long* off = reinterpret_cast<const long long*>(a_off);
+    if (x_dtype == VLSA_DT_F32) {
+        const size_t lds = (8 + (size_t)4 * 2 * 64 * 4) * sizeof(float);
+        hipLaunchKernelGGL((k_scored_pool_partial_vec<float, 2>), dim3(G, B), dim3(256), lds, s, static_cast<const float*>(nullptr), (int64_t)0,
+                           (int64_t)0, D, scores, pm, pl, pacc, G, bags, off);
+    } else {
+        const size_t lds = (8 + (size_t)4 * 1 * 64 * 8) * sizeof(float);
+        hipLaunchKernelGGL((k_scored_pool_partial_vec<__bf16, 1>), dim3(G, B), dim3(256), lds, s, static_cast<const __bf16*>(nullptr), (int64_t)0,
+                           (int64_t)0, D, scores, pm, pl, pacc, G, bags, off);
+    }
+    return st();
 }
 
 template <typename XT>

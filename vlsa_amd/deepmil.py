@@ -260,6 +260,24 @@ class DeepMIL(nn.Module):
         else:
             self.g = nn.Linear(dim_in, num_cls)
 
+    def pool_bags(self, flat):
+        """Pooled bag vectors [B, C] of a list of validated [N_i, 512] device bags (one dtype) without autograd: the
+        (gated-)attention poolings run as ONE score launch and ONE pooling launch per <= 64 bags when the fused kernel applies
+        (512 -> 256 hidden, no active dropout), otherwise bag by bag.  model/deepmil.py:270-283 per bag."""
+        sg = self.sigma
+        if isinstance(sg, str):
+            return torch.stack([VF.scored_pool(x, None) if sg == "mean" else VF.colmax(x) for x in flat])
+        gated = isinstance(sg, Gated_Attention_Pooling)
+        lin_a = sg.fc1[0] if gated else sg.attention[0]
+        if (not (gated and sg.training and sg.fc1[2].p > 0) and len(flat) > 0
+                and all(VF.FusedAttnScores.supported(x, lin_a.in_features, lin_a.out_features) for x in flat)):
+            if not hasattr(self, "_fused_scores"):
+                self._fused_scores = VF.FusedAttnScores()
+            w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
+                 (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
+            return torch.cat([self._fused_scores.pool_bags(flat[i:i + 64], *w)[0] for i in range(0, len(flat), 64)])
+        return torch.stack([VF.scored_pool(x, self._attention_scores(x)) for x in flat])
+
     def _attention_scores(self, X2):
         """raw scores a[N] of the pooling module on all patches: hidden projections by rocBLAS, the rest in HIP when
         no autograd graph is needed (else torch elementwise ops so the pooling parameters get gradients)."""

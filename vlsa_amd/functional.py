@@ -626,18 +626,82 @@ class FusedAttnScores:
         return (X2.is_cuda and X2.dtype in (torch.bfloat16, torch.float32) and dim_in == 512 and dim_hid == 256
                 and X2.shape[0] > 0)
 
-    def __call__(self, X2, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
+    def _packed(self, device, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
         lib = nat.load()
         gated = Wg is not None
         params = [t for t in (Wa, ba, Wg, bg, w2, c) if t is not None]
         key = tuple((t.data_ptr(), t._version) for t in params)
         if key != self._key:
-            prep = torch.empty(lib.vlsa_gated_prep_bytes(int(gated)), dtype=torch.uint8, device=X2.device)
+            prep = torch.empty(lib.vlsa_gated_prep_bytes(int(gated)), dtype=torch.uint8, device=device)
             f = lambda t: None if t is None else _f32c(t).reshape(-1)  # noqa: E731
             keep = [f(t) for t in (Wa, ba, Wg, bg, w2, c)]
             nat.check(lib.vlsa_prepare_gated_weights(*[_p(t) for t in keep], Wa.shape[1], Wa.shape[0], int(gated), _p(prep),
                                                      _stream()), "vlsa_prepare_gated_weights")
             self._key, self._prep = key, prep
+        return self._prep
+
+    def pool_bags(self, bags, Wa, ba, Wg, bg, w2, c):
+        """The N-sized part of DeepMIL for up to 64 bags ([N_i, 512], one dtype, validated by the caller) in three launches:
+        raw scores of all bags (vlsa_gated_scores_batch), softmax-weighted row sums (vlsa_scored_pool_partial_batch), fold.
+        Returns (pooled [B, 512] fp32, scores [sum N_i] fp32, offsets [B + 1]) -- model/layers.py:103-122,137-153 per bag."""
+        lib, s, dev = nat.load(), _stream(), bags[0].device
+        gated, B = Wg is not None, len(bags)
+        if not (1 <= B <= 64):
+            raise ValueError("1..64 bags per call")
+        prep = self._packed(dev, Wa, ba, Wg, bg, w2, c)
+        rows = [x.shape[0] for x in bags]
+        f32 = bags[0].dtype == torch.float32
+        max_rows = 128 if (f32 and gated) else 256
+        rpt = max_rows
+        if sum((n + max_rows - 1) // max_rows for n in rows) < 128:      # less than one round of the 256 CUs: smaller tiles
+            rpt = 16
+            while rpt < max_rows and sum((n + rpt - 1) // rpt for n in rows) > 128:
+                rpt += 16
+        import numpy as np
+        stage = getattr(self, "_stage", None)
+        if stage is None or stage[0] != B:
+            meta = torch.empty(4 * B + (B + 2) // 2, dtype=torch.int64).pin_memory()
+            stage = self._stage = [B, meta, None]
+        elif stage[2] is not None:
+            stage[2].synchronize()                 # the previous call's async table upload has read the staging buffer
+        meta = stage[1]
+        m = meta.numpy()
+        m[:3 * B] = np.asarray([(x.data_ptr(), n, x.stride(0)) for x, n in zip(bags, rows)], dtype=np.int64).reshape(-1)
+        offs = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(rows, out=offs[1:])
+        m[3 * B:4 * B] = offs[:B]
+        ts = m[4 * B:].view(np.int32)
+        ts[0] = 0
+        np.cumsum([(n + rpt - 1) // rpt for n in rows], out=ts[1:B + 1])
+        n_tiles, total = int(ts[B]), int(offs[B])
+        meta_d = meta.to(dev, non_blocking=True)
+        stage[2] = torch.cuda.Event()
+        stage[2].record()
+        base = meta_d.data_ptr()
+        G = max(1, min(64, 512 // B))
+        a = torch.empty(total, dtype=torch.float32, device=dev)
+        pm = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pl = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pacc = torch.empty(B * G, 512, dtype=torch.float32, device=dev)
+        m2 = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        l = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
+        pooled = torch.empty(B, 512, dtype=torch.float32, device=dev)
+        dt = nat.DT_F32 if f32 else nat.DT_BF16
+        nat.check(lib.vlsa_gated_scores_batch(base, B, dt, 512, _p(prep), int(gated), base + 32 * B, n_tiles, rpt, _p(a),
+                                              base + 24 * B, total, s), "vlsa_gated_scores_batch")
+        nat.check(lib.vlsa_scored_pool_partial_batch(base, B, dt, 512, _p(a), base + 24 * B, G, _p(pm), _p(pl), _p(pacc), s),
+                  "vlsa_scored_pool_partial_batch")
+        st = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, 512, G * nat.P_STRIDE, G * nat.P_STRIDE, G * 512,
+                                  nat.P_STRIDE, nat.P_STRIDE, 512)
+        nat.check(lib.vlsa_vlfan_merge_batch_strided(_p(pm), _p(pl), _p(pacc), B, G, 1, 512, 1, st, _p(m2), _p(l), _p(pooled), s),
+                  "vlsa_vlfan_merge_batch_strided")
+        self._keep = (meta_d, bags)                # the kernels read these
+        return pooled, a, offs
+
+    def __call__(self, X2, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
+        lib = nat.load()
+        gated = Wg is not None
+        self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
         N = X2.shape[0]
         a = torch.empty(N, dtype=torch.float32, device=X2.device)
         nat.check(lib.vlsa_gated_scores(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(self._prep), int(gated), _p(a),

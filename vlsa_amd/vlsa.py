@@ -324,18 +324,11 @@ class VLSA(nn.Module):
         return logits, feats, That
 
     def _forward_bags_deepmil(self, flat, text_features):
-        """DeepMIL encoder over a list of bags: per bag the N-sized part (attention scores + softmax-weighted row sum, 3-4
-        launches), then ONE batched tail for all bags (head, normalise, cosine logits on [B, 512])."""
+        """DeepMIL encoder over a list of bags: the N-sized part (attention scores + softmax-weighted row sum) in one score
+        launch and one pooling launch per <= 64 bags (``DeepMIL.pool_bags``), then ONE batched tail for all bags (head,
+        normalise, cosine logits on [B, 512])."""
         enc = self.mil_encoder
-        pooled = []
-        for x in flat:
-            if enc.sigma == "mean":
-                pooled.append(VF.scored_pool(x, None))
-            elif enc.sigma == "max":
-                pooled.append(VF.colmax(x))
-            else:
-                pooled.append(VF.scored_pool(x, enc._attention_scores(x)))
-        f = torch.stack(pooled)                                                      # [B, 512]
+        f = enc.pool_bags(flat)                                                      # [B, 512]
         if enc.pred_head == "Adapter":
             v = enc.keep_ratio * f + (1 - enc.keep_ratio) * enc.visual_adapter(f)
         else:
