@@ -2,16 +2,21 @@
 """End-to-end walk through the public API on synthetic data (no reference checkout, no CONCH weights needed):
 
   1. slides on the host (fp32 `.pt`-like tensors, several per patient)  ->  resident bf16 arena in HBM (one upload)
-  2. evaluation: 32 patients per launch through `VLSA.forward_bags` (persistent multi-bag HIP kernels)
-  3. a few optimizer steps: batched HIP forward + backward of the aggregation, IF-MLE + EMD loss in one kernel, Adam
+  2. the text side: ordinal rank prompts (`RankPromptLearner`) through a (small, random-weight) CoCa-style text tower
+     (`CONCHPromptEncoder`, HIP forward + backward) -> the K text features; evaluation: 32 patients per launch through
+     `VLSA.forward_bags` (persistent multi-bag HIP kernels)
+  3. a few optimizer steps: text tower once per step, batched HIP forward + backward of the aggregation, IF-MLE + EMD loss in
+     one kernel, Adam on the context / rank embeddings, the text queries' residual and the logit scale
   4. interpretation of one slide (`calc_text_img_similarity`)
 
     python examples/synthetic_demo.py [--patients 64] [--steps 5]
 """
 import argparse
 import os
+import re
 import sys
 import time
+import zlib
 
 import torch
 
@@ -21,7 +26,32 @@ from vlsa_amd.inference import calc_text_img_similarity  # noqa: E402
 from vlsa_amd.ingest import ArenaLayout, DeviceBagArena  # noqa: E402
 from vlsa_amd.losses import SurvObjective  # noqa: E402
 from vlsa_amd.prompt_adapter import PromptAdapter  # noqa: E402
+from vlsa_amd.prompt_encoder import CONCHPromptEncoder  # noqa: E402
+from vlsa_amd.prompt_learner import RankPromptLearner  # noqa: E402
 from vlsa_amd.vlsa import VLSA  # noqa: E402
+
+
+class ToyTokenizer:
+    """Word / punctuation tokenizer with hashed ids -- stands in for the CONCH tokenizer wrapper (model/utils_vl.py:19-75) with
+    the same call contract: a full row is <bos> ids.. <eos> <pad>.. ; 'raw' rows drop <bos> and stop at the longest sentence."""
+    bos_token_id, eos_token_id, pad_token_id = 1, 2, 0
+
+    def __init__(self, vocab, length=128):
+        self.vocab, self.length = vocab, length
+
+    def __call__(self, text, return_raw_tokens=True, return_num_tokens=True):
+        texts = [text] if isinstance(text, str) else list(text)
+        ids = [[3 + zlib.crc32(w.lower().encode()) % (self.vocab - 3) for w in re.findall(r"\w+|[^\w\s]", t)] for t in texts]
+        rows = torch.full((len(texts), self.length), self.pad_token_id, dtype=torch.long)
+        for i, r in enumerate(ids):
+            rows[i, 0] = self.bos_token_id
+            rows[i, 1:1 + len(r)] = torch.tensor(r, dtype=torch.long)
+            rows[i, 1 + len(r)] = self.eos_token_id
+        cnt = torch.tensor([len(r) for r in ids])
+        out = rows[:, 1:int(cnt.max()) + 1] if return_raw_tokens else rows
+        if isinstance(text, str):
+            out, cnt = out[0], cnt[0]
+        return (out, cnt) if return_num_tokens else out
 
 
 def main():
@@ -48,11 +78,22 @@ def main():
           f"in {(time.perf_counter() - t0) * 1e3:.1f} ms")
 
     # 2. model + evaluation -------------------------------------------------------------------------------------------
-    text_features = torch.randn(K, 512, generator=g)                       # stands in for the CONCH prompt encoder's output
+    torch.manual_seed(0)
+    tower = CONCHPromptEncoder(width=256, heads=4, layers=3, vocab_size=2000, output_dim=512).to(dev)   # random weights; CONCH: 768 / 12 / 12
+    for p_ in tower.parameters():
+        p_.requires_grad_(False)                                           # vlsa_txt_encoder_frozen: True (cfg_vlsa_conch.yaml:69)
+    learner = RankPromptLearner(dict(max_num_tokens=127, embedding_dim=256, embedding_dtype=torch.float32), ToyTokenizer(2000),
+                                tower.token_embedding, num_base_ranks=2, num_ranks=K, num_tokens_per_rank=2, num_context_tokens=8,
+                                init_context="a histopathology slide of a patient whose survival is",
+                                init_rank_names=["very short", "very long"])
     prompt_features = torch.randn(P, 512, generator=g)                     # frozen text prototypes of the PromptAdapter
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean", pred_head="default")
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=prompt_features, res_ratio=0.5)
-    net = VLSA(cfg, pretrained_text_features=text_features, query_network=qnet).to(dev)
+    net = VLSA(cfg, prompt_learner=learner, prompt_encoder=tower, query_network=qnet).to(dev)
+    with torch.no_grad():
+        tf = net.forward_text_only()
+    print(f"[text]   {K} rank prompts x {int(learner.pseudo_sentence_tokens[0].max())} tokens -> text features {tuple(tf.shape)} "
+          f"(|t| = {tf.norm(dim=-1).mean().item():.2f}); cached until a prompt parameter changes")
     pids = list(patients)
     net.eval()
     with torch.no_grad():                                                  # first pass: library load, plans, clock ramp

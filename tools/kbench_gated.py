@@ -11,8 +11,8 @@ for gated in (True, False):
     w2 = torch.randn(1, 256, device=dev) / 16; c = torch.randn(1, device=dev)
     fs = F.FusedAttnScores()
     for n, dt in ((50000, torch.bfloat16), (40000, torch.bfloat16), (70000, torch.bfloat16), (20000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (400000, torch.bfloat16),
-        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
                   (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
+        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
         bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(4 if n > 100000 else 16)]
         for i in range(60): fs(bags[i % len(bags)], Wa, ba, Wg, bg, w2, c)
         torch.cuda.synchronize()

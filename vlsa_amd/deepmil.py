@@ -266,6 +266,9 @@ class DeepMIL(nn.Module):
         (512 -> 256 hidden, no active dropout), otherwise bag by bag.  model/deepmil.py:270-283 per bag."""
         sg = self.sigma
         if isinstance(sg, str):
+            if sg == "mean" and len(flat) > 0 and all(x.is_cuda and x.shape[1] == 512 and x.shape[0] > 0
+                                                      and x.dtype == flat[0].dtype for x in flat):
+                return torch.cat([VF.mean_pool_bags(flat[i:i + 64]) for i in range(0, len(flat), 64)])
             return torch.stack([VF.scored_pool(x, None) if sg == "mean" else VF.colmax(x) for x in flat])
         gated = isinstance(sg, Gated_Attention_Pooling)
         lin_a = sg.fc1[0] if gated else sg.attention[0]

@@ -709,6 +709,27 @@ class FusedAttnScores:
         return a
 
 
+def mean_pool_bags(bags) -> torch.Tensor:
+    """Row means [B, 512] of up to 64 validated [N_i, 512] device bags (one dtype) in two launches (the 'mean' pooling of
+    FeatMIL / DeepMIL over a batch: model/deepmil.py:57-58,271-272 per bag)."""
+    lib, s, dev, B = nat.load(), _stream(), bags[0].device, len(bags)
+    if not (1 <= B <= 64):
+        raise ValueError("1..64 bags per call")
+    import numpy as np
+    desc = torch.from_numpy(np.asarray([(x.data_ptr(), x.shape[0], x.stride(0)) for x in bags], dtype=np.int64)).to(dev)
+    G = max(1, min(64, 512 // B))
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+    pm, pl, pacc, m2, l, out = f(B * G, nat.P_STRIDE), f(B * G, nat.P_STRIDE), f(B * G, 512), f(B, nat.P_STRIDE), f(B, nat.P_STRIDE), f(B, 512)
+    dt = nat.DT_F32 if bags[0].dtype == torch.float32 else nat.DT_BF16
+    nat.check(lib.vlsa_scored_pool_partial_batch(_p(desc), B, dt, 512, None, None, G, _p(pm), _p(pl), _p(pacc), s),
+              "vlsa_scored_pool_partial_batch")
+    st = (ctypes.c_int64 * 9)(nat.P_STRIDE, nat.P_STRIDE, 512, G * nat.P_STRIDE, G * nat.P_STRIDE, G * 512,
+                              nat.P_STRIDE, nat.P_STRIDE, 512)
+    nat.check(lib.vlsa_vlfan_merge_batch_strided(_p(pm), _p(pl), _p(pacc), B, G, 1, 512, 1, st, _p(m2), _p(l), _p(out), s),
+              "vlsa_vlfan_merge_batch_strided")
+    return out
+
+
 class FusedFeatProjecter:
     """Feat_Projecter (Linear(512, 512) + LayerNorm, model/layers.py:65-82) over all patch rows of a bf16 or fp32 bag in ONE
     MFMA kernel (vlsa_feat_project): fp32 [N, 512] out, the pre-activations never reach memory.  Holds the weights packed
