@@ -378,20 +378,35 @@ class AttnBuffers:
     ``vlsa_attn_normalise_batch`` turns them into the attention weights in place; ``views[i]`` is bag i's A [P, N_i]."""
 
     def __init__(self, sizes, P: int, device):
+        import numpy as np
         self.sizes, self.P = [int(n) for n in sizes], int(P)
-        lds = [(n + 63) // 64 * 64 for n in self.sizes]
-        offs, tot = [], 0
-        for ld in lds:
-            offs.append(tot)
-            tot += P * ld
-        self.buf = torch.empty(max(tot, 4), dtype=torch.float32, device=device)
+        B = len(self.sizes)
+        n = np.asarray(self.sizes, dtype=np.int64)
+        lds = (n + 63) // 64 * 64
+        offs = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(P * lds, out=offs[1:])
+        self.buf = torch.empty(max(int(offs[B]), 4), dtype=torch.float32, device=device)
         base = self.buf.data_ptr()
-        host = torch.tensor([[base + 4 * o if n > 0 else 0, ld] for o, ld, n in zip(offs, lds, self.sizes)], dtype=torch.int64)
-        self.desc = host.to(device)
-        # bag table holding only the N_i (vlsa_bag_desc layout): lets the normalise launch outlive a later set_bags()
-        self.ndesc = torch.tensor([[0, n, 0] for n in self.sizes], dtype=torch.int64).to(device)
-        self.views = [self.buf[o:o + P * ld].view(P, ld)[:, :n] for o, ld, n in zip(offs, lds, self.sizes)]
+        # ONE upload: [B, 2] vlsa_rows_desc (pointer, pitch) followed by a [B, 3] bag table holding only the N_i (vlsa_bag_desc
+        # layout: lets the normalise launch outlive a later set_bags())
+        host = np.zeros(5 * B, dtype=np.int64)
+        host[0:2 * B:2] = np.where(n > 0, base + 4 * offs[:B], 0)
+        host[1:2 * B:2] = lds
+        host[2 * B + 1::3] = n
+        dev = torch.from_numpy(host).to(device)
+        self.desc, self.ndesc = dev[:2 * B].view(B, 2), dev[2 * B:].view(B, 3)
+        self._offs, self._lds = offs, lds
+        self._views = None
         self.max_n = max(self.sizes) if self.sizes else 0
+
+    @property
+    def views(self):
+        """views[i] = bag i's matrix [P, N_i] (built on first use: callers that only feed the buffers to kernels skip it)"""
+        if self._views is None:
+            P = self.P
+            self._views = [self.buf[int(o):int(o) + P * int(ld)].view(P, int(ld))[:, :n]
+                           for o, ld, n in zip(self._offs[:-1], self._lds, self.sizes)]
+        return self._views
 
 
 class _BagTable:
@@ -402,18 +417,19 @@ class _BagTable:
         B = len(bags)
         if not (1 <= B <= lib.vlsa_batch_max_bags()):
             raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_max_bags()}]")
-        host = torch.zeros(B, 3, dtype=torch.int64)
-        keep = []
+        import numpy as np
+        keep, rows = [], []
         for i, x in enumerate(bags):
             _need_gpu(x)
             x = _bag2d(x)
             if x.shape[1] != D or (i > 0 and x.dtype != keep[0].dtype):
                 raise VlsaNativeError("the batched path takes bags with D == 512 and one dtype (bf16 or fp32) per batch")
             keep.append(x)
-            host[i, 0], host[i, 1], host[i, 2] = x.data_ptr(), x.shape[0], (x.stride(0) if x.shape[0] > 0 else D)
+            n = x.shape[0]
+            rows.append((x.data_ptr(), n, x.stride(0) if n > 0 else D))
         self.bags, self.B, self.D = keep, B, D
         self.dt = nat.DT_F32 if keep[0].dtype == torch.float32 else nat.DT_BF16
-        self.desc = host.to(keep[0].device, non_blocking=False)
+        self.desc = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(keep[0].device)
 
 
 class _VlfanBatchAggregateFn(torch.autograd.Function):
