@@ -244,6 +244,16 @@ int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtype, int D, c
                               void* bwd_prep, float* pm, float* pl, float* pacc, int groups, void* stream);
 
 /*
+ * The same batched backward for what the persistent kernel does not take (fp32 bags -- the reference's own feature format -- or
+ * P > 12): the per-bag kernel over the bag table in ONE launch, grid (G, B).  G: row blocks per bag (the largest
+ * vlsa_num_partials(N_i) of the batch).  Writes B * G partial sums: pm (= 0), pl (= 1) [B * G, 16], pacc [B * G, P, D]; reduce with
+ * vlsa_vlfan_merge(..., B * G, normalise = 0).  bwd_prep: vlsa_bwd_batch_prep_bytes(B, D).
+ */
+int vlsa_vlfan_backward_bags(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P, float coattn_scale,
+                             const float* dout, const float* out, const float* m2, const float* l, void* bwd_prep, float* pm,
+                             float* pl, float* pacc, int G, void* stream);
+
+/*
  * Batched log-sum-exp merge with explicit strides (in floats): strides9 (HOST array) = {partial stride of pm, pl, pacc;
  * bag stride of pm, pl, pacc; bag stride of the outputs m2, l, out}.  Used by the multi-GPU batch path to fold the
  * workgroup partials of B bags into B compact records and, after the all-gather, the per-rank records into the result.

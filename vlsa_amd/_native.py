@@ -72,6 +72,8 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                               c_void_p, c_int64, c_void_p]),
     "vlsa_bwd_batch_partials": (c_int, []),
+    "vlsa_vlfan_backward_bags": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "vlsa_bwd_batch_prep_bytes": (c_size_t, [c_int, c_int]),
     "vlsa_vlfan_backward_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

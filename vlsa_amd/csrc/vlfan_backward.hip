@@ -43,6 +43,13 @@ constexpr int bwd_lds_bytes() {
     return 4 * kSliceBytes * (F32 ? 2 : 1) + 2 * kBwdExchParity;
 }
 
+// Several bags per launch (grid (G, B); fp32 bags or P > 12, which the persistent batch kernel of vlfan_backward_batch.hip does
+// not take): bags != null -> workgroup (b, bag) works on rows block b of G of bag blockIdx.y, with that bag's upstream
+// gradient fragments dsplit + bag * 3 * 16 * D, (m2, l, delta) + bag * 16, and writes partial bag * G + b.
+struct BwdBag {
+    const void* X;
+    long long N, ldx;
+};
 template <typename XT>
 __global__ __launch_bounds__(256, 1) void k_vlfan_backward_mfma(const XT* __restrict__ X, int64_t N, int64_t ldx,
                                                                  const __bf16* __restrict__ qsplit,
@@ -50,7 +57,8 @@ __global__ __launch_bounds__(256, 1) void k_vlfan_backward_mfma(const XT* __rest
                                                                  const float* __restrict__ m2, const float* __restrict__ l,
                                                                  const float* __restrict__ delta, float scale,
                                                                  float* __restrict__ pm, float* __restrict__ pl,
-                                                                 float* __restrict__ pacc, int G) {
+                                                                 float* __restrict__ pacc, int G,
+                                                                 const BwdBag* __restrict__ bags) {
     constexpr bool F32 = sizeof(XT) == 4;
     constexpr int NX = F32 ? 2 : 1;
     constexpr int D = 512;
@@ -58,9 +66,21 @@ __global__ __launch_bounds__(256, 1) void k_vlfan_backward_mfma(const XT* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (bags != nullptr) {
+        const int bag = blockIdx.y;
+        const BwdBag d = bags[bag];
+        X = static_cast<const XT*>(d.X);
+        N = d.N;
+        ldx = d.ldx;
+        dsplit += (size_t)bag * 3 * 16 * 512;
+        m2 += (size_t)bag * kPStride;
+        l += (size_t)bag * kPStride;
+        delta += (size_t)bag * kPStride;
+    }
     int64_t rbeg, rend;
     block_rows(N, b, G, rbeg, rend);
+    b += blockIdx.y * G;   // partial slot
 
     unsigned char* xs = smem + (size_t)w * kSliceBytes * NX;
     unsigned char* exch = smem + (size_t)4 * kSliceBytes * NX;
@@ -250,14 +270,38 @@ extern "C" int vlsa_vlfan_backward(const void* X, int x_dtype, int64_t N, int64_
         static DeviceOnce once;
         if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, (const float*)X, N, ldx, qsplit, dsplit, P, m2, l, delta,
-                           coattn_scale, pm, pl, pacc, G);
+                           coattn_scale, pm, pl, pacc, G, static_cast<const BwdBag*>(nullptr));
     } else {
         auto kern = k_vlfan_backward_mfma<__bf16>;
         constexpr int lds = bwd_lds_bytes<false>();
         static DeviceOnce once;
         if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, (const __bf16*)X, N, ldx, qsplit, dsplit, P, m2, l, delta,
-                           coattn_scale, pm, pl, pacc, G);
+                           coattn_scale, pm, pl, pacc, G, static_cast<const BwdBag*>(nullptr));
+    }
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// The per-bag kernel over a table of bags in ONE launch (see BwdBag): dsplit [B][3][16][D] and delta [B][16] as produced by
+// k_prepare_backward_batch (vlfan_backward_batch.hip); pm / pl [B * G, 16], pacc [B * G, P, D].
+int vlsa_launch_backward_mfma_bags(const void* bag_desc, int B, int x_dtype, const __bf16* qsplit, const __bf16* dsplit, int P,
+                                   const float* m2, const float* l, const float* delta, float scale, float* pm, float* pl,
+                                   float* pacc, int G, hipStream_t s) {
+    const BwdBag* bags = static_cast<const BwdBag*>(bag_desc);
+    if (x_dtype == VLSA_DT_F32) {
+        auto kern = k_vlfan_backward_mfma<float>;
+        constexpr int lds = bwd_lds_bytes<true>();
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(G, B), dim3(256), lds, s, static_cast<const float*>(nullptr), (int64_t)0, (int64_t)0, qsplit, dsplit, P,
+                           m2, l, delta, scale, pm, pl, pacc, G, bags);
+    } else {
+        auto kern = k_vlfan_backward_mfma<__bf16>;
+        constexpr int lds = bwd_lds_bytes<false>();
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(G, B), dim3(256), lds, s, static_cast<const __bf16*>(nullptr), (int64_t)0, (int64_t)0, qsplit, dsplit, P,
+                           m2, l, delta, scale, pm, pl, pacc, G, bags);
     }
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

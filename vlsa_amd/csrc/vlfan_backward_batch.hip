@@ -399,3 +399,26 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
                        qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
+
+int vlsa_launch_backward_mfma_bags(const void* bag_desc, int B, int x_dtype, const __bf16* qsplit, const __bf16* dsplit, int P,
+                                   const float* m2, const float* l, const float* delta, float scale, float* pm, float* pl,
+                                   float* pacc, int G, hipStream_t s);  // vlfan_backward.hip
+
+/* The same backward for batches the persistent kernel does not take (fp32 bags, P > 12): the per-bag kernel of
+ * vlfan_backward.hip over the bag table in ONE launch, grid (G, B) -- G row blocks per bag (the caller passes the largest
+ * vlsa_num_partials(N_i) of the batch); B * G partial sums in pm (= 0), pl (= 1) [B * G, 16], pacc [B * G, P, D], to be reduced
+ * with vlsa_vlfan_merge(..., B * G, normalise = 0).  bwd_prep: vlsa_bwd_batch_prep_bytes(B, D). */
+extern "C" int vlsa_vlfan_backward_bags(const void* bag_desc, int B, int x_dtype, int D, const void* qprep, int P,
+                                        float coattn_scale, const float* dout, const float* out, const float* m2, const float* l,
+                                        void* bwd_prep, float* pm, float* pl, float* pacc, int G, void* stream) {
+    if (!bag_desc || !qprep || !dout || !out || !m2 || !l || !bwd_prep || !pm || !pl || !pacc) return VLSA_EINVAL;
+    if (B < 1 || B > bb::kMaxBags || P < 1 || P > VLSA_MAX_P || G < 1) return VLSA_EINVAL;
+    if (D != 512 || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    __bf16* dsplit = static_cast<__bf16*>(bwd_prep);
+    float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
+    hipLaunchKernelGGL(k_prepare_backward_batch, dim3(16, B), dim3(256), 0, s, dout, out, P, D, dsplit, delta);
+    const QPrepLayout L(D);
+    const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
+    return vlsa_launch_backward_mfma_bags(bag_desc, B, x_dtype, qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, G, s);
+}

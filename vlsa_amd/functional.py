@@ -484,25 +484,15 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
                                                     choose_groups([x.shape[0] for x in table.bags], 0), s),
                       "vlsa_vlfan_backward_batch")
             _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
-        else:  # fp32 bags or P > 12: the per-bag kernel, partial sums of all bags reduced together
-            Gs = [num_partials(x.shape[0]) for x in table.bags]
-            Gt = sum(Gs)
-            pm = torch.empty(Gt, nat.P_STRIDE, dtype=torch.float32, device=dev)
-            pl = torch.empty(Gt, nat.P_STRIDE, dtype=torch.float32, device=dev)
-            pacc = torch.empty(Gt, P, D, dtype=torch.float32, device=dev)
-            prep = torch.empty(B, lib.vlsa_bwd_prep_bytes(D), dtype=torch.uint8, device=dev)
-            g0 = 0
-            for i, x in enumerate(table.bags):
-                if x.shape[0] == 0:
-                    continue
-                nat.check(lib.vlsa_vlfan_backward(_p(x), table.dt, x.shape[0], x.stride(0), D, _p(qbuf), P, scale,
-                                                  _p(dout[i]), _p(out[i]), _p(m2[i]), _p(l[i]), _p(prep[i]),
-                                                  _p(pm[g0:]), _p(pl[g0:]), _p(pacc[g0:]), s), "vlsa_vlfan_backward")
-                g0 += Gs[i]
-            if g0 == 0:
-                dE = torch.zeros(P, D, dtype=torch.float32, device=dev)
-            else:
-                _, _, dE = vlfan_merge(pm[:g0], pl[:g0], pacc[:g0], normalise=False)
+        else:  # fp32 bags or P > 12: the per-bag kernel over the bag table in ONE launch, partial sums of all bags reduced together
+            G = max(num_partials(x.shape[0]) for x in table.bags)
+            pm = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pl = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            pacc = torch.empty(B * G, P, D, dtype=torch.float32, device=dev)
+            prep = torch.empty(lib.vlsa_bwd_batch_prep_bytes(B, D), dtype=torch.uint8, device=dev)
+            nat.check(lib.vlsa_vlfan_backward_bags(_p(table.desc), B, table.dt, D, _p(qbuf), P, scale, _p(dout), _p(out), _p(m2),
+                                                   _p(l), _p(prep), _p(pm), _p(pl), _p(pacc), G, s), "vlsa_vlfan_backward_bags")
+            _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
         qp = PreparedQueries(qbuf, nq, P, D, gated)
         qhat, qnorm = qp.qhat, qp.qnorm
         dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
