@@ -318,6 +318,13 @@ int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int
                                    int G, float* pm, float* pl, float* pacc, void* stream);
 
 /*
+ * Exact Shapley values of the P text prototypes for the survival risk sum_k (K - k) softmax_k(logit_scale * mean_{p in S} sim[p, k])
+ * with v(empty) = 1 (reference utils/model_inference.py:23-79, an O(P 2^P) host loop there).  sim: [P, K] fp32 decoupled
+ * similarities (device); values: workspace of 2^P floats (the coalition values, kept for inspection); shap: [P].  P <= 16.
+ */
+int vlsa_prototype_shapley(const float* sim, int P, int K, float logit_scale, float* values, float* shap, void* stream);
+
+/*
  * Feat_Projecter over all N patch rows of a bag: Y = LayerNorm(X W^T + b) * gamma + beta, W [512, 512]
  * (reference model/layers.py:65-82, applied by the encoders when use_feat_proj=True: model/deepmil.py:176-179,267-268).
  * vlsa_prepare_featproj packs the weights (bf16 hi + lo split, MFMA fragment order) into `prep`

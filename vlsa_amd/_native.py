@@ -96,6 +96,7 @@ _SIGNATURES = {
                                         c_int64, c_void_p]),
     "vlsa_scored_pool_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "vlsa_prototype_shapley": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vlsa_featproj_prep_bytes": (c_size_t, []),
     "vlsa_prepare_featproj": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "vlsa_feat_project": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p]),

@@ -917,3 +917,65 @@ extern "C" int vlsa_topk_mean(const float* S, int C, int64_t N, int k, float out
     hipLaunchKernelGGL(k_topk_mean, dim3(C), dim3(256), 0, (hipStream_t)stream, S, N, k, out_scale, out);
     return st();
 }
+
+// ---- exact Shapley values of the P text prototypes for the survival risk  v(S) = sum_k (K - k) softmax_k(ls * mean_{p in S} sim[p, k]),
+// v(empty) = 1 (reference utils/model_inference.py:23-79: an O(P 2^P) host loop there).  Two launches: the value of every
+// coalition (one thread each), then per prototype the weighted sum of its marginal contributions (one workgroup each).
+namespace vlsa {
+struct ShapWeights {
+    float w[16];   // w[c] = c! (P - c - 1)! / P!
+};
+
+__global__ __launch_bounds__(256) void k_shap_values(const float* __restrict__ sim, int P, int K, float ls, float* __restrict__ V) {
+    const unsigned int m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= (1u << P)) return;
+    if (m == 0) {
+        V[0] = 1.f;
+        return;
+    }
+    const float inv = 1.f / (float)__builtin_popcount(m);
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {          // two passes over the classes (K <= 64: the [P, K] table sits in L1 / scalar cache)
+        float z = 0.f;
+        for (int p = 0; p < P; ++p)
+            if ((m >> p) & 1u) z += sim[p * K + k];
+        mx = fmaxf(mx, ls * (z * inv));
+    }
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float z = 0.f;
+        for (int p = 0; p < P; ++p)
+            if ((m >> p) & 1u) z += sim[p * K + k];
+        const float e = __expf(ls * (z * inv) - mx);
+        den += e;
+        num += e * (float)(K - k);
+    }
+    V[m] = num / den;
+}
+
+__global__ __launch_bounds__(256) void k_shap_reduce(const float* __restrict__ V, int P, const ShapWeights wt, float* __restrict__ shap) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const unsigned int half = 1u << (P - 1), lowmask = (1u << i) - 1u;
+    float acc = 0.f;
+    for (unsigned int j = tid; j < half; j += 256) {
+        const unsigned int m = ((j & ~lowmask) << 1) | (j & lowmask);      // j with a zero bit inserted at position i
+        acc += wt.w[__builtin_popcount(m)] * (V[m | (1u << i)] - V[m]);
+    }
+    acc = block_sum_256(acc, red);
+    if (tid == 0) shap[i] = acc;
+}
+}  // namespace vlsa
+
+extern "C" int vlsa_prototype_shapley(const float* sim, int P, int K, float logit_scale, float* values, float* shap, void* stream) {
+    if (!sim || !values || !shap || P < 1 || P > 16 || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    vlsa::ShapWeights wt;
+    double fac[17];
+    fac[0] = 1.0;
+    for (int i = 1; i <= 16; ++i) fac[i] = fac[i - 1] * i;
+    for (int c = 0; c < 16; ++c) wt.w[c] = c < P ? (float)(fac[c] * fac[P - c - 1] / fac[P]) : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vlsa::k_shap_values, dim3(((1u << P) + 255u) / 256u), dim3(256), 0, s, sim, P, K, logit_scale, values);
+    hipLaunchKernelGGL(vlsa::k_shap_reduce, dim3(P), dim3(256), 0, s, values, P, wt, shap);
+    return st();
+}

@@ -20,6 +20,19 @@ from .deepmil import VLFAN
 def evaluate_prototype_shap_imp(decoupled_similarity, logit_scale, verbose=False):
     """Exact Shapley values of the P prototypes for the survival risk sum_k (K - k) softmax(ls * mean_p sim)[k];
     the empty coalition is worth 1 (utils/model_inference.py:23-79).  O(P 2^P) on the host, vectorised."""
+    if isinstance(decoupled_similarity, torch.Tensor) and decoupled_similarity.is_cuda:
+        # on the device: the value of every coalition by one thread each, then one workgroup per prototype (vlsa_prototype_shapley)
+        from . import _native as nat
+        sim = decoupled_similarity.detach().float().contiguous()
+        num_p, num_cls = sim.shape
+        lib = nat.load()
+        V = torch.empty(2 ** num_p, dtype=torch.float32, device=sim.device)
+        shap = torch.empty(num_p, dtype=torch.float32, device=sim.device)
+        nat.check(lib.vlsa_prototype_shapley(sim.data_ptr(), num_p, num_cls, float(logit_scale), V.data_ptr(), shap.data_ptr(),
+                                             torch.cuda.current_stream(sim.device).cuda_stream), "vlsa_prototype_shapley")
+        if verbose:
+            print("[SHAP] base", V[0].item(), "full", V[-1].item(), "sum", shap.sum().item())
+        return shap.cpu()
     # numpy on purpose: the arrays are tiny ([2^P, P]); torch's CPU ops wake its whole intra-op thread pool for them, which
     # on a many-core host costs milliseconds per call and is erratic (measured 1.7 ... 19 ms for the same input)
     import numpy as np
@@ -63,22 +76,24 @@ def calc_text_img_similarity(model, X_feats, axis_softmax="V", verbose=False):
     X = X.to(next(model.parameters()).device)
     logit_scale = float(model.get_logit_scale())
     That = F.normalize(model.forward_text_only(), dim=-1)
-    image_feature, cottn = enc(X, ret_with_attn=True)            # HIP forward with attention weights
-    cottn = cottn[0] if isinstance(cottn, tuple) else cottn
-    cottn = cottn.squeeze(0)                                      # [P, N]
+    # ONE pass over the bag: the P aggregated rows and the attention weights; pooling + head on the P rows (as VLFAN.forward)
+    Xp = enc.project(X)
+    out, cottn = VF.vlfan_cross_attention(Xp, enc.get_query(), gated=enc.gated_query,
+                                          coattn_scale=float(enc.coattn_logit_scale.exp()), want_attn=True)   # [P, D], [P, N]
+    image_feature = enc.visual_adapter(enc.forward_query_pooling(out.unsqueeze(0))[0])
     if axis_softmax == "V":
         A = cottn
     else:  # softmax over the prototypes of the same scaled cosine scores: recover them from the patch-softmax weights
         qp = VF.prepare_queries(enc.get_query(), enc.gated_query, float(enc.coattn_logit_scale.exp()))
-        _, _, _, scores = VF.vlfan_partial(X, qp, want_scores=True)  # log2-domain scaled scores
+        _, _, _, scores = VF.vlfan_partial(Xp, qp, want_scores=True)  # log2-domain scaled scores
         A = F.softmax(scores / 1.4426950408889634, dim=0)
     L = image_feature.norm(dim=-1)
     probs = F.softmax(logit_scale * (image_feature / L) @ That.t(), dim=-1)
     # decoupled similarities from the aggregated rows (see module docstring)
-    out, _ = VF.vlfan_cross_attention(X, enc.get_query(), gated=enc.gated_query,
-                                      coattn_scale=float(enc.coattn_logit_scale.exp()))
     dec = (enc.visual_adapter(out) / L) @ That.t()                # [P, K]
     decoupled_imp = F.softmax(logit_scale * dec, dim=0)
     probs_2 = F.softmax(logit_scale * dec.mean(dim=0, keepdim=True), dim=-1)
-    shap = evaluate_prototype_shap_imp(dec.cpu(), logit_scale, verbose=verbose)
-    return None, A.cpu(), cottn.cpu(), probs.cpu(), probs_2.cpu(), decoupled_imp.cpu(), shap
+    shap = evaluate_prototype_shap_imp(dec, logit_scale, verbose=verbose)
+    cottn_h = cottn.cpu()
+    A_h = cottn_h.clone() if A is cottn else A.cpu()              # axis 'V': the same matrix -- one device-to-host copy, two tensors
+    return None, A_h, cottn_h, probs.cpu(), probs_2.cpu(), decoupled_imp.cpu(), shap
