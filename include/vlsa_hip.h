@@ -234,7 +234,7 @@ int vlsa_vlfan_forward_batch_attn(const void* bag_desc, int B, int x_dtype, int 
  * dout, out: [B, P, D]; m2, l: [B, 16] (the batched forward's outputs).  ONE persistent launch streams all bags and writes
  * G = vlsa_bwd_batch_partials() partial sums of  sum_bags de  into pm (= 0), pl (= 1) [G, 16] and pacc [G, P, D]; reduce them
  * with vlsa_vlfan_merge(..., G, normalise = 0).  bwd_prep: scratch of vlsa_bwd_batch_prep_bytes(B, D).
- * bf16 bags, D == 512 and P <= 12 (VLSA_EUNSUPPORTED otherwise: loop vlsa_vlfan_backward over the bags instead).
+ * D == 512; bf16 bags with P <= 12, or fp32 bags (any P <= 16) -- VLSA_EUNSUPPORTED otherwise: vlsa_vlfan_backward_bags.
  * groups: bags in flight as in vlsa_vlfan_partial_batch_ex (0 = min(B, 8)).
  */
 int vlsa_bwd_batch_partials(void);

@@ -25,7 +25,8 @@ def _oracle_grads(bags, Q, Gs, gated):
 
 
 @pytest.mark.parametrize("dtype,P,gated", [(torch.bfloat16, 12, False), (torch.bfloat16, 7, True), (torch.bfloat16, 1, False),
-                                           (torch.float32, 12, False), (torch.bfloat16, 16, False)])
+                                           (torch.float32, 12, False), (torch.bfloat16, 16, False), (torch.float32, 16, True),
+                                           (torch.float32, 5, False)])
 @pytest.mark.parametrize("sizes", [[3000, 1, 33, 700], [64, 65, 31, 32, 4100, 17, 200, 1000, 5]])
 def test_batched_backward_vs_oracle_autograd(sizes, dtype, P, gated):
     from vlsa_amd import functional as F
@@ -45,12 +46,13 @@ def test_batched_backward_vs_oracle_autograd(sizes, dtype, P, gated):
     assert (Qd.grad.cpu() - ref_grad).abs().max().item() < GRAD_RTOL * scale
 
 
-def test_batched_backward_equals_per_bag_backward_full_size():
-    """32 bags of 2k..50k bf16 rows: the persistent batch backward vs the sum of the per-bag HIP backward."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_batched_backward_equals_per_bag_backward_full_size(dtype):
+    """32 bags of 2k..50k bf16 / fp32 rows: the persistent batch backward vs the sum of the per-bag HIP backward."""
     from vlsa_amd import functional as F
     dev = torch.device("cuda", 0)
     sizes = [50_000, 10_000, 2798, 20_001] + [2000 + 977 * i for i in range(28)]
-    base = cases.make_bag(50_000, 920).to(torch.bfloat16).to(dev)
+    base = cases.make_bag(50_000, 920).to(dtype).to(dev)
     bags = [base[:n] if i % 2 == 0 else base[50_000 - n:] for i, n in enumerate(sizes)]
     params = cases.make_params(12, 4, 921)
     Q = (0.5 * params["resid"] + params["prompt"]).to(dev)

@@ -242,3 +242,19 @@ def test_forward_bags_with_module_pooling_matches_per_bag_forward(pooling):
     assert (lb - torch.cat([r[0] for r in ref])).abs().max().item() < 1e-4
     assert (fb - torch.cat([r[1] for r in ref])).abs().max().item() < 1e-5
     assert (tb - ref[0][2]).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("P,K", [(12, 12), (8, 4), (1, 4), (16, 8)])
+def test_prototype_shapley_device_matches_host_and_sums_to_the_full_value(P, K):
+    """vlsa_prototype_shapley (one thread per coalition) vs the vectorised host restatement of utils/model_inference.py:23-79
+    (pinned to the reference by interpretation.npz above); efficiency: the values sum to v(all) - v(empty)."""
+    from vlsa_amd.inference import evaluate_prototype_shap_imp
+    sim = (torch.rand(P, K, generator=cases.gen(77 + P)) * 2 - 1) * 0.08
+    ls = 56.31
+    host = evaluate_prototype_shap_imp(sim, ls)
+    dev = evaluate_prototype_shap_imp(sim.cuda(), ls)
+    assert dev.shape == (P,) and not dev.is_cuda
+    assert (dev - host).abs().max().item() < 1e-5
+    prob = torch.softmax(ls * sim.mean(dim=0), dim=-1)
+    v_full = (prob * torch.arange(K, 0, -1, dtype=torch.float32)).sum().item()
+    assert abs(dev.sum().item() - (v_full - 1.0)) < 1e-4

@@ -5,7 +5,8 @@ import torch
 from vlsa_amd import functional as F
 dev = "cuda"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-base = torch.randn(32 * n, 512, device=dev).to(torch.bfloat16)
+dt = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "fp32") else torch.bfloat16
+base = torch.randn(32 * n, 512, device=dev).to(dt)
 bags = [base[i * n:(i + 1) * n] for i in range(32)]
 Q = torch.randn(12, 512, device=dev, requires_grad=True)
 G = torch.randn(32, 12, 512, device=dev)

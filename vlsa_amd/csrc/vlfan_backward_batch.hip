@@ -369,6 +369,10 @@ using namespace vlsa;
 
 static inline int bwd_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
 
+int vlsa_launch_backward_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, const __bf16* dsplit, int P,
+                                   const float* m2, const float* l, const float* delta, float scale, float* pm, float* pl,
+                                   float* pacc, int S, hipStream_t s);  // vlfan_backward_batch_f32.hip
+
 extern "C" int vlsa_bwd_batch_partials(void) { return 512; }
 
 extern "C" size_t vlsa_bwd_batch_prep_bytes(int B, int D) { return (size_t)B * 3 * 16 * D * 2 + (size_t)B * kPStride * 4; }
@@ -378,8 +382,9 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
                                          const float* l, void* bwd_prep, float* pm, float* pl, float* pacc, int groups,
                                          void* stream) {
     if (!bag_desc || !qprep || !dout || !out || !m2 || !l || !bwd_prep || !pm || !pl || !pacc) return VLSA_EINVAL;
-    if (B < 1 || B > bb::kMaxBags || P < 1) return VLSA_EINVAL;
-    if (D != 512 || x_dtype != VLSA_DT_BF16 || P > bb::kMaxP) return VLSA_EUNSUPPORTED;
+    if (B < 1 || B > bb::kMaxBags || P < 1 || P > VLSA_MAX_P) return VLSA_EINVAL;
+    if (D != 512 || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    if (x_dtype == VLSA_DT_BF16 && P > bb::kMaxP) return VLSA_EUNSUPPORTED;   // (fp32 bags: any P <= 16)
     int S = groups > 0 ? groups : bwd_groups(B);  // bags in flight: power of two <= min(B, 64)
     {
         int p2 = 1;
@@ -391,6 +396,12 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
     float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
     hipLaunchKernelGGL(k_prepare_backward_batch, dim3(16, B), dim3(256), 0, s, dout, out, P, D, dsplit, delta);
     const QPrepLayout L(D);
+    if (x_dtype == VLSA_DT_F32) {
+        const unsigned char* qp = static_cast<const unsigned char*>(qprep);
+        return vlsa_launch_backward_f32_batch(bag_desc, B, reinterpret_cast<const float*>(qp + L.qeff),
+                                              reinterpret_cast<const float*>(qp + L.qnorm), dsplit, P, m2, l, delta, coattn_scale, pm,
+                                              pl, pacc, S, s);
+    }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
     static DeviceOnce attr_once;
     if (attr_once.first())

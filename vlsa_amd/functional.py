@@ -473,7 +473,7 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         lib, s = nat.load(), _stream()
         B, dev = table.B, out.device
         dout = _f32c(dout)
-        if table.dt == nat.DT_BF16 and P <= 12:
+        if (table.dt == nat.DT_BF16 and P <= 12) or table.dt == nat.DT_F32:   # the persistent batch kernels (bf16: P <= 12; fp32: any P)
             G = lib.vlsa_bwd_batch_partials()
             pm = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
             pl = torch.empty(G, nat.P_STRIDE, dtype=torch.float32, device=dev)
