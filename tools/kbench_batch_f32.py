@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"
-for n, dt, B in ((50000, torch.float32, 16), (10000, torch.float32, 32), (2798, torch.float32, 32), (50000, torch.bfloat16, 16), (10000, torch.bfloat16, 32)):
+for n, dt, B in ((50000, torch.float32, 32), (10000, torch.float32, 32), (2798, torch.float32, 32), (50000, torch.bfloat16, 32), (10000, torch.bfloat16, 32)):
     torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
     bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(B)]
     Q = torch.randn(12, 512, device=dev); T = torch.randn(4, 512, device=dev)
