@@ -369,7 +369,7 @@ using namespace vlsa;
 
 static inline int bwd_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
 
-int vlsa_launch_backward_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, const __bf16* dsplit, int P,
+int vlsa_launch_backward_f32_batch(const void* bag_desc, int B, const __bf16* qsplit, const __bf16* dsplit, int P,
                                    const float* m2, const float* l, const float* delta, float scale, float* pm, float* pl,
                                    float* pacc, int S, hipStream_t s);  // vlfan_backward_batch_f32.hip
 
@@ -396,13 +396,9 @@ extern "C" int vlsa_vlfan_backward_batch(const void* bag_desc, int B, int x_dtyp
     float* delta = reinterpret_cast<float*>(static_cast<unsigned char*>(bwd_prep) + (size_t)B * 3 * 16 * D * 2);
     hipLaunchKernelGGL(k_prepare_backward_batch, dim3(16, B), dim3(256), 0, s, dout, out, P, D, dsplit, delta);
     const QPrepLayout L(D);
-    if (x_dtype == VLSA_DT_F32) {
-        const unsigned char* qp = static_cast<const unsigned char*>(qprep);
-        return vlsa_launch_backward_f32_batch(bag_desc, B, reinterpret_cast<const float*>(qp + L.qeff),
-                                              reinterpret_cast<const float*>(qp + L.qnorm), dsplit, P, m2, l, delta, coattn_scale, pm,
-                                              pl, pacc, S, s);
-    }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
+    if (x_dtype == VLSA_DT_F32)
+        return vlsa_launch_backward_f32_batch(bag_desc, B, qsplit, dsplit, P, m2, l, delta, coattn_scale, pm, pl, pacc, S, s);
     static DeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute((const void*)k_vlfan_backward_dma_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bb::kLdsBytes);

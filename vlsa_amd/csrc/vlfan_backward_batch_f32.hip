@@ -4,15 +4,16 @@
 // Persistent LDS-DMA streaming kernel: the row layout, ring and swizzle of k_vlfan_partial_f32_batch (vlfan_batch_f32.hip), the
 // structure of k_vlfan_backward_dma_batch (vlfan_backward_batch.hip): four-wave workgroups = the four 128-column quarters of a
 // 16-row tile, 512 workgroups = two per CU, accumulators kept in registers across ALL bags, one partial per workgroup.
-// Matrix-pipe work per 16-row tile and wave:
-//   * scores S = X e^T on the f32 pipe (32 steps of v_mfma_f32_16x16x4_f32): bit-compatible with the forward kernel, so
-//     A = exp2(t - m2) / l reproduces the forward's weights from its (m2, l);
-//   * dA = X dout^T on the bf16 pipe: the score fragments already sit in registers as 4 consecutive columns per lane and
-//     8-column group; split into bf16 hi + lo they ARE the A operand of v_mfma_f32_16x16x32_bf16 (k-slot e of lane group g
-//     <-> column 32 s + 16 (e >> 2) + 4 g + (e & 3); the dout fragments use the same map): X_hi d_hi + X_hi d_lo + X_lo d_hi,
-//     12 steps instead of 32 f32 ones (gradient tolerance; the forward's exact scores are not touched);
-//   * de += u X with u = A (dA - delta) scale / |x| on the bf16 pipe from in-register hi + lo splits (24 steps of 16x16x16),
-//     as the forward's weighted sum.
+// Matrix-pipe work per 16-row tile and wave -- all of it on the bf16 pipe, from ONE set of registers: the row fragments come in
+// as 4 consecutive columns per lane and 16-column group (one ds_read_b128 each, as in the forward kernel); split into bf16 hi +
+// lo they ARE the A operand of v_mfma_f32_16x16x32_bf16 under the k map  slot e of lane group g of step s <-> column
+// 32 s + 16 (e >> 2) + 4 g + (e & 3), which the query and dout fragments share:
+//   * scores  S  = X e^T:    X_hi (e0 + e1 + e2) + X_lo (e0 + e1)       20 steps  (3-term queries as in the bf16 kernels)
+//   * dA         = X dout^T: X_hi (d0 + d1) + X_lo d0                   12 steps
+//   * de += u X with u = A (dA - delta) scale / |x|: 24 steps of 16x16x16 from in-register hi + lo splits, as the forward's sum.
+// 896 matrix-pipe cycles per tile instead of 1600 with the scores on the f32 pipe (measured 755 -> 613 us per 32 x 50k bags):
+// unlike the forward -- whose exact f32 scores define the attention weights it hands out -- the backward only needs
+// A = exp2(t - m2) / l to the gradient tolerance, and the 2^-17 operand split moves t by ~3e-5.
 // No P <= 12 restriction here (the exchange tiles are the full 16 x 16).
 #include "vlsa_common.h"
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ int fswzb(int row, int col) { return row * 512 + ((((
     } while (0)
 
 __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDescF* __restrict__ bags, int B,
-                                                                     const float* __restrict__ qeff, const float* __restrict__ qmeta,
+                                                                     const __bf16* __restrict__ qsplit,
                                                                      const __bf16* __restrict__ dsplit, int P,
                                                                      const float* __restrict__ m2, const float* __restrict__ l,
                                                                      const float* __restrict__ delta, float scale,
@@ -97,15 +98,21 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDe
         e[6] = 0;
         e[7] = mine ? 1 : 0;
     }
-    // query fragments, fp32, scale * log2(e) applied: lane holds e_p[p = i16][128 cw + 16 j + 4 g + r] in qf[4 j + r]
-    float qf[32];
-    {
-        const float sc = qmeta[31];
+    // query fragments: the 3-term bf16 split of the effective queries (scale * log2 e folded in), in the column map of the row
+    // fragments: k-slot e of lane group g of step s <-> column 128 cw + 32 s + 16 (e >> 2) + 4 g + (e & 3)
+    bf16x8 qs[3][4];
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) qf[kk] = qeff[(size_t)i16 * D + cw * 128 + 16 * (kk >> 2) + 4 * g + (kk & 3)] * sc;
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) asm volatile("" : "+v"(qf[kk]));
-    }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const __bf16* src = qsplit + ((size_t)t * 16 + i16) * D + cw * 128 + 32 * s4 + 4 * g;
+            const bf16x4 lo4 = *reinterpret_cast<const bf16x4*>(src), hi4 = *reinterpret_cast<const bf16x4*>(src + 16);
+            qs[t][s4] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(qs[t][s4]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -214,13 +221,6 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDe
                     xa[4 * j + 2] = v[2];
                     xa[4 * j + 3] = v[3];
                 }
-                f32x4 Sb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 32; kk += 2) {
-                    Sv = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], qf[kk], Sv, 0, 0, 0);
-                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 1], qf[kk + 1], Sb, 0, 0, 0);
-                }
-                Sv += Sb;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 2) {
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDe
                     s1 = fmaf(xa[kk + 1], xa[kk + 1], s1);
                 }
                 ss = quad_rows_sum(s0 + s1);
-                // dA on the bf16 pipe from the same registers
-                f32x4 Db = {0.f, 0.f, 0.f, 0.f};
+                // scores and dA on the bf16 pipe from the same registers
+                f32x4 Db = {0.f, 0.f, 0.f, 0.f}, Sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
                     bf16x8 xh, xl;
@@ -240,10 +240,16 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDe
                         xh[e] = h;
                         xl[e] = (__bf16)(v - (float)h);
                     }
+                    Sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qs[0][s4], Sv, 0, 0, 0);
                     Dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, df[0][s4], Dv, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qs[1][s4], Sb, 0, 0, 0);
                     Db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, df[1][s4], Db, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qs[0][s4], Sb, 0, 0, 0);
                     Db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, df[0][s4], Db, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, qs[2][s4], Sb, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, qs[1][s4], Sb, 0, 0, 0);
                 }
+                Sv += Sb;
                 Dv += Db;
             }
 
@@ -330,13 +336,13 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_f32_batch(const BagDe
 using namespace vlsa;
 
 // fp32 bags of vlsa_vlfan_backward_batch: dsplit / delta as produced by k_prepare_backward_batch; 512 partials
-int vlsa_launch_backward_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, const __bf16* dsplit, int P,
+int vlsa_launch_backward_f32_batch(const void* bag_desc, int B, const __bf16* qsplit, const __bf16* dsplit, int P,
                                    const float* m2, const float* l, const float* delta, float scale, float* pm, float* pl,
                                    float* pacc, int S, hipStream_t s) {
     static DeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute((const void*)k_vlfan_backward_f32_batch, hipFuncAttributeMaxDynamicSharedMemorySize, bbf::kLdsBytes);
     hipLaunchKernelGGL(k_vlfan_backward_f32_batch, dim3(512), dim3(256), bbf::kLdsBytes, s, static_cast<const BagDescF*>(bag_desc), B,
-                       qeff, qmeta, dsplit, P, m2, l, delta, scale, pm, pl, pacc, S);
+                       qsplit, dsplit, P, m2, l, delta, scale, pm, pl, pacc, S);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
