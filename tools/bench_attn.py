@@ -9,7 +9,8 @@ from vlsa_amd import functional as F
 
 dev = "cuda"
 B, n, P, K = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 12, 4
-bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(B)]
+DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
+bags = [torch.randn(n, 512, device=dev).to(DT) for _ in range(B)]
 Q = torch.randn(P, 512, device=dev); T = torch.randn(K, 512, device=dev)
 W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -39,7 +40,7 @@ for want in (False, True):
     for _ in range(30):
         e0.record(); plan.run_partial_only(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     kern = sorted(ts)[len(ts) // 2] * 1e-3
-    bytes_pp = 1024 + (4 * P if want else 0)
-    print(f"want_attn={want}: step {dt * 1e6:.1f} us per {B} bags = {dt / B * 1e6:.2f} us/bag = {B * n / dt / 1e9:.2f} G patches/s; "
+    bytes_pp = 512 * bags[0].element_size() + (4 * P if want else 0)
+    print(f"{str(DT)[6:]} want_attn={want}: step {dt * 1e6:.1f} us per {B} bags = {dt / B * 1e6:.2f} us/bag = {B * n / dt / 1e9:.2f} G patches/s; "
           f"whole-step {B * n * bytes_pp / dt / 1e12:.2f} TB/s = {B * n * bytes_pp / dt / 8e12 * 100:.1f} % of the ({bytes_pp} B/patch) HBM roofline; "
           f"streaming kernel alone {kern * 1e6:.1f} us (event pair included)")

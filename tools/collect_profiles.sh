@@ -44,6 +44,7 @@ python tools/bench_text.py --cpu > $O/bench_text.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python tools/prof_train.py > /dev/null 2>&1
 cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_batch_kernel_stats.csv
 python tools/bench_attn.py > $O/bench_attn.txt 2>&1
+python tools/bench_attn.py 50000 fp32 2>&1 | grep want_attn >> $O/bench_attn.txt
 python tools/bench_step.py > $O/bench_step.txt 2>&1
 python tools/bench_train.py > $O/bench_train.txt 2>&1
 python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                         if (row0 + 4 * g + r >= nrows) T[r] = -INFINITY;
                 }
                 if constexpr (kScores) {  // the four column-quarter waves hold identical scores: wave cw = 0 stores them
-                    if (srow != nullptr) __builtin_nontemporal_store(T, reinterpret_cast<f32x4*>(srow + row0));
+                    if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = T;   // write-back: the partner row group's half of the line follows within the iteration
                 }
                 const float tmax = fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3]));
                 if (__builtin_amdgcn_ballot_w64(tmax > M + kThr) != 0) {
