@@ -67,3 +67,23 @@ def test_deepmil_forward_bags_equals_per_bag_forward(pooling):
             lg, ft, _ = model(bags[i][None])
             assert (logits[i] - lg[0]).abs().max().item() < 5e-5
             assert (feats[i] - ft[0]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("pooling", ["mean", "max"])
+def test_featmil_forward_bags_equals_per_bag_forward(pooling, dtype):
+    from oracle import vlsa_oracle as O
+    from vlsa_amd.vlsa import VLSA
+    dev = torch.device("cuda", 0)
+    T = torch.randn(4, 512, generator=cases.gen(31))
+    model = VLSA(dict(name="FeatMIL", dim_in=512, pooling=pooling), pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
+    sizes = [1, 33, 2798, 5000, 64] + [300 + 11 * i for i in range(62)]            # > 64 bags: two chunks of the mean launch
+    bags = [cases.make_bag(n, 6300 + i, "clustered" if i % 2 else "iid").to(dtype).to(dev) for i, n in enumerate(sizes)]
+    with torch.no_grad():
+        logits, feats, _ = model.forward_bags(bags)
+        for i in (0, 1, 2, 3, 4, 66):
+            lg, ft, _ = model(bags[i][None])
+            assert (logits[i] - lg[0]).abs().max().item() < 5e-5
+            f = O.featmil_forward(bags[i].float().cpu(), pooling)
+            ref = torch.nn.functional.normalize(f.reshape(1, -1), dim=-1)
+            assert (feats[i].cpu() - ref[0]).abs().max().item() < 1e-5

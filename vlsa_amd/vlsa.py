@@ -267,6 +267,16 @@ class VLSA(nn.Module):
                     and flat[0].dtype in (torch.bfloat16, torch.float32))
             if same and isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max") and text_features.shape[0] <= 64:
                 return self._forward_bags_zeroshot(flat, text_features)
+            if same and isinstance(enc, FeatMIL) and enc.pooling in ("mean", "max"):
+                # FeatMIL baseline (model/deepmil.py:57-60): row means of all bags in two launches / column maxima bag by bag,
+                # then normalise + cosine logits on [B, 512]
+                if enc.pooling == "mean":
+                    f = torch.cat([VF.mean_pool_bags(flat[i:i + 64]) for i in range(0, len(flat), 64)])
+                else:
+                    f = torch.stack([VF.colmax(x) for x in flat])
+                That = F.normalize(text_features.detach().float(), dim=-1)
+                feats = F.normalize(f, dim=-1)
+                return self.logit_scale.exp() * feats @ That.t(), feats, That
             if same and isinstance(enc, mil_encoders.DeepMIL) and (enc.feat_proj is None or projected):
                 return self._forward_bags_deepmil(flat, text_features)
             if (isinstance(enc, VLFAN) and (enc.feat_proj is None or projected) and len(flat) > 0
