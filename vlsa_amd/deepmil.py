@@ -178,10 +178,47 @@ class VLFAN(nn.Module):
         return (self.feat_proj is not None and torch.is_grad_enabled()
                 and any(p.requires_grad for p in self.feat_proj.parameters()))
 
+    def _fused_encode(self, X, ret_with_attn):
+        """Inference, nothing to differentiate: the whole encoder (query preparation, streaming aggregation, merge, attention
+        weights, query pooling, adapter) as ONE host call into the C ABI (``VlfanInferencePlan``; the text part of the fused
+        head is fed a dummy class).  None when the configuration has no fused form."""
+        spec = self.fused_head_spec()
+        if (spec is None or spec[0] == "module" or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+                or not X.is_cuda or X.shape[-1] != 512 or X.shape[1] == 0 or X.dtype not in (torch.float32, torch.bfloat16)):
+            return None
+        mode, pw, W, b = spec
+        X2 = VF._bag2d(X)
+        Q = self.get_query().detach().float().contiguous()
+        P = Q.shape[0] - (1 if self.gated_query else 0)
+        if not (1 <= P <= 16):
+            return None
+        N, dev = X2.shape[0], X2.device
+        plans = self.__dict__.setdefault("_enc_plans", {})
+        key = (N, dev, bool(ret_with_attn), P, mode, W is None)
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) > 32:
+                plans.clear()
+            plan = plans[key] = VF.VlfanInferencePlan(N, 512, P, 1, dev, gated=self.gated_query, pool=mode, identity_head=W is None,
+                                                      want_attn=ret_with_attn, coattn_scale=float(self.coattn_logit_scale.exp()))
+            plan._dummy = (torch.ones(1, 512, device=dev), torch.zeros((), device=dev))
+        outs = {"v": torch.empty(512, dtype=torch.float32, device=dev)}
+        if ret_with_attn:
+            outs["A"] = torch.empty(P, N, dtype=torch.float32, device=dev)
+        plan.run(X2, Q, plan._dummy[0], plan._dummy[1], None if W is None else W.detach().float().contiguous(),
+                 None if b is None else b.detach().float().contiguous(),
+                 None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs)
+        v = outs["v"][None]
+        return (v, outs["A"][None]) if ret_with_attn else v
+
     def forward(self, X, ret_with_attn=False):
         assert X.shape[0] == 1
         if self.feat_proj is not None:
             X = self.feat_proj(X)
+        if not (torch.is_grad_enabled() and X.requires_grad):
+            fused = self._fused_encode(X, ret_with_attn)
+            if fused is not None:
+                return fused
         Q = self.get_query()
         if self.gated_query:
             assert self._pos_gated_query == -1, "The gated query is placed at the end by default."
