@@ -21,4 +21,9 @@ for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfl
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(40): net.forward_bags(bags)
         torch.cuda.synchronize(); t2 = (time.perf_counter() - t0) / 40 / 32 * 1e6
-    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag")
+        bags2 = bags + bags                      # 64 bags per call = one persistent launch
+        for i in range(10): net.forward_bags(bags2)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(40): net.forward_bags(bags2)
+        torch.cuda.synchronize(); t3 = (time.perf_counter() - t0) / 40 / 64 * 1e6
+    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag")

@@ -298,7 +298,7 @@ class VLSA(nn.Module):
         Wc = None if W is None else W.detach().float().contiguous()
         bc = None if b is None else b.detach().float().contiguous()
         pwc = None if pw is None else pw.detach().float().reshape(-1).contiguous()
-        step = 32
+        step = 64          # bags per persistent launch (the kernels' maximum: fewer launches and host calls per bag)
         for i in range(0, len(flat), step):
             chunk = flat[i:i + step]
             key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else 0)
