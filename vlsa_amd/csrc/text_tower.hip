@@ -118,6 +118,7 @@ struct GemmArgs {
     const float* H;        // row-major [M_pad, ldh]: EPI_GELU_BWD multiplies by gelu'(H)
     const float *ln_w, *ln_b;
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
+    int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
 };
 
 // Tile choice (measured, K = 12 prompts -> 192 padded rows): the operands reach the MFMAs through the CU's L1 at ~46 B/clk, and an
@@ -708,7 +709,9 @@ inline Scratch scratch_of(float* p, const Shape& s) {
 
 template <int MT, int NW, int PRO, int GT, int NTW = 2>
 int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
-    a.MG = M_pad / (16 * MT);
+    // row groups: only those that hold real rows (the rows behind M_real are padding nobody reads a result from)
+    a.MG = a.M_real > 0 ? (a.M_real + 16 * MT - 1) / (16 * MT) : M_pad / (16 * MT);
+    if (a.MG * 16 * MT > M_pad) a.MG = M_pad / (16 * MT);
     const int NT = a.N / (16 * NTW);
     a.xcd_map = (NT % 8 == 0) ? 1 : 0;
     size_t lds = (size_t)NW * MT * NTW * 4 * 64 * sizeof(float);
@@ -866,7 +869,12 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(c.xin_t, pw.in_w, 3 * d, d);
             a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS | TT_DBG_BITS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
-            TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
+            a.M_real = s.M;
+            // 32-row workgroup tiles when they still fit one round of the CUs (K = 12 prompts: 5 x 48 = 240 workgroups of 2/3 the
+            // work instead of 4 x 48 = 192), else 48-row tiles
+            const int nt = (3 * d) % 48 == 0 ? (3 * d) / 48 : (3 * d) / 32;
+            if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
+            else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0, r->cls_keep,
                            s.heads, d);
