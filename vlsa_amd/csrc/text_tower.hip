@@ -735,6 +735,19 @@ int launch_gemm_wide(const GemmArgs& a, int M_pad, hipStream_t st) {
     if (G == G1) return launch_gemm_g<MT, NW, PRO, G1, 2>(a, M_pad, st);
     return launch_gemm_g<MT, NW, PRO, 0, 2>(a, M_pad, st);
 }
+// 16-row workgroup tiles (the N = d products): 32-column tiles when the grid then still fits one round of the 256 CUs -- more
+// workgroups with a third less weight traffic each (the c_proj product moves the most bytes per workgroup: 18.7 -> ~10 us) --
+// else the 48-column choice of launch_gemm_wide.  M = rows that carry data.
+template <int NW, int G1>
+int launch_gemm_rows16(GemmArgs a, int M, int M_pad, hipStream_t st) {
+    a.M_real = M;
+    const int G = a.K / NW / 16;
+    if (a.N % 32 == 0 && ((M + 15) / 16) * (a.N / 32) <= 256) {
+        if (G == G1) return launch_gemm_g<1, NW, PRO_NONE, G1, 2>(a, M_pad, st);
+        return launch_gemm_g<1, NW, PRO_NONE, 0, 2>(a, M_pad, st);
+    }
+    return launch_gemm_wide<1, NW, PRO_NONE, G1>(a, M_pad, st);
+}
 template <int MT, int NW, int PRO, int G1, int G2>
 int launch_gemm_wide2(const GemmArgs& a, int M_pad, hipStream_t st) {
     const int G = a.K / NW / 16;
@@ -882,7 +895,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(c.attn_t, pw.out_w, d, d);
             a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = c.xmid_t; a.epi = EPI_BIAS | EPI_RESID;
-            TT_TRY((launch_gemm_wide<1, 4, PRO_NONE, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
         {
             GemmArgs a = gemm_args(c.xmid_t, pw.fc_w, 4 * d, d);
@@ -893,7 +906,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
             a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
-            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 24>(a, Mp, st)));
+            TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
     }
     hipLaunchKernelGGL(k_tt_lnf_fwd, dim3((s.ns_pad + 3) / 4), dim3(256), 0, st, c.x_final, r->seq_row0, m->lnf_w, m->lnf_b, c.pooled_t, d,
@@ -950,7 +963,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d ln_2 out = d h_pre @ W_fc
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
             a.Y = c.da; a.ldy = d;
-            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 24>(a, Mp, st)));
+            TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp);
         TT_LAUNCHED();
@@ -958,7 +971,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d attn = dx_mid @ W_out
             GemmArgs a = gemm_args(c.dxb_t, pw.out_w, d, d);
             a.Y = c.dattn; a.ldy = d;
-            TT_TRY((launch_gemm_wide<1, 4, PRO_NONE, 12>(a, Mp, st)));
+            TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d, c.dqkv_t, r->seq_row0,
                            r->cls_keep, s.heads, d);
@@ -966,7 +979,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
             a.Y = c.da; a.ldy = d;
-            TT_TRY((launch_gemm_wide<1, 8, PRO_NONE, 18>(a, Mp, st)));
+            TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp);
         TT_LAUNCHED();
