@@ -901,7 +901,12 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             GemmArgs a = gemm_args(c.xmid_t, pw.fc_w, 4 * d, d);
             a.bias = w.fc_b; a.Yt = c.hact_t; a.Ypre = save_for_backward ? h_pre : nullptr; a.ldy = 4 * d; a.epi = EPI_BIAS | EPI_GELU;
             a.ln_w = w.ln2_w; a.ln_b = w.ln2_b;
-            TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
+            a.M_real = s.M;
+            // 32 x 64 workgroup tiles when they fit one round (K = 12 prompts: 5 x 48 = 240 workgroups, 160 instead of 192 rows of
+            // f32-MFMA work -- this product is matrix-pipe-bound), else 48 x 48
+            if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
+                TT_TRY((launch_gemm_g<2, 4, PRO_LN, 12, 4>(a, Mp, st)));
+            else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
         {
             GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
@@ -958,7 +963,10 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
         {   // d h_pre = (dx @ W_proj) * gelu'(h_pre)
             GemmArgs a = gemm_args(c.dxa_t, pw.proj_w, 4 * d, d);
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
-            TT_TRY((launch_gemm_wide<3, 4, PRO_NONE, 12>(a, Mp, st)));
+            a.M_real = s.M;
+            if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
+                TT_TRY((launch_gemm_g<2, 4, PRO_NONE, 12, 4>(a, Mp, st)));
+            else TT_TRY((launch_gemm_wide<3, 4, PRO_NONE, 12>(a, Mp, st)));
         }
         {   // d ln_2 out = d h_pre @ W_fc
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
