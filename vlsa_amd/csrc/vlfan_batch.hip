@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 5) void k_vlfan_merge_batch(const float* __res
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) float4 sacc[128];
     __shared__ float sl;
-    __builtin_amdgcn_s_setprio(3);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = blockIdx.y, c0 = blockIdx.x * 512, bag = blockIdx.z;
     pm += (size_t)bag * st.bm;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512, 4) void k_vlfan_merge_pool_batch(const float* 
     __shared__ __attribute__((aligned(16))) float4 sacc[VLSA_MAX_P][16];
     __shared__ float slt[VLSA_MAX_P][16];
     __shared__ float spw[VLSA_MAX_P];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int tid = threadIdx.x;
     const int gs = tid >> 8, p = (tid >> 4) & 15, c4 = tid & 15, bag = blockIdx.y;
     const int col = blockIdx.x * 64 + c4 * 4;

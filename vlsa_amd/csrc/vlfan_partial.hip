@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_prepare_queries(const float* __restrict
                                                           const float* __restrict__ T, float* __restrict__ That,
                                                           float* __restrict__ tnorm) {
     __shared__ float red[4];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     if (blockIdx.x >= 17) {  // fused text-feature normalisation: F.normalize(text_features) (model/vlsa.py:186)
         const int r = blockIdx.x - 17, tid = threadIdx.x;
         const float* x = T + (size_t)r * D;

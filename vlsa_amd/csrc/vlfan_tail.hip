@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_attn_normalise(const float* __restrict_
 __global__ __launch_bounds__(256) void k_normalize_rows(const float* __restrict__ in, int D, float* __restrict__ out,
                                                          float* __restrict__ norms) {
     __shared__ float red[4];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int r = blockIdx.x, tid = threadIdx.x;
     const float* x = in + (size_t)r * D;
     float ss = 0.f;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ rows, in
     __shared__ float slog[VLSA_MAX_K];
     __shared__ float red[4];
     __shared__ int s_last;
-    __builtin_amdgcn_s_setprio(3);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);  // short kernel that may co-run with a persistent streaming kernel: win issue arbitration
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {   // batched launch: blockIdx.y selects the bag; every per-bag pointer is advanced here
         const int bag = blockIdx.y;
@@ -271,7 +271,7 @@ constexpr int kHeadBagsPerBlock = 8;
 __global__ __launch_bounds__(256) void k_head_linear(const float* __restrict__ pooled, int B, int D,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
                                                       float* __restrict__ v) {
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int bag0 = blockIdx.y * kHeadBagsPerBlock;
     float4 wq[2][VLSA_MAX_D / 256];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v
     __shared__ float sp[VLSA_MAX_D];
     __shared__ float slog[VLSA_MAX_K];
     __shared__ float red[4];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, bag = blockIdx.x;
     v += (size_t)bag * D;
     vhat += (size_t)bag * D;

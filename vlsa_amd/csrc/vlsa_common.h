@@ -6,6 +6,11 @@
 
 #include "../../include/vlsa_hip.h"
 
+// wave priority of the short tail / preparation kernels that co-run with a persistent streaming kernel
+#ifndef VLSA_TAIL_PRIO
+#define VLSA_TAIL_PRIO 3
+#endif
+
 namespace vlsa {
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
