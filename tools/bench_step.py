@@ -65,6 +65,19 @@ for label, sizes in (("TCGA-like 2k-12k", [int(x) for x in torch.randint(2000, 1
     torch.cuda.synchronize()
     tt = (time.perf_counter() - t0) / 20
     npatch = sum(sizes)
+    if "--profile" in sys.argv:       # host side of one step (the GPU work of a small-bag step is ~2.4 ms: is the host the limit?)
+        import cProfile, pstats
+        t0 = time.perf_counter()
+        for _ in range(R):
+            step()
+        th = (time.perf_counter() - t0) / R
+        torch.cuda.synchronize()
+        print(f"host-only per step {th * 1e3:.2f} ms")
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(20):
+            step()
+        pr.disable(); torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
     print(f"{label}: {npatch} patches in 32 bags: {dt * 1e3:.2f} ms per optimizer step ({npatch / dt / 1e9:.2f} G patches/s trained), of which the "
           f"text side (rank prompts -> CONCH-size tower, forward + backward) {tt * 1e3:.2f} ms; the reference runs the tower 32x per step on top of "
           f"the bag path (1.44 s per call on its CPU path, BASELINE.md)")

@@ -206,11 +206,20 @@ class CONCHPromptEncoder(nn.Module):
 
     # -- C-side view of the weights ------------------------------------------------------------------------------------
     def _tower_tensors(self):
+        # cached: ~300 nn.Module attribute look-ups per call otherwise, several calls per step.  The Parameter objects survive
+        # .to(device) / load_state_dict (in-place), whose effects the callers' (data_ptr, _version) keys still see; re-assigning a
+        # parameter attribute is caught by the identity check on the first and last tensors.
+        blocks = self.transformer.resblocks
+        c = self.__dict__.get("_tt_cache")
+        if (c is not None and c[0] == len(blocks) and c[1][0] is self.positional_embedding and c[1][4] is self.text_projection
+                and (len(blocks) == 0 or c[1][-1] is blocks[len(blocks) - 1].mlp.c_proj.bias)):
+            return c[1]
         ts = [self.positional_embedding, self.cls_emb, self.ln_final.weight, self.ln_final.bias, self.text_projection]
-        for blk in self.transformer.resblocks:
+        for blk in blocks:
             ts += [blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.attn.out_proj.weight,
                    blk.attn.out_proj.bias, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias,
                    blk.mlp.c_proj.weight, blk.mlp.c_proj.bias]
+        self.__dict__["_tt_cache"] = (len(blocks), ts)
         return ts
 
     def _c_model(self, device):
@@ -239,9 +248,8 @@ class CONCHPromptEncoder(nn.Module):
         """The tiled (MFMA-fragment-major) copies of the tower's matrices the product kernels read, rebuilt when a weight's
         storage or in-place version changes (load_state_dict, .to(device)); the backward set (transposes) only once a
         gradient is asked for."""
-        mats = [self.text_projection]
-        for blk in self.transformer.resblocks:
-            mats += [blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight]
+        ts = self._tower_tensors()
+        mats = [ts[4]] + [ts[5 + 12 * i + j] for i in range((len(ts) - 5) // 12) for j in (2, 4, 8, 10)]   # projection, in / out / fc / proj
         key = tuple((t.data_ptr(), t._version) for t in mats)
         if self._pk is not None and self._pk_key == key and (self._pk_bwd or not with_backward):
             return self._pk

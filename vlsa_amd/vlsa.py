@@ -91,8 +91,21 @@ class VLSA(nn.Module):
         key = [torch.is_grad_enabled()]
         for m in mods:
             key.append((id(m), m.training))
-            key.extend((id(t), t._version) for t in m.parameters())
-            key.extend((id(t), t._version) for t in m.buffers())
+            # own walk over the module tree (parameters / buffers of every submodule, dict order): nn.Module.parameters() spends
+            # ~0.3 ms per call on a 150-tensor text tower in generator / prefix-string bookkeeping, and this runs once per step
+            stack, seen = [m], set()
+            while stack:
+                x = stack.pop()
+                if id(x) in seen:
+                    continue
+                seen.add(id(x))
+                for t in x._parameters.values():
+                    if t is not None:
+                        key.append((id(t), t._version))
+                for t in x._buffers.values():
+                    if t is not None:
+                        key.append((id(t), t._version))
+                stack.extend(c for c in x._modules.values() if c is not None)
         return tuple(key)
 
     def compute_text_features_with_coop(self, prompt_learner):
