@@ -318,6 +318,20 @@ int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int
                                    int G, float* pm, float* pl, float* pacc, void* stream);
 
 /*
+ * Sentence assembly of the CoOp prompt learners in embedding space (reference model/prompt_learners/rank_prompt_learner.py:100-156,
+ * plain_prompt_learner.py): out [R, L, dim] = the sentence template (<sot>, ".", <eot>, pad embeddings) with slot s of sentence
+ * i (position s + 1) taken from source order[i, s]: < C -> context row (context [C, dim], or [R, C, dim] with ctx_per_rank),
+ * >= C -> rank token row, interpolated over the n_base base ranks with interp [R, n_base] (rank [n_base, T, dim]) or, interp NULL,
+ * rank [R, T, dim] directly; order [R, C + T] int32, -1 = unused slot.  Backward: pos [R, C + T] int32 = position of every
+ * source in its sentence (-1: absent); writes dcontext (shape of context) and drank (shape of rank, n_rank_rows = its first dim).
+ */
+int vlsa_prompt_sentences(const float* templ, const float* context, int ctx_per_rank, const float* rank, const float* interp,
+                          int n_base, const int* order, int R, int L, int S, int C, int T, int dim, float* out, void* stream);
+int vlsa_prompt_sentences_backward(const float* dout, const int* pos, int ctx_per_rank, const float* interp, int n_base,
+                                   int n_rank_rows, int R, int L, int S, int C, int T, int dim, float* dcontext, float* drank,
+                                   void* stream);
+
+/*
  * Exact Shapley values of the P text prototypes for the survival risk sum_k (K - k) softmax_k(logit_scale * mean_{p in S} sim[p, k])
  * with v(empty) = 1 (reference utils/model_inference.py:23-79, an O(P 2^P) host loop there).  sim: [P, K] fp32 decoupled
  * similarities (device); values: workspace of 2^P floats (the coalition values, kept for inspection); shap: [P].  P <= 16.

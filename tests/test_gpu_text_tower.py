@@ -144,3 +144,37 @@ def test_vlsa_end_to_end_with_gpu_text_side():
         t0 = model.forward_text_only().clone()
         pl.rank_embeds.add_(0.01)
         assert not torch.equal(model.forward_text_only(), t0)
+
+
+@pytest.mark.parametrize("kind", ["rank_tail", "rank_front", "rank_middle", "rank_own_context", "plain_ragged"])
+def test_sentence_assembly_kernels_match_the_torch_ops(kind):
+    """vlsa_prompt_sentences / _backward (one launch each way) vs the learner's torch-op assembly on the same device -- which
+    tests/test_text_modules_cpu.py pins to the reference's sentences (fixtures) on the CPU."""
+    from vlsa_amd.prompt_learner import PlainPromptLearner, RankPromptLearner
+    torch.manual_seed(5)
+    vocab, dim = 500, 128
+    E = torch.nn.Embedding(vocab, dim).cuda()
+    table, ctx_key, names = TC.synthetic_prompt_table(vocab, 3, n_ctx=6, rank_lens=(4, 2, 3, 4) if kind == "plain_ragged" else (3, 3, 3, 3))
+    tok = TC.ReplayTokenizer(table)
+    cfg = dict(max_num_tokens=127, embedding_dim=dim, embedding_dtype=torch.float32)
+    if kind == "plain_ragged":
+        pl = PlainPromptLearner(cfg, tok, E, num_ranks=4, num_tokens_per_rank=[4, 2, 3, 4], num_context_tokens=6,
+                                init_context=ctx_key, init_rank_names=names)
+    else:
+        pl = RankPromptLearner(cfg, tok, E, num_base_ranks=4, num_ranks=7, num_tokens_per_rank=3, num_context_tokens=6,
+                               rank_tokens_position={"rank_front": "front", "rank_middle": "middle"}.get(kind, "tail"),
+                               rank_specific_context=kind == "rank_own_context", init_context=ctx_key, init_rank_names=names)
+    with torch.no_grad():
+        pl.context_embeds.add_(torch.randn_like(pl.context_embeds) * 0.1)
+        pl.rank_embeds.add_(torch.randn_like(pl.rank_embeds) * 0.1)
+    G = torch.randn_like(pl.sentence_embeds)
+    out = pl()
+    (out * G).sum().backward()
+    g_hip = (pl.context_embeds.grad.clone(), pl.rank_embeds.grad.clone())
+    pl.zero_grad(set_to_none=True)
+    pl._torch_ops_only = True
+    ref = pl()
+    (ref * G).sum().backward()
+    assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-6
+    assert (g_hip[0] - pl.context_embeds.grad).abs().max().item() < 1e-5 * max(1.0, pl.context_embeds.grad.abs().max().item())
+    assert (g_hip[1] - pl.rank_embeds.grad).abs().max().item() < 1e-5 * max(1.0, pl.rank_embeds.grad.abs().max().item())

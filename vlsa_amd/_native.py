@@ -96,6 +96,10 @@ _SIGNATURES = {
                                         c_int64, c_void_p]),
     "vlsa_scored_pool_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "vlsa_prompt_sentences": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_void_p]),
+    "vlsa_prompt_sentences_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_prototype_shapley": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vlsa_featproj_prep_bytes": (c_size_t, []),
     "vlsa_prepare_featproj": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -42,6 +42,48 @@ def _spread_names(names: Sequence[str], n: int) -> List[str]:
     return list(names)
 
 
+class _SentenceFn(torch.autograd.Function):
+    """Sentence assembly on the device (vlsa_prompt_sentences / _backward): what ``forward`` below does with torch ops, in one
+    launch each way -- the optimizer step is bound by the number of dependent launches."""
+
+    @staticmethod
+    def forward(ctx, context, rank, module):
+        from . import _native as nat
+        lib = nat.load()
+        order, pos = module._hip_plan()
+        templ = module.sentence_embeds
+        R, L, dim = templ.shape
+        S = order.shape[1]
+        T = rank.shape[1]
+        C = S - T
+        interp = module._interp()
+        cont, rk = context.detach().contiguous(), rank.detach().contiguous()
+        ip = None if interp is None else interp.detach().float().contiguous()
+        out = torch.empty_like(templ)
+        st = torch.cuda.current_stream(templ.device).cuda_stream
+        nat.check(lib.vlsa_prompt_sentences(templ.data_ptr(), cont.data_ptr(), int(context.dim() == 3), rk.data_ptr(),
+                                            None if ip is None else ip.data_ptr(), 0 if ip is None else ip.shape[1], order.data_ptr(),
+                                            R, L, S, C, T, dim, out.data_ptr(), st), "vlsa_prompt_sentences")
+        ctx.meta = (module, ip, context.shape, rank.shape, (R, L, S, C, T, dim))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _native as nat
+        lib = nat.load()
+        module, ip, cshape, rshape, (R, L, S, C, T, dim) = ctx.meta
+        _, pos = module._hip_plan()
+        dout = dout.contiguous()
+        dcontext = torch.empty(cshape, dtype=torch.float32, device=dout.device)
+        drank = torch.empty(rshape, dtype=torch.float32, device=dout.device)
+        st = torch.cuda.current_stream(dout.device).cuda_stream
+        nat.check(lib.vlsa_prompt_sentences_backward(dout.data_ptr(), pos.data_ptr(), int(len(cshape) == 3),
+                                                     None if ip is None else ip.data_ptr(), 0 if ip is None else ip.shape[1],
+                                                     rshape[0], R, L, S, C, T, dim, dcontext.data_ptr(), drank.data_ptr(), st),
+                  "vlsa_prompt_sentences_backward")
+        return dcontext, drank, None
+
+
 class PlainPromptLearner(nn.Module):
     """One learnable embedding block per rank (model/prompt_learners/plain_prompt_learner.py)."""
 
@@ -150,8 +192,29 @@ class PlainPromptLearner(nn.Module):
     def _rank_rows(self) -> torch.Tensor:
         return self.rank_embeds                       # [num_ranks, T, dim]
 
+    def _interp(self):
+        return None                                   # plain learner: one embedding row per rank
+
+    def _hip_plan(self):
+        """int32 slot -> source table (-1: unused) and its inverse (source -> sentence position) for vlsa_prompt_sentences"""
+        p = self.__dict__.get("_hip_tables")
+        if p is None or p[0].device != self._order.device:
+            order = torch.where(self._valid, self._order, torch.full_like(self._order, -1)).to(torch.int32).contiguous()
+            R, S = order.shape
+            pos = torch.full((R, S), -1, dtype=torch.int32)
+            oc, vc = self._order.cpu(), self._valid.cpu()
+            for i in range(R):
+                for s_ in range(S):
+                    if bool(vc[i, s_]):
+                        pos[i, int(oc[i, s_])] = s_ + 1
+            p = self.__dict__["_hip_tables"] = (order, pos.to(order.device))
+        return p
+
     def forward(self):
         ctx = self.context_embeds
+        if (ctx.is_cuda and ctx.dtype == torch.float32 and self.rank_embeds.dtype == torch.float32
+                and self.sentence_embeds.dtype == torch.float32 and not getattr(self, "_torch_ops_only", False)):
+            return _SentenceFn.apply(ctx, self.rank_embeds, self)        # one HIP launch forward, one backward
         if ctx.dim() == 2:
             ctx = ctx[None].expand(self.num_ranks, *ctx.shape)
         src = torch.cat([ctx, self._rank_rows()], dim=1)                                        # [R, C + T, dim]
@@ -204,6 +267,9 @@ class RankPromptLearner(PlainPromptLearner):
 
     def _rank_rows(self) -> torch.Tensor:
         return torch.einsum("rb,btd->rtd", self.interpolation_weights, self.rank_embeds)
+
+    def _interp(self):
+        return self.interpolation_weights
 
 
 def load_prompt_learner(method: str, cfg: dict):
