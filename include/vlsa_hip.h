@@ -279,6 +279,18 @@ int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mod
                             float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
                             void* stream);
 
+/*
+ * Backward of vlsa_head_forward_batch with pool_mode MEAN (the training step's tail: model/deepmil.py:203-204, model/vlsa.py:188-192
+ * under autograd) in two launches: dlogits [B, K] (+ optional gradients g_vhat [B, D], g_That [K, D] flowing into the returned unit
+ * features) -> drows [B, P, D], dW [D, D], db [D] (W NULL: identity adapter, no dW / db), dT [K, D] (w.r.t. the RAW text features:
+ * tnorm [K] = their norms from vlsa_normalize_rows), dls [1] (w.r.t. the pre-exp logit scale).  pooled, vhat, vnorm, logits: the
+ * forward's outputs.  workspace: (B * D + B) floats.
+ */
+int vlsa_head_backward_batch(const float* dlogits, const float* g_vhat, const float* g_That, const float* pooled, const float* vhat,
+                             const float* vnorm, const float* That, const float* tnorm, const float* logits, const float* W,
+                             const float* logit_scale, int B, int P, int D, int K, float* workspace, float* drows, float* dW,
+                             float* db, float* dT, float* dls, void* stream);
+
 /* ---- the other MIL encoders the VLSA wrapper accepts (FeatMIL, DeepMIL) and the zero-shot path ---------- */
 
 /* Partials written by vlsa_scored_pool_partial / scratch rows of vlsa_colmax for N rows. */

@@ -108,3 +108,36 @@ def test_forward_bags_training_matches_per_bag_loop(pooling):
         scale = max(pb.grad.abs().max().item(), 1e-6)
         # + 2e-6: the attention-pooling output bias is softmax-invariant, its gradient is rounding noise around 0
         assert (pa.grad - pb.grad).abs().max().item() < GRAD_RTOL * scale + 2e-6, na
+
+
+@pytest.mark.parametrize("B,P,K,linear", [(32, 12, 12, True), (5, 7, 4, True), (1, 1, 1, True), (70, 12, 8, False), (3, 16, 64, True)])
+def test_fused_training_head_matches_torch_autograd(B, P, K, linear):
+    """VF.head_train (mean pooling + adapter + normalise + cosine logits: two launches each way) vs the same math as torch ops
+    under autograd (model/deepmil.py:203-204, model/vlsa.py:188-192), incl. gradients flowing into the returned unit features."""
+    import torch.nn.functional as TF
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    g = cases.gen(1200 + B)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev).requires_grad_(True)  # noqa: E731
+    rows, T, ls = mk(B, P, 512), mk(K, 512), torch.tensor(cases.LOGIT_SCALE, device=dev, requires_grad=True)
+    W, b = (mk(512, 512, sc=512 ** -0.5), mk(512, sc=0.1)) if linear else (None, None)
+    Gl, Gv, Gt = (torch.randn(B, K, generator=g).to(dev), torch.randn(B, 512, generator=g).to(dev) * 0.3,
+                  torch.randn(K, 512, generator=g).to(dev) * 0.3)
+
+    def ref():
+        pooled = rows.mean(dim=1)
+        v = pooled @ W.t() + b if linear else pooled
+        vh, th = TF.normalize(v, dim=-1), TF.normalize(T, dim=-1)
+        return ls.exp() * vh @ th.t(), vh, th
+    leaves = [t for t in (rows, W, b, T, ls) if t is not None]
+    for use_feats in (False, True):
+        lo, vh, th = F.head_train(rows, W, b, T, ls)
+        loss = (lo * Gl).sum() + ((vh * Gv).sum() + (th * Gt).sum() if use_feats else 0.0)
+        got = torch.autograd.grad(loss, leaves)
+        lo2, vh2, th2 = ref()
+        loss2 = (lo2 * Gl).sum() + ((vh2 * Gv).sum() + (th2 * Gt).sum() if use_feats else 0.0)
+        want = torch.autograd.grad(loss2, leaves)
+        assert (lo - lo2).abs().max().item() < 1e-4 and (vh - vh2).abs().max().item() < 1e-6 and (th - th2).abs().max().item() < 1e-6
+        for a, w_ in zip(got, want):
+            assert a.shape == w_.shape
+            assert (a - w_).abs().max().item() < 2e-5 * max(1.0, w_.abs().max().item()), (use_feats, a.shape)

@@ -533,3 +533,152 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
     return vlsa_head_forward(out, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, pooled, v, vhat, vnorm, logits,
                              incidence, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the batched head (mean query pooling + Linear / identity adapter + cosine logits) for the training step:
+//   pooled = mean_p rows;  v = W pooled + b;  v^ = v / |v|;  T^ = T / |T|;  logits = exp(ls) v^ T^^T     (model/deepmil.py:203-204,
+//   model/vlsa.py:188-192).  Two launches instead of ~25 autograd kernels -- the optimizer step is bound by its number of
+//   dependent launches.  k_head_bwd_dv (one workgroup per bag): d v^ = exp(ls) dlogits T^ (+ g_vhat), d v = (d v^ - v^ (v^ . d v^)) / |v|,
+//   and the bag's share of d ls = sum_k dlogits logits.  k_head_bwd_params: block j < D: dW[j, :] = sum_b dv[b, j] pooled[b, :],
+//   db[j] = sum_b dv[b, j]; the next B blocks: d pooled[b] = dv[b] W (identity head: dv[b]), d rows[b, p, :] = d pooled[b] / P;
+//   the next K blocks: d T^[k] = exp(ls) sum_b dlogits[b, k] v^[b] (+ g_That), d T = (d T^ - T^ (T^ . d T^)) / |T|; the last: d ls.
+namespace vlsa {
+__global__ __launch_bounds__(256) void k_head_bwd_dv(const float* __restrict__ dlogits, const float* __restrict__ g_vhat,
+                                                      const float* __restrict__ vhat, const float* __restrict__ vnorm,
+                                                      const float* __restrict__ That, const float* __restrict__ logits,
+                                                      const float* __restrict__ logit_scale, int D, int K, float* __restrict__ dv,
+                                                      float* __restrict__ dls_part) {
+    __shared__ float red[4];
+    __shared__ float sd[VLSA_MAX_K];
+    const int bag = blockIdx.x, tid = threadIdx.x;
+    const float ls = expf(logit_scale[0]);
+    if (tid < K) sd[tid] = dlogits[(size_t)bag * K + tid];
+    __syncthreads();
+    float dvh[VLSA_MAX_D / 256];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+        const int c = tid + 256 * i;
+        float s = 0.f;
+        if (c < D) {
+            for (int k = 0; k < K; ++k) s = fmaf(sd[k], That[(size_t)k * D + c], s);
+            s *= ls;
+            if (g_vhat != nullptr) s += g_vhat[(size_t)bag * D + c];
+            dot = fmaf(s, vhat[(size_t)bag * D + c], dot);
+        }
+        dvh[i] = s;
+    }
+    dot = block_sum_256(dot, red);
+    const float inv = 1.f / vnorm[bag];
+#pragma unroll
+    for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+        const int c = tid + 256 * i;
+        if (c < D) dv[(size_t)bag * D + c] = (dvh[i] - vhat[(size_t)bag * D + c] * dot) * inv;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(sd[k], logits[(size_t)bag * K + k], s);
+        dls_part[bag] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict__ dv, const float* __restrict__ pooled,
+                                                          const float* __restrict__ W, const float* __restrict__ dlogits,
+                                                          const float* __restrict__ g_That, const float* __restrict__ vhat,
+                                                          const float* __restrict__ That, const float* __restrict__ tnorm,
+                                                          const float* __restrict__ logit_scale, const float* __restrict__ dls_part,
+                                                          int B, int P, int D, int K, float* __restrict__ dW, float* __restrict__ db,
+                                                          float* __restrict__ drows, float* __restrict__ dT, float* __restrict__ dls) {
+    __shared__ float red[4];
+    __shared__ float sb[64];
+    const int tid = threadIdx.x;
+    int blk = blockIdx.x;
+    const int nW = W != nullptr ? D : 0;
+    if (blk < nW) {                                   // dW row j, db[j]
+        const int j = blk;
+        for (int b0 = 0; b0 < B; b0 += 64) {           // dv[:, j] of up to 64 bags at a time
+            __syncthreads();
+            if (tid < 64) sb[tid] = b0 + tid < B ? dv[(size_t)(b0 + tid) * D + j] : 0.f;
+            __syncthreads();
+            for (int c = tid; c < D; c += 256) {
+                float s = b0 == 0 ? 0.f : dW[(size_t)j * D + c];
+                for (int b = 0; b < 64 && b0 + b < B; ++b) s = fmaf(sb[b], pooled[(size_t)(b0 + b) * D + c], s);
+                dW[(size_t)j * D + c] = s;
+            }
+            if (tid == 0) {
+                float s = b0 == 0 ? 0.f : db[j];
+                for (int b = 0; b < 64 && b0 + b < B; ++b) s += sb[b];
+                db[j] = s;
+            }
+        }
+        return;
+    }
+    blk -= nW;
+    if (blk < B) {                                    // d pooled[b] -> d rows[b, p, :]
+        const int b = blk;
+        const float invP = 1.f / (float)P;
+        for (int c = tid; c < D; c += 256) {
+            float s;
+            if (W != nullptr) {
+                s = 0.f;
+                for (int j = 0; j < D; ++j) s = fmaf(dv[(size_t)b * D + j], W[(size_t)j * D + c], s);   // coalesced over c
+            } else {
+                s = dv[(size_t)b * D + c];
+            }
+            s *= invP;
+            for (int p = 0; p < P; ++p) drows[((size_t)b * P + p) * D + c] = s;
+        }
+        return;
+    }
+    blk -= B;
+    if (blk < K) {                                    // d T[k]
+        const int k = blk;
+        const float ls = expf(logit_scale[0]);
+        float dth[VLSA_MAX_D / 256];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+            const int c = tid + 256 * i;
+            float s = 0.f;
+            if (c < D) {
+                for (int b = 0; b < B; ++b) s = fmaf(dlogits[(size_t)b * K + k], vhat[(size_t)b * D + c], s);
+                s *= ls;
+                if (g_That != nullptr) s += g_That[(size_t)k * D + c];
+                dot = fmaf(s, That[(size_t)k * D + c], dot);
+            }
+            dth[i] = s;
+        }
+        dot = block_sum_256(dot, red);
+        const float inv = 1.f / fmaxf(tnorm[k], kNormEps);
+#pragma unroll
+        for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+            const int c = tid + 256 * i;
+            if (c < D) dT[(size_t)k * D + c] = (dth[i] - That[(size_t)k * D + c] * dot) * inv;
+        }
+        return;
+    }
+    if (tid == 0) {                                   // d logit_scale
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dls_part[b];
+        dls[0] = s;
+    }
+}
+}  // namespace vlsa
+
+/* workspace: (B * D + B) floats.  g_vhat [B, D] / g_That [K, D]: gradients flowing into the returned unit features, or NULL. */
+extern "C" int vlsa_head_backward_batch(const float* dlogits, const float* g_vhat, const float* g_That, const float* pooled,
+                                        const float* vhat, const float* vnorm, const float* That, const float* tnorm,
+                                        const float* logits, const float* W, const float* logit_scale, int B, int P, int D, int K,
+                                        float* workspace, float* drows, float* dW, float* db, float* dT, float* dls, void* stream) {
+    if (!dlogits || !pooled || !vhat || !vnorm || !That || !tnorm || !logits || !logit_scale || !workspace || !drows || !dT || !dls)
+        return VLSA_EINVAL;
+    if (W && (!dW || !db)) return VLSA_EINVAL;
+    if (B < 1 || P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D < 1 || D > VLSA_MAX_D) return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* dv = workspace;
+    float* dls_part = workspace + (size_t)B * D;
+    hipLaunchKernelGGL(vlsa::k_head_bwd_dv, dim3(B), dim3(256), 0, s, dlogits, g_vhat, vhat, vnorm, That, logits, logit_scale, D, K, dv, dls_part);
+    hipLaunchKernelGGL(vlsa::k_head_bwd_params, dim3((W ? D : 0) + B + K + 1), dim3(256), 0, s, dv, pooled, W, dlogits, g_That, vhat, That,
+                       tnorm, logit_scale, dls_part, B, P, D, K, dW, db, drows, dT, dls);
+    return launch_status();
+}

@@ -253,6 +253,26 @@ class VLFAN(nn.Module):
             return torch.cat(rs)
         if self.feat_proj is not None and not projected:
             bags = [self.feat_proj(x) for x in bags]          # frozen / inference: one fused HIP launch per bag, fp32 out
+        outs_cat, attn = self._aggregate_bags(bags, ret_with_attn)
+        pooled_out, pooled_ext = self.forward_query_pooling(outs_cat)
+        feats = self.visual_adapter(pooled_out)
+        if not ret_with_attn:
+            return feats
+        if pooled_ext is not None:
+            attn = [(a, pooled_ext[i:i + 1].detach()) for i, a in enumerate(attn)]
+        return feats, attn
+
+    def aggregate_bags(self, bags):
+        """The P aggregated rows of every bag, [B, P, C], differentiable w.r.t. the queries (persistent multi-bag kernels forward
+        and backward) -- ``forward_bags`` without the query pooling and the adapter; None when gradients have to reach the bags
+        or a trainable Feat_Projecter (``forward_bags`` then goes bag by bag through torch ops)."""
+        if self._projecter_trains() or any(torch.is_grad_enabled() and x.requires_grad for x in bags):
+            return None
+        if self.feat_proj is not None:
+            bags = [self.feat_proj(x) for x in bags]
+        return self._aggregate_bags(bags, False)[0]
+
+    def _aggregate_bags(self, bags, ret_with_attn):
         Q = self.get_query()
         scale = float(self.coattn_logit_scale.exp())
         outs, attn = [], []
@@ -264,13 +284,7 @@ class VLFAN(nn.Module):
                 attn.extend(a.unsqueeze(0) for a in r[1])
             else:
                 outs.append(r)
-        pooled_out, pooled_ext = self.forward_query_pooling(torch.cat(outs))
-        feats = self.visual_adapter(pooled_out)
-        if not ret_with_attn:
-            return feats
-        if pooled_ext is not None:
-            attn = [(a, pooled_ext[i:i + 1].detach()) for i, a in enumerate(attn)]
-        return feats, attn
+        return (outs[0] if len(outs) == 1 else torch.cat(outs)), attn
 
 
 class DeepMIL(nn.Module):

@@ -207,6 +207,64 @@ def head_forward(rows: torch.Tensor, pool: str, pool_w: Optional[torch.Tensor], 
     return dict(pooled=pooled, v=v, vhat=vhat, vnorm=vnorm, logits=logits, incidence=inc)
 
 
+_TICKETS = {}
+
+
+class _HeadTrainFn(torch.autograd.Function):
+    """(logits [B, K], v^ [B, D], T^ [K, D]) from the aggregated rows [B, P, D]: mean query pooling, Linear / identity adapter,
+    normalisation and cosine logits (model/deepmil.py:203-204, model/vlsa.py:188-192) -- two launches forward
+    (vlsa_normalize_rows, vlsa_head_forward_batch), two backward (vlsa_head_backward_batch), in place of ~40 autograd kernels:
+    the optimizer step is bound by its number of dependent launches."""
+
+    @staticmethod
+    def forward(ctx, rows, W, b, T, logit_scale):
+        lib, s = nat.load(), _stream()
+        rows = _f32c(rows)
+        B, P, D = rows.shape
+        dev = rows.device
+        Tc = _f32c(T)
+        K = Tc.shape[0]
+        That, tnorm = normalize_rows(Tc)
+        Wc = None if W is None else _f32c(W)
+        bc = None if b is None else _f32c(b)
+        ls = _f32c(logit_scale).reshape(1)
+        tk = _TICKETS.get((dev, B))
+        if tk is None:
+            tk = _TICKETS[(dev, B)] = torch.zeros(B, dtype=torch.int32, device=dev)      # the kernel hands the tickets back zeroed
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+        pooled, v, vhat, vnorm, logits = f(B, D), f(B, D), f(B, D), f(B), f(B, K)
+        nat.check(lib.vlsa_head_forward_batch(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(That), K, _p(ls), _p(tk),
+                                              _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), None, s), "vlsa_head_forward_batch")
+        ctx.save_for_backward(pooled, vhat, vnorm, That, tnorm, logits, ls, *([Wc] if Wc is not None else []))
+        ctx.meta = (B, P, D, K, Wc is not None, b is not None)
+        return logits, vhat, That
+
+    @staticmethod
+    def backward(ctx, dlogits, g_vhat, g_That):
+        lib, s = nat.load(), _stream()
+        B, P, D, K, has_w, has_b = ctx.meta
+        pooled, vhat, vnorm, That, tnorm, logits, ls = ctx.saved_tensors[:7]
+        Wc = ctx.saved_tensors[7] if has_w else None
+        dev = pooled.device
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+        dl = _f32c(dlogits) if dlogits is not None else torch.zeros(B, K, dtype=torch.float32, device=dev)
+        gv = None if g_vhat is None else _f32c(g_vhat)
+        gt = None if g_That is None else _f32c(g_That)
+        ws, drows, dT, dls = f(B * D + B), f(B, P, D), f(K, D), f(1)
+        dW, db = (f(D, D), f(D)) if has_w else (None, None)
+        nat.check(lib.vlsa_head_backward_batch(_p(dl), _p(gv), _p(gt), _p(pooled), _p(vhat), _p(vnorm), _p(That), _p(tnorm), _p(logits),
+                                               _p(Wc), _p(ls), B, P, D, K, _p(ws), _p(drows), _p(dW), _p(db), _p(dT), _p(dls), s),
+                  "vlsa_head_backward_batch")
+        return drows, dW, (db if has_b else None), dT, dls.reshape(())
+
+
+def head_train(rows: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor):
+    """Differentiable (logits, unit image features, unit text features) of a batch of aggregated rows [B, P, 512] -- see
+    ``_HeadTrainFn``; W / b: the Linear adapter (None: identity)."""
+    _need_gpu(rows, T, logit_scale)
+    return _HeadTrainFn.apply(rows, W, b, T, logit_scale)
+
+
 def vlfan_aggregate(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
                     kernel: int = nat.KERNEL_AUTO, want_attn: bool = False):
     """Inference-only cross-attention aggregation: out[P, D] = softmax_N(100 cos(Q, X)) @ X, plus A[P, N]."""

@@ -237,6 +237,13 @@ class VLSA(nn.Module):
         if self._needs_grad(text_features):
             if (isinstance(enc, VLFAN) and len(bags) > 0 and all(x.is_cuda and x.shape[-1] == 512 and x.shape[-2] > 0 for x in bags)
                     and all(x.dtype == bags[0].dtype for x in bags)):
+                spec = enc.fused_head_spec()
+                if (spec is not None and spec[0] == "mean" and text_features.is_cuda and text_features.shape[0] <= 64
+                        and text_features.shape[1] == 512):
+                    rows = enc.aggregate_bags(bags)          # [B, P, 512]: HIP forward + backward of the aggregation
+                    if rows is not None:
+                        # mean pooling + Linear / identity adapter + normalisation + cosine logits: two launches each way
+                        return VF.head_train(rows, spec[2], spec[3], text_features, self.logit_scale)
                 text_n = F.normalize(text_features, dim=-1)
                 image_features = F.normalize(enc.forward_bags(bags), dim=-1)
                 return self.logit_scale.exp() * image_features @ text_n.t(), image_features, text_n
