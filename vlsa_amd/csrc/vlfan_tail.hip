@@ -540,7 +540,7 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
 //   model/vlsa.py:188-192).  Two launches instead of ~25 autograd kernels -- the optimizer step is bound by its number of
 //   dependent launches.  k_head_bwd_dv (one workgroup per bag): d v^ = exp(ls) dlogits T^ (+ g_vhat), d v = (d v^ - v^ (v^ . d v^)) / |v|,
 //   and the bag's share of d ls = sum_k dlogits logits.  k_head_bwd_params: block j < D: dW[j, :] = sum_b dv[b, j] pooled[b, :],
-//   db[j] = sum_b dv[b, j]; the next B blocks: d pooled[b] = dv[b] W (identity head: dv[b]), d rows[b, p, :] = d pooled[b] / P;
+//   db[j] = sum_b dv[b, j]; the next D / 64 blocks: d pooled[:, 64 columns] = dv W (identity head: dv), d rows[b, p, :] = d pooled[b] / P;
 //   the next K blocks: d T^[k] = exp(ls) sum_b dlogits[b, k] v^[b] (+ g_That), d T = (d T^ - T^ (T^ . d T^)) / |T|; the last: d ls.
 namespace vlsa {
 __global__ __launch_bounds__(256) void k_head_bwd_dv(const float* __restrict__ dlogits, const float* __restrict__ g_vhat,
@@ -614,23 +614,56 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
         return;
     }
     blk -= nW;
-    if (blk < B) {                                    // d pooled[b] -> d rows[b, p, :]
-        const int b = blk;
+    const int nC = (D + 63) / 64;                     // d pooled -> d rows: one workgroup per 64 columns, all bags
+    if (blk < nC) {
+        // d pooled[b, c] = sum_j dv[b, j] W[j, c]: thread (c, js) walks a quarter of the j range for 8 bags at a time (dv staged in
+        // LDS, W row pieces coalesced, 8 independent loads in flight), the four quarters are summed through LDS
+        __shared__ float sdv[8][VLSA_MAX_D];
+        __shared__ float sred[4][8][64];
+        const int c = blk * 64 + (tid & 63), js = tid >> 6;
         const float invP = 1.f / (float)P;
-        for (int c = tid; c < D; c += 256) {
-            float s;
-            if (W != nullptr) {
-                s = 0.f;
-                for (int j = 0; j < D; ++j) s = fmaf(dv[(size_t)b * D + j], W[(size_t)j * D + c], s);   // coalesced over c
-            } else {
-                s = dv[(size_t)b * D + c];
+        const int jq = (D + 3) / 4;
+        for (int b0 = 0; b0 < B; b0 += 8) {
+            __syncthreads();
+            for (int e = tid; e < 8 * D; e += 256) {
+                const int b = e / D, j = e % D;
+                sdv[b][j] = b0 + b < B ? dv[(size_t)(b0 + b) * D + j] : 0.f;
             }
-            s *= invP;
-            for (int p = 0; p < P; ++p) drows[((size_t)b * P + p) * D + c] = s;
+            __syncthreads();
+            float acc[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+            if (W != nullptr) {
+                const int jbeg = js * jq, jend = min(D, jbeg + jq);
+                for (int j0 = jbeg; j0 < jend; j0 += 8) {
+                    float wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv[u] = (j0 + u < jend && c < D) ? W[(size_t)(j0 + u) * D + c] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < jend) {
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) acc[b] = fmaf(sdv[b][j0 + u], wv[u], acc[b]);
+                        }
+                }
+            } else if (js == 0 && c < D) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[b] = sdv[b][c];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sred[js][b][tid & 63] = acc[b];
+            __syncthreads();
+            for (int e = tid; e < 8 * 64; e += 256) {
+                const int b = e >> 6, cc = e & 63, col = blk * 64 + cc;
+                if (b0 + b < B && col < D) {
+                    const float v = ((sred[0][b][cc] + sred[1][b][cc]) + (sred[2][b][cc] + sred[3][b][cc])) * invP;
+                    for (int p = 0; p < P; ++p) drows[((size_t)(b0 + b) * P + p) * D + col] = v;
+                }
+            }
         }
         return;
     }
-    blk -= B;
+    blk -= nC;
     if (blk < K) {                                    // d T[k]
         const int k = blk;
         const float ls = expf(logit_scale[0]);
@@ -678,7 +711,7 @@ extern "C" int vlsa_head_backward_batch(const float* dlogits, const float* g_vha
     float* dv = workspace;
     float* dls_part = workspace + (size_t)B * D;
     hipLaunchKernelGGL(vlsa::k_head_bwd_dv, dim3(B), dim3(256), 0, s, dlogits, g_vhat, vhat, vnorm, That, logits, logit_scale, D, K, dv, dls_part);
-    hipLaunchKernelGGL(vlsa::k_head_bwd_params, dim3((W ? D : 0) + B + K + 1), dim3(256), 0, s, dv, pooled, W, dlogits, g_That, vhat, That,
+    hipLaunchKernelGGL(vlsa::k_head_bwd_params, dim3((W ? D : 0) + (D + 63) / 64 + K + 1), dim3(256), 0, s, dv, pooled, W, dlogits, g_That, vhat, That,
                        tnorm, logit_scale, dls_part, B, P, D, K, dW, db, drows, dT, dls);
     return launch_status();
 }
