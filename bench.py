@@ -137,6 +137,12 @@ def main():
     device = torch.device("cuda", local_rank)
     from vlsa_amd import functional as F
     from vlsa_amd.sharded import shard_bounds
+    # Everything imported so far (torch: ~10^6 tracked objects) out of the cyclic collector's way: a generation-2 pass otherwise
+    # stalls ONE host call for ~40 ms (measured: profiles/README.md), which in a ~100 ms timed region would be the GPU's to wait for.
+    # Nothing is skipped by this -- the collector stays enabled for what the run itself allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
 
     dist = None
     force_sharded = os.environ.get("VLSA_BENCH_FORCE_SHARDED") == "1"  # exercise the N > 1 code path on one GPU

@@ -8,6 +8,7 @@ import torch
 from vlsa_amd import functional as F
 
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 B, n, P, K = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 50000, 12, 4
 DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
 bags = [torch.randn(n, 512, device=dev).to(DT) for _ in range(B)]

@@ -5,6 +5,7 @@ import torch
 from vlsa_amd.vlsa import VLSA
 from vlsa_amd.inference import calc_text_img_similarity
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 K, P, n = 4, 12, 50000
 def timeit(f, reps=100):
     with torch.no_grad():
@@ -15,7 +16,7 @@ def timeit(f, reps=100):
     return (time.perf_counter() - t0) / reps * 1e6
 T = torch.randn(K, 512)
 for dt in (torch.bfloat16, torch.float32):
-    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+    torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     X = torch.randn(1, n, 512, device=dev).to(dt)
     rows = []
     for qp in ("mean", "max", "weight", "attention", "gated_attention"):

@@ -16,6 +16,7 @@ from vlsa_amd.prompt_learner import RankPromptLearner
 from vlsa_amd.vlsa import VLSA
 
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 K = P = 12
 c = TC.TOWERS["conch"]
 enc = CONCHPromptEncoder(width=c["width"], heads=c["heads"], layers=c["layers"], vocab_size=c["vocab"], output_dim=c["out_dim"])

@@ -11,6 +11,7 @@ import text_cases as TC
 import text_helpers as TH
 from test_text_modules_cpu import build_learner
 from test_gpu_text_tower import build_encoder
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 
 case = TC.RANK_CASES[0]
 inp = TH.rank_case_inputs(case)

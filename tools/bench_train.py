@@ -4,8 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
-    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+    torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(8)]
     Q = torch.randn(12, 512, device=dev, requires_grad=True)
     G = torch.randn(12, 512, device=dev)
@@ -22,7 +23,7 @@ for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (10000, torch.flo
 
 # 32 bags per optimizer step through the persistent batch kernels (forward + backward)
 for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (10000, torch.float32)):
-    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+    torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     base = torch.randn(32 * n + 4096, 512, device=dev).to(dt)
     bags = [base[i * n:(i + 1) * n] for i in range(32)]
     Q = torch.randn(12, 512, device=dev, requires_grad=True)

@@ -4,12 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd.vlsa import VLSA
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 K = 4
 for pooling in ("logit_mean", "logit_max", "logit_top10"):
     cfg = dict(name="FeatMIL", dim_in=512, pooling=pooling)
     net = VLSA(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
     for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (2798, torch.float32)):
-        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+        torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
         bags = [torch.randn(1, n, 512, device=dev).to(dt) for _ in range(8)]
         with torch.no_grad():
             for i in range(40): net(bags[i % 8])

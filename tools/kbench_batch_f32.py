@@ -3,8 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 for n, dt, B in ((50000, torch.float32, 32), (10000, torch.float32, 32), (2798, torch.float32, 32), (50000, torch.bfloat16, 32), (10000, torch.bfloat16, 32)):
-    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+    torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(B)]
     Q = torch.randn(12, 512, device=dev); T = torch.randn(4, 512, device=dev)
     W = torch.randn(512, 512, device=dev) / 22; b = torch.randn(512, device=dev); ls = torch.tensor(4.03, device=dev)

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd.layers import Feat_Projecter
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 m = Feat_Projecter(512, 512).to(dev)
 
 
@@ -21,7 +22,7 @@ def timed(fn, reps=50):
 
 
 for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
-    torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+    torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     X = torch.randn(n, 512, device=dev).to(dt)
     with torch.no_grad():
         t_hip = timed(lambda: m(X))

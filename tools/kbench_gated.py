@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"
+import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 for gated in (True, False):
     Wa = torch.randn(256, 512, device=dev) / 22; ba = torch.randn(256, device=dev) * 0.05
     Wg = torch.randn(256, 512, device=dev) / 22 if gated else None; bg = torch.randn(256, device=dev) * 0.05 if gated else None
@@ -12,7 +13,7 @@ for gated in (True, False):
     fs = F.FusedAttnScores()
     for n, dt in ((50000, torch.bfloat16), (40000, torch.bfloat16), (70000, torch.bfloat16), (20000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (400000, torch.bfloat16),
                   (50000, torch.float32), (10000, torch.float32), (2798, torch.float32)):
-        torch.cuda.empty_cache()   # fresh segments: bags carved out of a recycled allocator block can sit on small page fragments (TLB-bound outliers, profiles/README.md)
+        torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
         bags = [torch.randn(n, 512, device=dev).to(dt) for _ in range(4 if n > 100000 else 16)]
         for i in range(60): fs(bags[i % len(bags)], Wa, ba, Wg, bg, w2, c)
         torch.cuda.synchronize()
