@@ -28,7 +28,11 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / shared device tensors fail with the legacy mode); the driver's
+# environment exports this already -- keep it even when bench.py is launched from a bare shell
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
