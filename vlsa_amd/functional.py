@@ -228,11 +228,12 @@ class _HeadTrainFn(torch.autograd.Function):
         Wc = None if W is None else _f32c(W)
         bc = None if b is None else _f32c(b)
         ls = _f32c(logit_scale).reshape(1)
-        tk = _TICKETS.get((dev, B, s))           # per stream: two streams must not share a ticket counter
+        sid = s.value or 0
+        tk = _TICKETS.get((dev, B, sid))         # per stream: two streams must not share a ticket counter
         if tk is None:
             if len(_TICKETS) > 256:
                 _TICKETS.clear()
-            tk = _TICKETS[(dev, B, s)] = torch.zeros(B, dtype=torch.int32, device=dev)   # the kernel hands the tickets back zeroed
+            tk = _TICKETS[(dev, B, sid)] = torch.zeros(B, dtype=torch.int32, device=dev)   # the kernel hands the tickets back zeroed
         f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
         pooled, v, vhat, vnorm, logits = f(B, D), f(B, D), f(B, D), f(B), f(B, K)
         nat.check(lib.vlsa_head_forward_batch(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(That), K, _p(ls), _p(tk),
