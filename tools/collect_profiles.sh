@@ -38,6 +38,32 @@ def collect(tags, pat):
 json.dump(collect(("fetch", "write", "sq", "lds"), "partial_dma_batch"), open("$O/pmc_batch_kernel.json", "w"), indent=1)
 json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "k_gated_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)
 PY
+# PMC passes for the two persistent backward kernels (bf16 / fp32 batches): traffic vs the algorithmic bytes, matrix-pipe share
+pmc bw_fetch FETCH_SIZE -- python tools/prof_train.py 50000 20
+pmc bw_write WRITE_SIZE -- python tools/prof_train.py 50000 20
+pmc bw_sq SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python tools/prof_train.py 50000 20
+pmc bwf_fetch FETCH_SIZE -- python tools/prof_train.py 50000 20 fp32
+pmc bwf_sq SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python tools/prof_train.py 50000 20 fp32
+python - <<PY
+import csv, glob, collections, json
+def collect(tags, pat):
+    out = {}
+    for tag in tags:
+        fs = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
+        if not fs: continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            if pat in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            v = v[4:] or v
+            out[k] = sum(v) / len(v)
+    return out
+json.dump({"k_vlfan_backward_dma_batch (bf16, 32 x 50k bags)": collect(("bw_fetch", "bw_write", "bw_sq"), "backward_dma_batch"),
+           "k_vlfan_backward_f32_batch (fp32, 32 x 50k bags)": collect(("bwf_fetch", "bwf_sq"), "backward_f32_batch")},
+          open("$O/pmc_backward_kernels.json", "w"), indent=1)
+PY
+rm -rf $O/pmc_bw_fetch $O/pmc_bw_write $O/pmc_bw_sq $O/pmc_bwf_fetch $O/pmc_bwf_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/text -- python tools/bench_text.py > /dev/null 2>&1
 cp $(find $O/text -name "*kernel_stats.csv" | head -1) $O/text_kernel_stats.csv
 python tools/bench_text.py --cpu > $O/bench_text.txt 2>&1
