@@ -38,6 +38,26 @@ def collect(tags, pat):
 json.dump(collect(("fetch", "write", "sq", "lds"), "partial_dma_batch"), open("$O/pmc_batch_kernel.json", "w"), indent=1)
 json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "k_gated_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)
 PY
+# PMC passes for the fp32 streaming kernel
+pmc f32_fetch FETCH_SIZE -- python tools/run_batch.py 32 50000 0 f32
+pmc f32_write WRITE_SIZE -- python tools/run_batch.py 32 50000 0 f32
+pmc f32_sq SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python tools/run_batch.py 32 50000 0 f32
+python - <<PY
+import csv, glob, collections, json
+out = {}
+for tag in ("f32_fetch", "f32_write", "f32_sq"):
+    fs = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
+    if not fs: continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "partial_f32_batch" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        v = v[8:] or v
+        out[k] = sum(v) / len(v)
+json.dump(out, open("$O/pmc_batch_kernel_f32.json", "w"), indent=1)
+PY
+rm -rf $O/pmc_f32_fetch $O/pmc_f32_write $O/pmc_f32_sq
 # PMC passes for the two persistent backward kernels (bf16 / fp32 batches): traffic vs the algorithmic bytes, matrix-pipe share
 pmc bw_fetch FETCH_SIZE -- python tools/prof_train.py 50000 20
 pmc bw_write WRITE_SIZE -- python tools/prof_train.py 50000 20
