@@ -188,7 +188,10 @@ class VLFAN(nn.Module):
             return None
         mode, pw, W, b = spec
         X2 = VF._bag2d(X)
-        Q = self.get_query().detach().float().contiguous()
+        Q = self.get_query()
+        if torch.is_grad_enabled() and Q.requires_grad:
+            return None      # a query that needs a gradient but is no registered parameter (closure / plain callable): autograd route
+        Q = Q.detach().float().contiguous()
         P = Q.shape[0] - (1 if self.gated_query else 0)
         if not (1 <= P <= 16):
             return None

@@ -207,7 +207,22 @@ def head_forward(rows: torch.Tensor, pool: str, pool_w: Optional[torch.Tensor], 
     return dict(pooled=pooled, v=v, vhat=vhat, vnorm=vnorm, logits=logits, incidence=inc)
 
 
-_TICKETS = {}
+class HeadTickets:
+    """Ticket counters of the batched training head (one int32 per bag, handed back zeroed by the kernel), owned by whoever
+    runs the head -- ``VLSA`` keeps one per model.  One buffer per (device, B, stream): two streams must not share a counter,
+    and two heads of different models never do (no process-global state: SURVEY.md 8(b))."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, device, B: int, stream_id: int) -> torch.Tensor:
+        key = (device, B, stream_id)
+        t = self._bufs.get(key)
+        if t is None:
+            if len(self._bufs) > 64:
+                self._bufs.clear()
+            t = self._bufs[key] = torch.zeros(B, dtype=torch.int32, device=device)
+        return t
 
 
 class _HeadTrainFn(torch.autograd.Function):
@@ -217,7 +232,7 @@ class _HeadTrainFn(torch.autograd.Function):
     the optimizer step is bound by its number of dependent launches."""
 
     @staticmethod
-    def forward(ctx, rows, W, b, T, logit_scale):
+    def forward(ctx, rows, W, b, T, logit_scale, tickets):
         lib, s = nat.load(), _stream()
         rows = _f32c(rows)
         B, P, D = rows.shape
@@ -228,24 +243,20 @@ class _HeadTrainFn(torch.autograd.Function):
         Wc = None if W is None else _f32c(W)
         bc = None if b is None else _f32c(b)
         ls = _f32c(logit_scale).reshape(1)
-        sid = s.value or 0
-        tk = _TICKETS.get((dev, B, sid))         # per stream: two streams must not share a ticket counter
-        if tk is None:
-            if len(_TICKETS) > 256:
-                _TICKETS.clear()
-            tk = _TICKETS[(dev, B, sid)] = torch.zeros(B, dtype=torch.int32, device=dev)   # the kernel hands the tickets back zeroed
+        # the kernel hands the tickets back zeroed; without an owner: a fresh zeroed buffer (one memset launch more)
+        tk = torch.zeros(B, dtype=torch.int32, device=dev) if tickets is None else tickets.get(dev, B, s.value or 0)
         f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
         pooled, v, vhat, vnorm, logits = f(B, D), f(B, D), f(B, D), f(B), f(B, K)
         nat.check(lib.vlsa_head_forward_batch(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(That), K, _p(ls), _p(tk),
                                               _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), None, s), "vlsa_head_forward_batch")
         ctx.save_for_backward(pooled, vhat, vnorm, That, tnorm, logits, ls, *([Wc] if Wc is not None else []))
-        ctx.meta = (B, P, D, K, Wc is not None, b is not None)
+        ctx.meta = (B, P, D, K, Wc is not None, b is not None, tuple(logit_scale.shape))
         return logits, vhat, That
 
     @staticmethod
     def backward(ctx, dlogits, g_vhat, g_That):
         lib, s = nat.load(), _stream()
-        B, P, D, K, has_w, has_b = ctx.meta
+        B, P, D, K, has_w, has_b, ls_shape = ctx.meta
         pooled, vhat, vnorm, That, tnorm, logits, ls = ctx.saved_tensors[:7]
         Wc = ctx.saved_tensors[7] if has_w else None
         dev = pooled.device
@@ -258,14 +269,15 @@ class _HeadTrainFn(torch.autograd.Function):
         nat.check(lib.vlsa_head_backward_batch(_p(dl), _p(gv), _p(gt), _p(pooled), _p(vhat), _p(vnorm), _p(That), _p(tnorm), _p(logits),
                                                _p(Wc), _p(ls), B, P, D, K, _p(ws), _p(drows), _p(dW), _p(db), _p(dT), _p(dls), s),
                   "vlsa_head_backward_batch")
-        return drows, dW, (db if has_b else None), dT, dls.reshape(())
+        return drows, dW, (db if has_b else None), dT, dls.reshape(ls_shape), None
 
 
-def head_train(rows: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor):
+def head_train(rows: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor, tickets: Optional[HeadTickets] = None):
     """Differentiable (logits, unit image features, unit text features) of a batch of aggregated rows [B, P, 512] -- see
-    ``_HeadTrainFn``; W / b: the Linear adapter (None: identity)."""
+    ``_HeadTrainFn``; W / b: the Linear adapter (None: identity); tickets: the caller's ``HeadTickets`` (None: a zeroed
+    buffer is allocated per call)."""
     _need_gpu(rows, T, logit_scale)
-    return _HeadTrainFn.apply(rows, W, b, T, logit_scale)
+    return _HeadTrainFn.apply(rows, W, b, T, logit_scale, tickets)
 
 
 def vlfan_aggregate(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,

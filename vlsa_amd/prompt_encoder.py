@@ -125,7 +125,7 @@ class _TextTowerFn(torch.autograd.Function):
         if x.dtype != torch.float32 or x.stride(-1) != 1:
             x = x.float().contiguous()
         out = torch.empty(plan.n_seq, enc.output_dim, dtype=torch.float32, device=emb.device)
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)
         packed = enc._packed_weights(emb.device, with_backward=bool(save))
         nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(packed.data_ptr()),
                                       ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), save,
@@ -142,7 +142,7 @@ class _TextTowerFn(torch.autograd.Function):
         model = enc._c_model(dout.device)
         g = dout.detach().float().contiguous()
         demb = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = ctypes.c_void_p(torch.cuda.current_stream(dout.device).cuda_stream)
         nat.check(lib.vlsa_tt_backward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(ctx.packed.data_ptr()),
                                        ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(ctx.ws.data_ptr()),
                                        ctypes.c_void_p(demb.data_ptr()), demb.stride(0), demb.stride(1), demb.numel(), s),
@@ -174,6 +174,7 @@ class CONCHPromptEncoder(nn.Module):
             self.token_embedding = t.token_embedding
             if self.cls_emb is None:
                 raise NotImplementedError("the CONCH text tower embeds a CLS token (embed_cls=True); towers without one are not supported")
+            self._check_architecture(t)
         else:
             self.pad_id, self.heads = 0, heads
             self.positional_embedding = nn.Parameter(torch.empty(context_length, width))
@@ -189,6 +190,37 @@ class CONCHPromptEncoder(nn.Module):
                             "embedding_dtype": self.token_embedding.weight.dtype}
         self._cm, self._cm_key, self._plans = None, None, {}
         self._pk, self._pk_key, self._pk_bwd = None, None, False
+
+    def _check_architecture(self, tower):
+        """The kernels hard-code the CoCa text block of model/conch/transformer.py:191-247: pre-LN with eps 1e-5, exact (erf)
+        GELU, no LayerScale, MLP ratio 4, causal mask.  Anything else would give wrong text features silently: refuse it."""
+        def bad(what):
+            raise NotImplementedError(f"text tower: {what} -- the HIP tower implements the CONCH text block only "
+                                      "(LayerNorm eps 1e-5, erf GELU, no LayerScale, mlp ratio 4, causal attention)")
+        width = self.positional_embedding.shape[1]
+        lns = [self.ln_final]
+        for blk in self.transformer.resblocks:
+            lns += [blk.ln_1, blk.ln_2]
+            for name in ("ls_1", "ls_2"):
+                ls = getattr(blk, name, None)
+                if ls is not None and not isinstance(ls, nn.Identity):
+                    bad(f"LayerScale ({name})")
+            if getattr(blk, "ln_1_kv", None) is not None:
+                bad("a cross-attention block")
+            act = getattr(blk.mlp, "gelu", None)
+            if not isinstance(act, nn.GELU) or getattr(act, "approximate", "none") != "none":
+                bad(f"activation {type(act).__name__}")
+            if blk.mlp.c_fc.out_features != 4 * width or blk.mlp.c_proj.in_features != 4 * width:
+                bad("mlp ratio != 4")
+        for ln in lns:
+            if abs(float(ln.eps) - 1e-5) > 1e-12 or not getattr(ln, "elementwise_affine", True):
+                bad(f"LayerNorm eps {ln.eps}")
+        mask = getattr(tower, "attn_mask", None)
+        if mask is not None:
+            n = mask.shape[-1]
+            causal = torch.full((n, n), float("-inf")).triu_(1)
+            if not torch.equal(mask.detach().float().cpu(), causal):
+                bad("a non-causal attention mask")
 
     def reset_parameters(self):
         """TextTransformer.init_parameters (model/conch/transformer.py:376-392)."""
@@ -260,19 +292,24 @@ class CONCHPromptEncoder(nn.Module):
             raise VlsaNativeError("text tower: unsupported shape (width % 128, width <= 768, 64 features per head, out_dim % 64)")
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         nat.check(lib.vlsa_tt_pack_weights(ctypes.byref(model), ctypes.c_void_p(buf.data_ptr()), int(with_backward),
-                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vlsa_tt_pack_weights")
+                                           ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "vlsa_tt_pack_weights")
         self._pk, self._pk_key, self._pk_bwd = buf, key, bool(with_backward)
         return buf
 
     def _plan(self, pseudo_tokens, device) -> _RowPlan:
-        key = (pseudo_tokens.data_ptr(), pseudo_tokens._version, tuple(pseudo_tokens.shape), str(device))
+        # fast path: the very tensor object (a learner's `pseudo_sentence_tokens` buffer) seen last time, unchanged in place;
+        # otherwise keyed on CONTENT (the pattern of non-pad positions): `generate_pseudo_tokens` makes a new tensor per call
+        last = self.__dict__.get("_plan_last")
+        if last is not None and last[0] is pseudo_tokens and last[1] == pseudo_tokens._version and last[2].row_seq.device == device:
+            return last[2]
+        key = (bytes((pseudo_tokens != 0).to("cpu", torch.uint8).contiguous().numpy().data), tuple(pseudo_tokens.shape), str(device))
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 16:
                 self._plans.clear()
             plan = _RowPlan(pseudo_tokens, self.context_length, device)
-            plan.keep = pseudo_tokens           # keeps the key's data_ptr alive / unique
             self._plans[key] = plan
+        self.__dict__["_plan_last"] = (pseudo_tokens, pseudo_tokens._version, plan)
         return plan
 
     # -- reference API ---------------------------------------------------------------------------------------------------

@@ -75,6 +75,8 @@ class VLSA(nn.Module):
         self._text_cache_key = None
         self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init)  # CoCa init, model/conch/coca_model.py:187
         self._plans = {}
+        self._head_tickets = VF.HeadTickets()
+        self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ was computed from
 
     # -- text side -----------------------------------------------------------------------------------------
     def _provider_modules(self):
@@ -183,9 +185,24 @@ class VLSA(nn.Module):
             self._plans[key] = plan
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=X2.device)  # noqa: E731
         outs = {"logits": f(1, K), "vhat": f(1, D), "That": None}   # fresh tensors, written by the kernels directly
-        # queries / text features only change with their parameters: in an evaluation loop they are prepared once, not per bag
-        qsrc = list(enc.Q.parameters()) + list(enc.Q.buffers()) if isinstance(enc.Q, nn.Module) else [enc.Q]
-        pkey = tuple((t.data_ptr(), t._version) for t in qsrc) + ((text_features.data_ptr(), text_features._version),)
+        # queries / text features only change with their parameters: in an evaluation loop they are prepared once, not per bag.
+        # The key never contains the ADDRESS of a transient tensor (a freed block is handed out again by the caching allocator
+        # with `_version == 0`): the text side contributes the identity of the exact tensor object the last preparation read,
+        # which this module keeps alive (`_prepared_text`), the queries the identity + in-place version of their source
+        # parameters / buffers (alive as long as the query network is).  A query source this object cannot enumerate (a plain
+        # callable) gives no key: prepare every call.
+        if isinstance(enc.Q, nn.Module):
+            qsrc = list(enc.Q.parameters()) + list(enc.Q.buffers())
+        elif isinstance(enc.Q, torch.Tensor):
+            qsrc = [enc.Q]
+        else:
+            qsrc = None
+        if qsrc is None:
+            pkey = None
+        else:
+            if self._prepared_text is not text_features:
+                self._prepared_text, self._prepared_gen = text_features, self._prepared_gen + 1
+            pkey = tuple((id(t), t._version) for t in qsrc) + ((self._prepared_gen, text_features._version),)
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
                  None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey,
@@ -243,7 +260,7 @@ class VLSA(nn.Module):
                     rows = enc.aggregate_bags(bags)          # [B, P, 512]: HIP forward + backward of the aggregation
                     if rows is not None:
                         # mean pooling + Linear / identity adapter + normalisation + cosine logits: two launches each way
-                        return VF.head_train(rows, spec[2], spec[3], text_features, self.logit_scale)
+                        return VF.head_train(rows, spec[2], spec[3], text_features, self.logit_scale, self._head_tickets)
                 text_n = F.normalize(text_features, dim=-1)
                 image_features = F.normalize(enc.forward_bags(bags), dim=-1)
                 return self.logit_scale.exp() * image_features @ text_n.t(), image_features, text_n
