@@ -89,7 +89,7 @@ def main():
     prompt_features = torch.randn(P, 512, generator=g)                     # frozen text prototypes of the PromptAdapter
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean", pred_head="default")
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=prompt_features, res_ratio=0.5)
-    net = VLSA(cfg, prompt_learner=learner, prompt_encoder=tower, query_network=qnet).to(dev)
+    net = VLSA.from_modules(cfg, prompt_learner=learner, prompt_encoder=tower, query_network=qnet).to(dev)
     with torch.no_grad():
         tf = net.forward_text_only()
     print(f"[text]   {K} rank prompts x {int(learner.pseudo_sentence_tokens[0].max())} tokens -> text features {tuple(tf.shape)} "

@@ -26,7 +26,7 @@ def _model(P, K, params, dev):
     cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, drop_rate=0.25, num_query=P, query="Text",
                gated_query=False, query_pooling="mean", pred_head="default", pooling="logit_top10")
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
-    m = VLSA(cfg, pretrained_text_features=params["T"].clone(), query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    m = VLSA.from_modules(cfg, pretrained_text_features=params["T"].clone(), query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
     with torch.no_grad():
         m.mil_encoder.Q.residual_features.copy_(params["resid"])
         m.mil_encoder.visual_adapter.weight.copy_(params["W"])

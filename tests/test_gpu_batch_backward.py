@@ -85,7 +85,7 @@ def test_forward_bags_training_matches_per_bag_loop(pooling):
         torch.manual_seed(5)
         cfg = dict(name="VLFAN", dim_in=512, dim_hid=64, use_feat_proj=False, query="Parameter", num_query=P,
                    gated_query=False, query_pooling=pooling, pred_head="default")
-        m = VLSA(cfg, pretrained_text_features=params["T"].clone()).to(dev)
+        m = VLSA.from_modules(cfg, pretrained_text_features=params["T"].clone()).to(dev)
         with torch.no_grad():
             m.mil_encoder.Q.copy_((0.5 * params["resid"] + params["prompt"]).to(dev))
             m.mil_encoder.visual_adapter.weight.copy_(params["W"].to(dev))

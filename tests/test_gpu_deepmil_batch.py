@@ -58,7 +58,7 @@ def test_deepmil_forward_bags_equals_per_bag_forward(pooling):
     torch.manual_seed(21)
     cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25, pooling=pooling,
                pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
-    model = VLSA(cfg, pretrained_text_features=torch.randn(4, 512), logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
+    model = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(4, 512), logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
     sizes = [700 + 37 * i for i in range(70)]                 # > 64 bags: two chunks
     bags = [cases.make_bag(n, 6200 + i, "clustered").to(torch.bfloat16).to(dev) for i, n in enumerate(sizes)]
     with torch.no_grad():
@@ -76,7 +76,7 @@ def test_featmil_forward_bags_equals_per_bag_forward(pooling, dtype):
     from vlsa_amd.vlsa import VLSA
     dev = torch.device("cuda", 0)
     T = torch.randn(4, 512, generator=cases.gen(31))
-    model = VLSA(dict(name="FeatMIL", dim_in=512, pooling=pooling), pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
+    model = VLSA.from_modules(dict(name="FeatMIL", dim_in=512, pooling=pooling), pretrained_text_features=T, logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
     sizes = [1, 33, 2798, 5000, 64] + [300 + 11 * i for i in range(62)]            # > 64 bags: two chunks of the mean launch
     bags = [cases.make_bag(n, 6300 + i, "clustered" if i % 2 else "iid").to(dtype).to(dev) for i, n in enumerate(sizes)]
     with torch.no_grad():

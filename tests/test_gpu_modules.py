@@ -28,7 +28,7 @@ def build_vlsa(case, params, pool, requires_grad=True):
     tp = TextParam(params["T"])
     qnet = None if gated else PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"],
                                             res_ratio=0.5)
-    model = VLSA(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     with torch.no_grad():
         if gated:
@@ -111,7 +111,7 @@ def test_vlsa_zeroshot_and_featmil(case):
     fx = H.load_fixture("zeroshot_" + name)
     X = cases.make_bag(N, seed)
     params = cases.make_params(1, K, seed + 1000)
-    model = VLSA(dict(name="FeatMIL", pooling=pooling), pretrained_text_features=params["T"],
+    model = VLSA.from_modules(dict(name="FeatMIL", pooling=pooling), pretrained_text_features=params["T"],
                  logit_scale_init=cases.LOGIT_SCALE).cuda().eval()
     with torch.no_grad():
         logits, img, txt = model(X[None].cuda())
@@ -133,7 +133,7 @@ def test_vlsa_deepmil_forward_backward(case):
     tp = TextParam(params["T"])
     cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25,
                pooling=pooling, pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
-    model = VLSA(cfg, text_provider=lambda: tp.T, prompt_learner=tp, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     pp = cases.make_pool_params(pooling, seed + 3000)
     ad = cases.make_adapter_params(seed + 4000)
@@ -234,7 +234,7 @@ def test_forward_bags_with_module_pooling_matches_per_bag_forward(pooling):
     params = cases.make_params(P, K, 9300)
     torch.manual_seed(3)
     cfg = dict(name="VLFAN", dim_in=512, dim_hid=64, use_feat_proj=False, query="Parameter", num_query=P, query_pooling=pooling)
-    m = VLSA(cfg, pretrained_text_features=params["T"].clone()).to(dev).eval()
+    m = VLSA.from_modules(cfg, pretrained_text_features=params["T"].clone()).to(dev).eval()
     bags = [cases.make_bag(n, 9310 + i).to(torch.bfloat16).to(dev)[None] for i, n in enumerate([700, 64, 2798, 1])]
     with torch.no_grad():
         lb, fb, tb = m.forward_bags(bags)

@@ -57,7 +57,7 @@ def test_feat_projecter_forward_and_gradients(case):
     else:
         cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=True, drop_rate=0.25,
                    pooling=pooling, pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
-    model = VLSA(cfg, text_provider=lambda: tp.T, prompt_learner=tp, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     fpp = cases.make_featproj_params(seed + 5000)
     with torch.no_grad():
@@ -119,7 +119,7 @@ def test_deepmil_linear_head(case):
     params = cases.make_params(1, K, seed + 1000)
     cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25,
                pooling=pooling, pred_head="default")
-    model = VLSA(cfg, pretrained_text_features=params["T"], logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, pretrained_text_features=params["T"], logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     gp = cases.make_linear_params(seed + 4000, cases.D, cases.D)
     with torch.no_grad():
@@ -183,7 +183,7 @@ def test_negative_prompt_adapter_feeds_gated_query_vlfan():
     params = cases.make_params(P, 8, seed + 1000)
     cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, num_query=P, query="Text", gated_query=True,
                query_pooling="mean", pred_head="default")
-    model = VLSA(cfg, pretrained_text_features=params["T"], query_network=pa, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, pretrained_text_features=params["T"], query_network=pa, logit_scale_init=cases.LOGIT_SCALE)
     with torch.no_grad():
         model.mil_encoder.visual_adapter.weight.copy_(params["W"]); model.mil_encoder.visual_adapter.bias.copy_(params["b"])
     model = model.cuda().eval()
@@ -223,7 +223,7 @@ def test_deepmil_bf16_bag_fused_scores_vs_reference_fixture(case):
     params = cases.make_params(1, K, seed + 1000)
     cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25,
                pooling=pooling, pred_head="Adapter", dim_reduction=4, keep_ratio=0.8)
-    model = VLSA(cfg, pretrained_text_features=params["T"], logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, pretrained_text_features=params["T"], logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     ad = cases.make_adapter_params(seed + 4000)
     with torch.no_grad():

@@ -113,7 +113,7 @@ def test_vlsa_end_to_end_with_gpu_text_side():
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
     cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, num_query=P, query="Text", gated_query=False,
                query_pooling="mean", pred_head="default")
-    model = VLSA(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
     with torch.no_grad():
         qnet.residual_features.copy_(params["resid"])
         model.mil_encoder.visual_adapter.weight.copy_(params["W"]); model.mil_encoder.visual_adapter.bias.copy_(params["b"])

@@ -66,7 +66,7 @@ def _gpu_run(bags, t, e, params):
     tp = TextParam(params["T"])
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean")
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
-    model = VLSA(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     with torch.no_grad():
         enc.Q.residual_features.copy_(params["resid"])

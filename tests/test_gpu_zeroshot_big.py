@@ -46,7 +46,7 @@ def test_zeroshot_full_size_matches_oracle_and_can_skip_features():
     params = cases.make_params(8, K, 6200)
     X = cases.make_bag(N, 6201, "clustered")
     for pooling in ("logit_mean", "logit_max", "logit_top10"):
-        net = VLSA(dict(name="FeatMIL", dim_in=512, pooling=pooling), pretrained_text_features=params["T"].clone(),
+        net = VLSA.from_modules(dict(name="FeatMIL", dim_in=512, pooling=pooling), pretrained_text_features=params["T"].clone(),
                    logit_scale_init=cases.LOGIT_SCALE).to(dev).eval()
         with torch.no_grad():
             logits, feats, That = net(X[None].to(dev))

@@ -103,7 +103,7 @@ def test_arena_feeds_forward_bags():
     for i, x in enumerate(hosts):
         arena.add(i, x)
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=P, query_pooling="mean")
-    m = VLSA(cfg, pretrained_text_features=params["T"].clone()).to(dev).eval()
+    m = VLSA.from_modules(cfg, pretrained_text_features=params["T"].clone()).to(dev).eval()
     with torch.no_grad():
         m.mil_encoder.Q.copy_((0.5 * params["resid"] + params["prompt"]).to(dev))
         m.mil_encoder.visual_adapter.weight.copy_(params["W"].to(dev))

@@ -18,7 +18,7 @@ def _model():
     from vlsa_amd.prompt_adapter import PromptAdapter
     from vlsa_amd.vlsa import VLSA
     qnet = PromptAdapter(method="TaskRes", num_prompts=12, pretrained_prompt_features=torch.randn(12, 512))
-    return VLSA(SHIPPED_CFG, pretrained_text_features=torch.randn(12, 512), query_network=qnet)
+    return VLSA.from_modules(SHIPPED_CFG, pretrained_text_features=torch.randn(12, 512), query_network=qnet)
 
 
 def test_state_dict_keys_match_shipped_checkpoint():
@@ -74,7 +74,7 @@ def test_text_feature_cache_tracks_parameter_versions():
         calls.append(1)
         return pl.w * 2
 
-    m = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=provider, prompt_learner=pl)
+    m = VLSA.from_modules(dict(name="FeatMIL", pooling="mean"), text_provider=provider, prompt_learner=pl)
     with torch.no_grad():
         a = m.forward_text_only(); b = m.forward_text_only()
         assert len(calls) == 1 and a is b
@@ -93,7 +93,7 @@ def test_text_cache_with_module_provider_and_repeated_backward():
     from vlsa_amd.vlsa import VLSA
     torch.manual_seed(0)
     pa = PromptAdapter(method="Adapter", num_prompts=4, pretrained_prompt_features=torch.randn(4, 512))
-    m = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=pa)
+    m = VLSA.from_modules(dict(name="FeatMIL", pooling="mean"), text_provider=pa)
     assert any(k.startswith("prompt_adapter.adapter.fc.") for k in m.state_dict())
     assert not any(k.startswith("text_provider") for k in m.state_dict())
     a = m.forward_text_only()
@@ -107,14 +107,14 @@ def test_text_cache_with_module_provider_and_repeated_backward():
         next(pa.adapter.parameters()).mul_(0.5)   # optimizer step
         assert not torch.equal(m.forward_text_only(), c0)
     fc = PromptAdapter(method="FC", num_prompts=4, pretrained_prompt_features=torch.randn(4, 512))
-    m2 = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=fc)
+    m2 = VLSA.from_modules(dict(name="FeatMIL", pooling="mean"), text_provider=fc)
     with torch.no_grad():
         m2.train(); t1 = m2.forward_text_only().clone()
         m2.eval(); t2 = m2.forward_text_only().clone()
         assert not torch.equal(t1, t2)           # dropout on / off: the mode is part of the cache key
     # an opaque callable with no declared modules is never cached
     calls = []
-    m3 = VLSA(dict(name="FeatMIL", pooling="mean"), text_provider=lambda: (calls.append(1), torch.ones(4, 512))[1])
+    m3 = VLSA.from_modules(dict(name="FeatMIL", pooling="mean"), text_provider=lambda: (calls.append(1), torch.ones(4, 512))[1])
     with torch.no_grad():
         m3.forward_text_only(); m3.forward_text_only()
     assert len(calls) == 2

@@ -96,7 +96,7 @@ def test_gpu_training_step_matches_reference(batched, fused_loss):
     cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, drop_rate=0.25, num_query=P, query="Text",
                gated_query=False, query_pooling="mean", pred_head="default")
     qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
-    model = VLSA(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
     enc = model.mil_encoder
     with torch.no_grad():
         enc.Q.residual_features.copy_(params["resid"])

@@ -5,7 +5,7 @@ from vlsa_amd.vlsa import VLSA
 from vlsa_amd.inference import calc_text_img_similarity
 dev = "cuda"
 cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=8, query_pooling="mean")
-net = VLSA(cfg, pretrained_text_features=torch.randn(8, 512)).to(dev).eval()
+net = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(8, 512)).to(dev).eval()
 for rep in range(2):
     for dt in (torch.bfloat16, torch.float32):
         X = torch.randn(1, 50000, 512, device=dev).to(dt)

@@ -8,7 +8,7 @@ dev = "cuda"
 import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of the collector's way: a gen-2 pass otherwise stalls one call by ~40 ms (profiles/README.md)
 P, K = 12, 4
 cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=P, query_pooling="mean")
-net = VLSA(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
+net = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
 for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfloat16), (2798, torch.float32), (10000, torch.float32), (50000, torch.float32)):
     torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
     base = torch.randn(32 * n, 512, device=dev).to(dt)

@@ -22,19 +22,19 @@ for dt in (torch.bfloat16, torch.float32):
     for qp in ("mean", "max", "weight", "attention", "gated_attention"):
         for gq in (False, True):
             cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=False, query="Parameter", num_query=P, gated_query=gq, query_pooling=qp)
-            net = VLSA(cfg, pretrained_text_features=T).to(dev).eval()
+            net = VLSA.from_modules(cfg, pretrained_text_features=T).to(dev).eval()
             rows.append((f"VLFAN pool={qp} gated_query={gq}", timeit(lambda: net(X))))
             if qp in ("mean", "attention") and not gq:
                 rows.append((f"  + mil_encoder(X, ret_with_attn=True)", timeit(lambda: net.mil_encoder(X, ret_with_attn=True))))
     for pool in ("mean", "max"):
-        net = VLSA(dict(name="FeatMIL", dim_in=512, pooling=pool), pretrained_text_features=T).to(dev).eval()
+        net = VLSA.from_modules(dict(name="FeatMIL", dim_in=512, pooling=pool), pretrained_text_features=T).to(dev).eval()
         rows.append((f"FeatMIL pool={pool}", timeit(lambda: net(X))))
     for pool in ("mean", "max", "attention", "gated_attention"):
-        net = VLSA(dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, pooling=pool, pred_head="Adapter"),
+        net = VLSA.from_modules(dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, pooling=pool, pred_head="Adapter"),
                    pretrained_text_features=T).to(dev).eval()
         rows.append((f"DeepMIL pool={pool} Adapter", timeit(lambda: net(X))))
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=8, query_pooling="mean")
-    net = VLSA(cfg, pretrained_text_features=torch.randn(8, 512)).to(dev).eval()
+    net = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(8, 512)).to(dev).eval()
     rows.append(("calc_text_img_similarity (P=8, K=8)", timeit(lambda: calc_text_img_similarity(net, X), reps=10)))
     print(f"---- {str(dt)[6:]} N={n}")
     for name, us in rows:

@@ -29,7 +29,7 @@ pl = RankPromptLearner(dict(max_num_tokens=127, embedding_dim=768, embedding_dty
                        init_context=ctx_key, init_rank_names=names)
 qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=torch.randn(P, 512), res_ratio=0.5)
 cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean", pred_head="default")
-net = VLSA(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet).to(dev).train()
+net = VLSA.from_modules(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet).to(dev).train()
 params = [p_ for p_ in net.parameters() if p_.requires_grad]
 opt = torch.optim.Adam(params, lr=2e-4)
 objective = SurvObjective()

@@ -8,7 +8,7 @@ import gc; gc.collect(); gc.freeze()   # torch's ~10^6 imported objects out of t
 K = 4
 for pooling in ("logit_mean", "logit_max", "logit_top10"):
     cfg = dict(name="FeatMIL", dim_in=512, pooling=pooling)
-    net = VLSA(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
+    net = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
     for n, dt in ((50000, torch.bfloat16), (50000, torch.float32), (2798, torch.float32)):
         torch.cuda.empty_cache()   # every configuration allocates from fresh allocator segments
         bags = [torch.randn(1, n, 512, device=dev).to(dt) for _ in range(8)]

@@ -13,7 +13,7 @@ elif which == "deepmil":
     cfg = dict(name="DeepMIL", dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, pooling="gated_attention", pred_head="Adapter")
 else:
     cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, query="Parameter", num_query=12, query_pooling="mean")
-net = VLSA(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
+net = VLSA.from_modules(cfg, pretrained_text_features=torch.randn(K, 512)).to(dev).eval()
 base = torch.randn(32 * n, 512, device=dev).to(torch.bfloat16)
 bags = [base[i * n:(i + 1) * n] for i in range(32)]
 with torch.no_grad():

@@ -1,0 +1,86 @@
+"""Model factory with the reference's names and signatures (model/utils.py:13-45, model/prompt_encoder.py:22-33,
+model/prompt_learners/__init__.py:6-24): what ``VLSAHandler.func_load_model`` reaches through
+``load_model(cfg['arch'], **arch_cfg)`` (runner/vlsa_handler.py:112-120).
+
+    load_model('VLSA', text_encoder_cfg=..., image_encoder_cfg=..., prompt_learner_cfg=..., pretrained_prompt_learner_cfg=...,
+               vlsa_api=..., path_clip_model=...)  ->  vlsa_amd.vlsa.VLSA
+
+``patch_reference()`` is the one-line swap for a process running the reference's code: it points the reference's factory
+(and its MIL-encoder name lookup) at the classes of this package, after which ``runner/vlsa_handler.py`` runs unmodified --
+construction, freezing (126-149), ``.cuda()``, the per-bag training / evaluation loops (260-345) and checkpoint loading.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+__all__ = ["load_model", "Deep_VLSA", "get_prompt_encoder", "load_prompt_learner", "load_prompt_adapter", "patch_reference"]
+
+
+def load_model(arch: str, dims: Optional[List] = None, **kws):
+    """model/utils.py:13-38.  Only the 'VLSA' arch is this package's business; the plain MIL baselines
+    (``arch='DeepMIL'``: ABMIL / TransMIL / DSMIL ... classifiers of sa_handler) are out of scope."""
+    if arch == "VLSA":
+        return Deep_VLSA(**kws)
+    if arch == "DeepMIL":
+        raise NotImplementedError("arch='DeepMIL' (the non-VL survival baselines of model/utils.py:14-33) is outside the "
+                                  "language-guided aggregation path this package implements; use the reference's own factory")
+    raise NotImplementedError("Backbone {} cannot be recognized".format(arch))
+
+
+def Deep_VLSA(**kws):
+    """model/utils.py:40-45"""
+    for need in ("text_encoder_cfg", "image_encoder_cfg", "prompt_learner_cfg"):
+        assert need in kws
+    from .vlsa import VLSA
+    return VLSA(**kws)
+
+
+def get_prompt_encoder(vl_model, api):
+    """model/prompt_encoder.py:22-33.  CONCH: the HIP text tower adopting ``vl_model.text``.  The OpenAI-CLIP / HuggingFace
+    towers are alternative backbones no shipped config uses (cfg_vlsa_conch.yaml:39) and are not built."""
+    if api == "CONCH":
+        from .prompt_encoder import CONCHPromptEncoder
+        return CONCHPromptEncoder(vl_model)
+    if api in ("CLIP", "HF"):
+        raise NotImplementedError(f"vlsa_api={api!r}: only the CONCH text tower has a HIP implementation")
+    raise ValueError(f"Got an invalid api ({api}).")
+
+
+def load_prompt_learner(learner_name: str, cfg: dict):
+    """model/prompt_learners/__init__.py:6-18: 'plain' | 'rank'; anything else yields None there too."""
+    from .prompt_learner import PlainPromptLearner, RankPromptLearner
+    if learner_name == "plain":
+        return PlainPromptLearner(**cfg)
+    if learner_name == "rank":
+        return RankPromptLearner(**cfg)
+    return None
+
+
+def load_prompt_adapter(prompt_encoder, cfg: dict):
+    """model/prompt_learners/__init__.py:20-24"""
+    from .prompt_adapter import PromptAdapter
+    return PromptAdapter(prompt_encoder, **cfg)
+
+
+def patch_reference():
+    """Point the reference's factory at this package (call once, before the handler is built):
+
+        import vlsa_amd.model_utils; vlsa_amd.model_utils.patch_reference()
+
+    * ``model.utils.VLSA`` -> ``vlsa_amd.vlsa.VLSA``: ``load_model('VLSA', **arch_cfg)`` (model/utils.py:36,44) then builds the HIP
+      model from the handler's unmodified ``arch_cfg``;
+    * ``model.deepmil.{VLFAN, FeatMIL, DeepMIL, logit_pooling}`` -> this package's: the name lookup of
+      model/utils_vl.py:129-138 and ``utils/model_inference.py`` see the same classes.
+    Returns the patched reference modules (for un-patching in tests)."""
+    import model.deepmil as ref_mil
+    import model.utils as ref_utils
+    import model.vlsa as ref_vlsa
+    from . import deepmil as fast
+    from .vlsa import VLSA
+    saved = dict(VLSA_utils=ref_utils.VLSA, VLSA_vlsa=ref_vlsa.VLSA, VLFAN=ref_mil.VLFAN, FeatMIL=ref_mil.FeatMIL,
+                 DeepMIL=ref_mil.DeepMIL, logit_pooling=ref_mil.logit_pooling)
+    ref_utils.VLSA = VLSA
+    ref_vlsa.VLSA = VLSA
+    ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = fast.VLFAN, fast.FeatMIL, fast.DeepMIL
+    ref_mil.logit_pooling = ref_vlsa.logit_pooling = fast.logit_pooling
+    return saved

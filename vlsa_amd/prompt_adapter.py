@@ -1,13 +1,21 @@
-"""Query network of VLFAN: text-prototype features + a learnable adaptation (reference:
-model/prompt_learners/prompt_adapter.py:11-149).  The frozen prototype features come from the VL text tower,
-which is outside this package's scope: pass them in as ``pretrained_prompt_features`` (what
-the reference itself supports, prompt_adapter.py:65-68) or give a ``prompt_encoder`` + ``tokenizer`` + texts.
-State-dict keys match the reference (``residual_features``, ``neg_residual_features``, ``adapter.fc.*``, ``fc.0.weight``);
+"""Query network of VLFAN / text-side 'Adapter' prompt learner: frozen text-prototype features + a learnable adaptation
+(reference: model/prompt_learners/prompt_adapter.py:11-149).  Same constructor keywords as the reference
+(``prompt_encoder, tokenizer, method, load_path, load_idx, load_negative_prompts, load_negative_idx, num_prompts,
+init_prompt_path, init_prompt_context_idx, init_prompt_rank_idx, pretrained_prompt_features, dim_reduction, keep_ratio,
+res_ratio``), same state-dict keys (``residual_features``, ``neg_residual_features``, ``adapter.fc.*``, ``fc.0.weight``);
 ``prompt_features`` / ``neg_prompt_features`` are non-persistent buffers there too.
+
+The frozen prototype features are text-tower outputs of fixed sentences (prompt_adapter.py:60-63,74-79).  The tower here is
+the HIP one (``vlsa_amd.prompt_encoder.CONCHPromptEncoder``), which runs on the MI355X only, while the reference's handler
+builds the model on the CPU and moves it afterwards (``func_load_model(cfg).cuda()``, runner/base_handler.py:114).  So when
+the encoder is not on the device yet, the sentences are tokenised at construction and the tower pass is DEFERRED to the first
+use (``forward`` / ``get_raw_prompt_features``), by which time ``.cuda()`` has happened; the result is the same tensor the
+reference computes in its constructor.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+import json
+from typing import Optional, Sequence, Union
 
 import torch
 import torch.nn as nn
@@ -15,38 +23,76 @@ import torch.nn as nn
 from .layers import Adapter
 
 
+def _read_json(path):
+    with open(path, "r") as f:
+        return json.load(f)
+
+
+def _rank_sentences(path, context_idx, rank_idx):
+    """context template with CLASSNAME replaced by each class' rank name (utils/io.py:151-173 with replace=True)."""
+    spec = _read_json(path)
+    template = spec["context_templates"][context_idx]
+    return [template.replace("CLASSNAME", names[rank_idx]) for names in spec["class_names"].values()]
+
+
+def _runs_on_host(prompt_encoder) -> bool:
+    """True for this package's HIP tower while its weights are still on the CPU (the pass must wait for ``.cuda()``)."""
+    tensors = getattr(prompt_encoder, "_tower_tensors", None)
+    return tensors is not None and not tensors()[0].is_cuda
+
+
 class PromptAdapter(nn.Module):
-    def __init__(self, prompt_encoder=None, tokenizer=None, method: str = "default", init_texts: Optional[Sequence[str]] = None,
-                 neg_texts: Optional[Sequence[str]] = None, num_prompts: int = 4, pretrained_prompt_features=None,
-                 pretrained_neg_prompt_features=None, load_negative_prompts: bool = False, dim_reduction: int = 4,
-                 keep_ratio: float = 0.8, res_ratio: float = 0.5, **kwargs):
+    def __init__(self, prompt_encoder=None, tokenizer=None, method: str = "default", load_path: Optional[str] = None,
+                 load_idx: Union[int, str] = 0, load_negative_prompts: bool = False, load_negative_idx: str = "prompt_normal_tissue",
+                 num_prompts: int = 4, init_prompt_path: Optional[str] = None, init_prompt_context_idx: int = 0,
+                 init_prompt_rank_idx: int = 0, pretrained_prompt_features=None, dim_reduction: int = 4, keep_ratio: float = 0.8,
+                 res_ratio: float = 0.5, init_texts: Optional[Sequence[str]] = None, neg_texts: Optional[Sequence[str]] = None,
+                 pretrained_neg_prompt_features=None, **kwargs):
+        """Beyond the reference's keywords: ``init_texts`` / ``neg_texts`` (the sentences themselves instead of a JSON path)
+        and ``pretrained_neg_prompt_features`` (a ready [1, D] negative prototype)."""
         super().__init__()
         assert method in ["default", "FC", "Adapter", "TaskRes"]
         self.method = method
+        self.__dict__["_pending"] = {}          # buffer name -> zero-argument callable producing it (deferred tower pass)
+        dim = None
         if pretrained_prompt_features is None:
-            if prompt_encoder is None or tokenizer is None or init_texts is None:
-                raise RuntimeError("give `pretrained_prompt_features`, or `prompt_encoder` + `tokenizer` + `init_texts`")
+            if init_texts is None:
+                if init_prompt_path is not None:
+                    init_texts = _rank_sentences(init_prompt_path, init_prompt_context_idx, init_prompt_rank_idx)
+                elif load_path is not None:
+                    init_texts = _read_json(load_path)[str(load_idx)]
+                else:
+                    raise RuntimeError("Please specify `init_prompt_path` or `load_path` to load initial prompts or texts.")
+            if prompt_encoder is None or tokenizer is None:
+                raise RuntimeError("give `pretrained_prompt_features`, or `prompt_encoder` + `tokenizer` + texts")
             assert len(init_texts) == num_prompts, f"Expected {num_prompts} initial texts, but got {len(init_texts)}."
-            with torch.no_grad():
-                prompt_features = prompt_encoder(prompts_text=tokenizer(list(init_texts), return_raw_tokens=False,
-                                                                        return_num_tokens=False))
+            prompt_features = self._encode_or_defer("prompt_features", prompt_encoder, tokenizer, list(init_texts), False)
+        elif callable(pretrained_prompt_features) and not isinstance(pretrained_prompt_features, torch.Tensor):
+            # features that need the device-side tower (a CoOp-pretrained learner's text features, model/vlsa.py:129-137):
+            # evaluated at first use, see the module docstring
+            self._pending["prompt_features"] = pretrained_prompt_features
+            prompt_features = None
         else:
             assert len(pretrained_prompt_features) == num_prompts, \
                 f"Expected {num_prompts} initial texts, but got {len(pretrained_prompt_features)}."
-            prompt_features = pretrained_prompt_features
-        self.register_buffer("prompt_features", prompt_features.detach().clone(), persistent=False)
+            prompt_features = pretrained_prompt_features.detach().clone()
+        self.register_buffer("prompt_features", prompt_features, persistent=False)
         if load_negative_prompts:
             if pretrained_neg_prompt_features is not None:
                 neg = pretrained_neg_prompt_features.detach().clone().reshape(1, -1)
             else:
-                assert neg_texts is not None and prompt_encoder is not None, "negative prompts need texts + encoder"
-                with torch.no_grad():
-                    neg = prompt_encoder(prompts_text=tokenizer(list(neg_texts), return_raw_tokens=False,
-                                                                return_num_tokens=False)).mean(0, keepdims=True)
+                if neg_texts is None:
+                    assert load_path is not None, "Found null `load_path`."
+                    neg_texts = _read_json(load_path)[str(load_negative_idx)]
+                assert prompt_encoder is not None and tokenizer is not None, "negative prompts need texts + encoder + tokenizer"
+                neg = self._encode_or_defer("neg_prompt_features", prompt_encoder, tokenizer, list(neg_texts), True)
             self.register_buffer("neg_prompt_features", neg, persistent=False)
-        dim = prompt_features.shape[-1]
+        if prompt_features is not None:
+            dim, dtype = prompt_features.shape[-1], prompt_features.dtype
+        else:
+            dim, dtype = int(prompt_encoder.output_dim), torch.float32
         if method == "Adapter":
-            self.adapter = Adapter(dim, dim_reduction).to(prompt_features.dtype)
+            self.adapter = Adapter(dim, dim_reduction).to(dtype)
             assert 0 <= keep_ratio <= 1.0
             self.keep_ratio = keep_ratio
         elif method == "TaskRes":
@@ -56,15 +102,55 @@ class PromptAdapter(nn.Module):
         elif method == "FC":
             self.fc = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.Dropout(0.25))
 
+    # -- frozen prototype features: now, or once the tower is on the device ----------------------------------------------
+    @staticmethod
+    def _tower_pass(prompt_encoder, token_ids, mean_row):
+        tensors = getattr(prompt_encoder, "_tower_tensors", None)
+        if tensors is not None:
+            dev = tensors()[0].device
+            if dev.type != "cuda":
+                from ._native import VlsaNativeError
+                raise VlsaNativeError("PromptAdapter: the text tower is still on the CPU -- move the model to the MI355X first "
+                                      "(`func_load_model(cfg).cuda()`); there is no CPU fallback for the tower")
+            token_ids = token_ids.to(dev)
+        with torch.no_grad():
+            feats = prompt_encoder(prompts_text=token_ids)
+            if mean_row:
+                feats = feats.mean(0, keepdims=True)
+        return feats.detach().clone()
+
+    def _encode_or_defer(self, name, prompt_encoder, tokenizer, texts, mean_row):
+        token_ids = tokenizer(texts, return_raw_tokens=False, return_num_tokens=False)      # [n, ctx_length]
+        if _runs_on_host(prompt_encoder):
+            self._pending[name] = lambda: self._tower_pass(prompt_encoder, token_ids, mean_row)
+            return None
+        return self._tower_pass(prompt_encoder, token_ids, mean_row)
+
+    def _materialise(self):
+        """Run the deferred tower passes (the encoder has been moved to the device by now)."""
+        for name in list(self._pending):
+            feats = self._pending[name]().detach().clone()
+            like = next((p for p in self.parameters()), None)
+            self._buffers[name] = feats if like is None else feats.to(like.device)
+            del self._pending[name]
+
+    def _feature(self, name):
+        if self._pending:
+            self._materialise()
+        return getattr(self, name)
+
+    def _has_neg(self):
+        return "neg_prompt_features" in self._buffers
+
     def get_raw_prompt_features(self):
-        raw = self.prompt_features.clone()
-        if hasattr(self, "neg_prompt_features"):
-            raw = torch.cat([raw, self.neg_prompt_features.clone()], dim=0)
+        raw = self._feature("prompt_features").clone()
+        if self._has_neg():
+            raw = torch.cat([raw, self._feature("neg_prompt_features").clone()], dim=0)
         return raw
 
     def forward(self):
-        pf = self.prompt_features.clone()
-        has_neg = hasattr(self, "neg_prompt_features")
+        pf = self._feature("prompt_features").clone()
+        has_neg = self._has_neg()
         if self.method == "Adapter":
             return (1 - self.keep_ratio) * self.adapter(pf) + self.keep_ratio * pf
         if self.method == "TaskRes":

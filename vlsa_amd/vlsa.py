@@ -36,16 +36,68 @@ def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
 
 
 class VLSA(nn.Module):
-    def __init__(self, image_encoder_cfg: dict, text_provider: Optional[Callable[[], torch.Tensor]] = None,
-                 pretrained_text_features: Optional[torch.Tensor] = None, query_network: Optional[nn.Module] = None,
-                 logit_scale_init: float = math.log(1 / 0.07), prompt_learner: Optional[nn.Module] = None,
-                 prompt_encoder: Optional[nn.Module] = None, cache_text_features: bool = True, **kwargs):
+    """``VLSA(text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None, vlsa_api=...,
+    path_clip_model=...)`` -- the reference's constructor (model/vlsa.py:22-105), i.e. what ``load_model('VLSA', **arch_cfg)``
+    calls from ``VLSAHandler.func_load_model`` (runner/vlsa_handler.py:112-120).  ``VLSA.from_modules(image_encoder_cfg, ...)``
+    assembles the same model from ready-made parts (text features / provider / prompt learner + encoder objects)."""
+
+    def __init__(self, text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None,
+                 info_prefix="VLSA-UNI", **kwargs):
+        super().__init__()
+        from . import hooks
+        from .model_utils import get_prompt_encoder
+        assert "vlsa_api" in kwargs, "Please specify `vlsa_api` in arguments."
+        assert "path_clip_model" in kwargs, "Please specify `path_clip_model` in arguments."
+        api, root = kwargs["vlsa_api"], kwargs["path_clip_model"]
+        # host side (tokenizer, pretrained VL weights) through the hooks; model/vlsa.py:38-49
+        self.text_tokenizer = hooks.make_tokenizer(root, text_encoder_cfg["name"], api)
+        vl_model = hooks.load_vl_model(text_encoder_cfg, root, api)
+        # language end (model/vlsa.py:51-70)
+        self.pmt_learner_name = prompt_learner_cfg["name"]
+        prompt_encoder = get_prompt_encoder(vl_model, api=api)
+        self.prompt_encoder = prompt_encoder          # registered first: the builders below read it
+        prompt_learner = text_module = None
+        if self.pmt_learner_name == "CoOp":
+            prompt_learner, frozen_features = self._build_prompt_learner(prompt_learner_cfg, pretrained_prompt_learner_cfg)
+        elif self.pmt_learner_name == "Adapter":
+            text_module, frozen_features = self._build_prompt_adapter(prompt_learner_cfg, pretrained_prompt_learner_cfg), False
+        else:
+            raise ValueError(f"{self.pmt_learner_name} is not a valid name of prompt learner.")
+        # vision end + the query network of VLFAN (model/vlsa.py:72-99)
+        query_network = None
+        if image_encoder_cfg["name"] == "VLFAN" and image_encoder_cfg["query"] == "Text":
+            qcfg = {k[len("query_text_"):]: v for k, v in image_encoder_cfg.items() if k.startswith("query_text_")}
+            qcfg.update(tokenizer=self.text_tokenizer, num_prompts=image_encoder_cfg["num_query"],
+                        load_negative_prompts=image_encoder_cfg.get("gated_query", False))
+            from .model_utils import load_prompt_adapter
+            query_network = load_prompt_adapter(prompt_encoder, qcfg)
+        self.text_encoder_cfg, self.prompt_learner_cfg = text_encoder_cfg, prompt_learner_cfg
+        self._assemble(image_encoder_cfg, text_provider=text_module, query_network=query_network, prompt_learner=prompt_learner,
+                       prompt_encoder=prompt_encoder, logit_scale=vl_model.logit_scale, kwargs=kwargs,
+                       frozen_coop_features=bool(frozen_features))
+        self.image_encoder_cfg = image_encoder_cfg      # the caller's dict object, as in the reference (model/vlsa.py:102)
+
+    @classmethod
+    def from_modules(cls, image_encoder_cfg: dict, text_provider: Optional[Callable[[], torch.Tensor]] = None,
+                     pretrained_text_features: Optional[torch.Tensor] = None, query_network: Optional[nn.Module] = None,
+                     logit_scale_init: float = math.log(1 / 0.07), prompt_learner: Optional[nn.Module] = None,
+                     prompt_encoder: Optional[nn.Module] = None, cache_text_features: bool = True, **kwargs):
         """image_encoder_cfg: the ``vlsa_img_encoder_*`` keys of cfg_vlsa_conch.yaml with the prefix stripped
         (runner/vlsa_handler.py:110-111).  Text side: ``pretrained_text_features`` [K, D] (the reference's cached
         branch, model/vlsa.py:160-161) or ``text_provider`` -- any callable returning [K, D], e.g. the reference's
-        ``lambda: prompt_encoder(prompts_embedding=prompt_learner(), prompts_pseudo_tokens=...)``."""
-        super().__init__()
-        self.kwargs = kwargs
+        ``lambda: prompt_encoder(prompts_embedding=prompt_learner(), prompts_pseudo_tokens=...)`` -- or a
+        ``prompt_learner`` + ``prompt_encoder`` pair (the CoOp route on the device)."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self._assemble(image_encoder_cfg, text_provider=text_provider, pretrained_text_features=pretrained_text_features,
+                       query_network=query_network, prompt_learner=prompt_learner, prompt_encoder=prompt_encoder,
+                       logit_scale=logit_scale_init, cache_text_features=cache_text_features, kwargs=kwargs)
+        return self
+
+    def _assemble(self, image_encoder_cfg, text_provider=None, pretrained_text_features=None, query_network=None,
+                  prompt_learner=None, prompt_encoder=None, logit_scale=math.log(1 / 0.07), cache_text_features=True, kwargs=None,
+                  frozen_coop_features=False):
+        self.kwargs = kwargs or {}
         self.image_encoder_cfg = dict(image_encoder_cfg)
         self.mil_encoder = build_mil_encoder(self.image_encoder_cfg)
         if isinstance(self.mil_encoder, VLFAN) and self.mil_encoder.query_type == "Text":
@@ -54,6 +106,12 @@ class VLSA(nn.Module):
             self.mil_encoder.reset_query(query_network)
         if pretrained_text_features is not None:
             self.register_buffer("pretrained_text_features", pretrained_text_features.detach().clone(), persistent=False)
+        elif frozen_coop_features:
+            # pretrained + fully frozen CoOp prompts: the reference pre-computes the text features in its constructor and
+            # never runs the tower again (model/vlsa.py:57-60,117-122).  The HIP tower needs the device, and the handler moves
+            # the model there only after construction: the buffer exists from the start (``hasattr`` is the reference's
+            # switch, model/vlsa.py:160) and is filled by the first ``forward_text_only``.
+            self.register_buffer("pretrained_text_features", None, persistent=False)
         if prompt_learner is not None:
             self.prompt_learner = prompt_learner
         if prompt_encoder is not None:
@@ -73,10 +131,50 @@ class VLSA(nn.Module):
         self.cache_text_features = cache_text_features
         self._text_cache = None
         self._text_cache_key = None
-        self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init)  # CoCa init, model/conch/coca_model.py:187
+        if isinstance(logit_scale, nn.Parameter):
+            self.logit_scale = logit_scale             # the VL model's own parameter (model/vlsa.py:105)
+        else:
+            self.logit_scale = nn.Parameter(torch.ones([]) * float(logit_scale))  # CoCa init, model/conch/coca_model.py:187
         self._plans = {}
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ was computed from
+
+    # -- builders of the text side (model/vlsa.py:107-147) -----------------------------------------------------------------
+    def _build_prompt_learner(self, prompt_learner_cfg, pretrained_prompt_learner_cfg):
+        """-> (prompt learner, whether its text features are fixed for good).  CoOp learner over this model's tokenizer and the
+        tower's token embedding; with ``pretrained`` its embeddings come from a checkpoint, and when both are frozen as well
+        the text features never change again."""
+        from .model_utils import load_prompt_learner
+        cfg = dict(prompt_learner_cfg)
+        cfg.update(tokenizer=self.text_tokenizer, text_config=self.prompt_encoder.text_config,
+                   token_embedding=self.prompt_encoder.token_embedding)
+        learner = load_prompt_learner(cfg["method"], cfg)
+        fixed = False
+        if cfg["pretrained"]:
+            assert pretrained_prompt_learner_cfg is not None, "Please specify `config` for `pretrained_prompt_learner`."
+            learner.load_pretrained_parameters(pretrained_prompt_learner_cfg["ckpt"])
+            fixed = bool(cfg["frozen_context_embeds"] and cfg["frozen_rank_embeds"])
+        return learner, fixed
+
+    def _build_prompt_adapter(self, prompt_learner_cfg, pretrained_prompt_learner_cfg):
+        """Text-side 'Adapter' learner (model/vlsa.py:124-147): a PromptAdapter over the rank sentences, or -- ``pretrained`` --
+        over the text features of a CoOp-pretrained, frozen prompt learner."""
+        from .model_utils import load_prompt_adapter
+        cfg = dict(prompt_learner_cfg)
+        features = None
+        if cfg["pretrained"]:
+            coop_cfg = dict(pretrained_prompt_learner_cfg)
+            coop_cfg["pretrained"] = True
+            learner, fixed = self._build_prompt_learner(coop_cfg, {"ckpt": coop_cfg["ckpt"]})
+            assert fixed, "Found empty `pretrained_text_features`."
+            encoder = self.prompt_encoder
+
+            def features():      # evaluated by the adapter at first use (the tower has to be on the device)
+                dev = encoder.token_embedding.weight.device
+                with torch.no_grad():
+                    return encoder(prompts_embedding=learner.to(dev)(), prompts_pseudo_tokens=learner.pseudo_sentence_tokens)
+        cfg.update(tokenizer=self.text_tokenizer, num_prompts=cfg["num_ranks"], pretrained_prompt_features=features)
+        return load_prompt_adapter(self.prompt_encoder, cfg)
 
     # -- text side -----------------------------------------------------------------------------------------
     def _provider_modules(self):
@@ -121,9 +219,22 @@ class VLSA(nn.Module):
     def _drop_text_cache(self, *_):
         self._text_cache = self._text_cache_key = None
 
+    def _fixed_text_features(self):
+        """The ``pretrained_text_features`` buffer, or None when this model has none.  A buffer registered empty (pretrained,
+        fully frozen CoOp prompts built before the model was on the device) is filled by its one tower pass here."""
+        if "pretrained_text_features" not in self._buffers:
+            return None
+        t = self._buffers["pretrained_text_features"]
+        if t is None:
+            with torch.no_grad():
+                t = self.compute_text_features_with_coop(self.prompt_learner).detach().clone()
+            self._buffers["pretrained_text_features"] = t
+        return t
+
     def forward_text_only(self):
-        if hasattr(self, "pretrained_text_features"):
-            return self.pretrained_text_features.clone()
+        fixed = self._fixed_text_features()
+        if fixed is not None:
+            return fixed.clone()
         provider = self.prompt_adapter if self._provider_is_module else self.text_provider
         if provider is None:
             raise RuntimeError("no text features: give `pretrained_text_features` or `text_provider`")
@@ -142,9 +253,8 @@ class VLSA(nn.Module):
 
     def _text_features(self):
         """forward_text_only without the defensive clone of the cached-features branch (nothing here writes to it)."""
-        if hasattr(self, "pretrained_text_features"):
-            return self.pretrained_text_features
-        return self.forward_text_only()
+        fixed = self._fixed_text_features()
+        return fixed if fixed is not None else self.forward_text_only()
 
     def encode_instances(self, X):
         return self.mil_encoder(X)
