@@ -3,7 +3,7 @@ exactly the way ``runner/vlsa_handler.py`` drives it on a box that has no refere
 
     build_model(cfg)            runner/vlsa_handler.py:88-151   cfg -> arch_cfg -> load_model('VLSA', **arch_cfg), freezing
     make_optimizer(model, cfg)  runner/base_handler.py:181-186 + optim/optim_factory.py:25-37,78-79 (Adam; weight decay on
-                                parameters with >= 2 dims whose name does not end in '.bias')
+                                every parameter that is not 1-D and whose name does not end in '.bias' -- the 0-dim logit_scale included)
     update_network(...)         runner/vlsa_handler.py:260-289  per-bag forward, cat, objective, backward, step
     test_model(...)             runner/vlsa_handler.py:315-345  eval mode, per-bag forward under no_grad, softmax
 
@@ -68,7 +68,7 @@ def make_optimizer(model, cfg):
     decay, plain = [], []
     for n, p in model.named_parameters():
         if p.requires_grad:
-            (plain if (p.dim() <= 1 or n.endswith(".bias")) else decay).append(p)
+            (plain if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)      # 0-dim logit_scale IS decayed there
     return torch.optim.Adam([{"params": plain, "weight_decay": 0.0}, {"params": decay, "weight_decay": cfg["opt_weight_decay"]}],
                             lr=cfg["opt_lr"])
 
