@@ -504,6 +504,44 @@ int vlsa_tt_backward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
 
+/*
+ * ---- backward of the N-sized layers around the aggregation --------------------------------------
+ * PyTorch autograd through the reference's modules keeps the [N, 256] / [N, 512] hidden activations of every bag alive and
+ * runs two library GEMMs + ~10 elementwise kernels per layer; these entry points recompute the activations tile by tile on the
+ * matrix pipe and contract dW = dH^T X in the same kernel (vlsa_amd/csrc/mlp_backward.hip).  All take B <= 64 bags per call:
+ * the layers' weights are shared by the bags of an optimizer step (runner/vlsa_handler.py:260-289), so dW sums over them.
+ *
+ * vlsa_attn_scores_backward: Gated_Attention_Pooling / Attention_Pooling scores a_n = w2 . (tanh(Wa x_n + ba) [* sigmoid(Wg x_n
+ *   + bg)]) + c (model/layers.py:103-122,137-153) given da = dL/da.  bag_desc: device table of vlsa_bag_desc (bf16 or fp32 rows,
+ *   D == 512); tile_start [B + 1] int32 (device): first row tile of every bag in tiles of vlsa_mlp_bwd_tile_rows(x_dtype) rows,
+ *   n_tiles = tile_start[B]; da: all bags' rows, bag b at da + a_off[b] (int64, device); prep: the block of
+ *   vlsa_prepare_gated_weights; ws: vlsa_mlp_bwd_workspace_bytes(gated, n_tiles) bytes.
+ *   Out: dW [gated ? 2 : 1][256][512] (dWa, dWg); dvec [3][512]: row 0 = (dba | dbg), row 1 = dw2 [256], dvec[2][0] = dc.
+ * vlsa_feat_project_train / _rowstats / _backward: Feat_Projecter y_n = LayerNorm(W x_n + b) gamma + beta (model/layers.py:65-82).
+ *   The training forward also stores (row mean, rstd) in stats [N][4] columns 0, 1; _rowstats fills columns 2, 3 from the upstream
+ *   gradient dy [N, 512] and the projected rows y (c1 = mean(dy gamma), c2 = mean(dy (y - beta))); _backward (mode 2 workspace)
+ *   takes tables of the input rows and of dy, stats of all bags (bag b at row row_off[b]) and writes dW [512][512] and
+ *   dvec [3][512] = (db, dgamma, dbeta).
+ * vlsa_vlfan_backward_dx: dL/dX of the cross attention (model/deepmil.py:187-200) for fp32 bags -- what a trainable
+ *   Feat_Projecter in front of VLFAN needs (model/deepmil.py:176-179).  dx_desc: table of the fp32 gradient rows to write;
+ *   tile_start in 64-row super tiles; qprep of vlsa_prepare_queries; dout / out [B][P][512], m2 / l [B][16] of the forward;
+ *   delta_ws: B * 16 floats.
+ */
+int vlsa_mlp_bwd_tile_rows(int x_dtype);
+size_t vlsa_mlp_bwd_workspace_bytes(int mode, int n_tiles);   /* mode: 0 attention, 1 gated attention, 2 Feat_Projecter */
+int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
+                              int n_tiles, const float* da, const int64_t* a_off, void* ws, float* dW, float* dvec, void* stream);
+int vlsa_feat_project_train(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
+                            int64_t ldy, float* stats, void* stream);
+int vlsa_feat_project_rowstats(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t N, const void* prep, float* stats,
+                               void* stream);
+int vlsa_feat_project_backward(const void* bag_desc, const void* dy_desc, int B, int x_dtype, const void* prep, const int* tile_start,
+                               int n_tiles, const float* stats, const int64_t* row_off, void* ws, float* dW, float* dvec,
+                               void* stream);
+int vlsa_vlfan_backward_dx(const void* bag_desc, const void* dx_desc, int B, int D, const void* qprep, int P, float coattn_scale,
+                           const int* tile_start, int n_tiles, const float* dout, const float* out, const float* m2, const float* l,
+                           float* delta_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,8 +102,12 @@ def test_functional_api_refuses_a_bag_that_requires_grad():
     from vlsa_amd import functional as F
     X = torch.randn(64, 512, device="cuda", requires_grad=True)
     Q = torch.randn(4, 512, device="cuda", requires_grad=True)
+    # fp32 [N, 512] bags get dX from vlsa_vlfan_backward_dx (round 3); anything else is still refused, never detached silently
+    Xb = torch.randn(64, 512, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     with pytest.raises(F.VlsaNativeError):
-        F.vlfan_cross_attention(X, Q)
+        F.vlfan_cross_attention(Xb, Q)
+    with pytest.raises(F.VlsaNativeError):
+        F.vlfan_cross_attention(torch.randn(64, 256, device="cuda", requires_grad=True), torch.randn(4, 256, device="cuda"))
     with pytest.raises(F.VlsaNativeError):
         F.scored_pool(X, torch.randn(64, device="cuda"))
     with torch.no_grad():

@@ -126,6 +126,16 @@ _SIGNATURES = {
     "vlsa_tt_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vlsa_tt_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "vlsa_tt_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "vlsa_mlp_bwd_tile_rows": (c_int, [c_int]),
+    "vlsa_mlp_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "vlsa_attn_scores_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+    "vlsa_feat_project_train": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vlsa_feat_project_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vlsa_feat_project_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
+    "vlsa_vlfan_backward_dx": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_debug_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
 }
 

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvlsa_hip.so")
-SOURCES = ["vlfan_partial.hip", "vlfan_partial_dma.hip", "vlfan_batch.hip", "vlfan_batch_f32.hip", "vlfan_backward.hip", "vlfan_backward_batch.hip", "vlfan_backward_batch_f32.hip", "vlfan_tail.hip", "mil_pool.hip", "ingest.hip", "surv_loss.hip", "gated_scores.hip", "feat_proj.hip", "text_tower.hip", "prompt_sentences.hip"]
+SOURCES = ["vlfan_partial.hip", "vlfan_partial_dma.hip", "vlfan_batch.hip", "vlfan_batch_f32.hip", "vlfan_backward.hip", "vlfan_backward_batch.hip", "vlfan_backward_batch_f32.hip", "vlfan_tail.hip", "mil_pool.hip", "ingest.hip", "surv_loss.hip", "gated_scores.hip", "feat_proj.hip", "text_tower.hip", "prompt_sentences.hip", "mlp_backward.hip", "vlfan_dx.hip"]
 HEADERS = ["vlsa_common.h", "vlfan_mfma_common.h", os.path.join("..", "..", "include", "vlsa_hip.h")]
 
 
@@ -22,28 +22,54 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _stale() -> bool:
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return _newer(LIB_PATH, deps)
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into one shared library. Returns its path."""
+    """Compile every HIP source for gfx950 (one object per source, stale ones only, in parallel) and link them into one shared
+    library.  Returns its path."""
     if not force and not _stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if force or _newer(obj, [os.path.join(CSRC, src)] + common):
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((src, cmd))
+    width = max(1, min(len(jobs), os.cpu_count() or 1))
+    for i in range(0, len(jobs), width):
+        procs = [(src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for src, cmd in jobs[i:i + width]]
+        for src, pr in procs:
+            out, _ = pr.communicate()
+            if pr.returncode != 0:
+                sys.stderr.write(out)
+                raise RuntimeError(f"hipcc failed on {src}")
+            if verbose and out.strip():
+                print(out)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES],
+            "-o", LIB_PATH + ".tmp"]
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libvlsa_hip.so")
+        raise RuntimeError("hipcc failed linking libvlsa_hip.so")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

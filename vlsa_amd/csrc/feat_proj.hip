@@ -89,7 +89,7 @@ __device__ __forceinline__ float fp_row16_sum(float v) {
 template <bool XF32, int RT>
 __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, long long N, long long ldx,
                                                     const unsigned char* __restrict__ prep, float eps, float* __restrict__ Y,
-                                                    long long ldy) {
+                                                    long long ldy, float* __restrict__ stats) {
     using namespace fp;
     constexpr int ROWS = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -205,11 +205,13 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
             if (i16 == 0) scr[w * ROWS + 16 * rt + 4 * g + r] = s;
         }
     __syncthreads();
+    float row_mean = 0.f;
     if (tid < ROWS) {
         float s = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) s += scr[ww * ROWS + tid];
-        stat[tid] = s * (1.f / kD);
+        row_mean = s * (1.f / kD);
+        stat[tid] = row_mean;
     }
     __syncthreads();
 #pragma unroll
@@ -229,7 +231,12 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
         float q = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) q += scr[ww * ROWS + tid];
-        stat[tid] = rsqrtf(q * (1.f / kD) + eps);
+        const float rstd = rsqrtf(q * (1.f / kD) + eps);
+        stat[tid] = rstd;
+        if (stats != nullptr && tid < nrows) {      // training: the LayerNorm statistics the backward kernel needs, [N][4]
+            stats[(row0 + tid) * 4] = row_mean;
+            stats[(row0 + tid) * 4 + 1] = rstd;
+        }
     }
     __syncthreads();
     float gm[4], bt[4];
@@ -268,8 +275,8 @@ extern "C" int vlsa_prepare_featproj(const float* W, const float* b, const float
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
-extern "C" int vlsa_feat_project(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
-                                 int64_t ldy, void* stream) {
+static int feat_project_impl(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
+                             int64_t ldy, float* stats, void* stream) {
     if (!X || !prep || !Y || N < 1 || ldx < D || ldy < D) return VLSA_EINVAL;
     if (D != fp::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
     const bool f32 = x_dtype == VLSA_DT_F32;
@@ -282,7 +289,7 @@ extern "C" int vlsa_feat_project(const void* X, int x_dtype, int64_t N, int64_t 
     // 313 of 32 30-35 us; tools/kbench_featproj.py)
 #define VLSA_FP(X32, RT_)                                                                                                  \
     hipLaunchKernelGGL((k_feat_proj<X32, RT_>), dim3((unsigned int)((N + 16 * RT_ - 1) / (16 * RT_))), dim3(512), fp::kLds, st, X, \
-                       (long long)N, (long long)ldx, pp, eps, Y, (long long)ldy)
+                       (long long)N, (long long)ldx, pp, eps, Y, (long long)ldy, stats)
     if (f32) {
         if (N >= 120 * 64) VLSA_FP(true, 4);
         else VLSA_FP(true, 2);
@@ -293,4 +300,17 @@ extern "C" int vlsa_feat_project(const void* X, int x_dtype, int64_t N, int64_t 
     }
 #undef VLSA_FP
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_feat_project(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
+                                 int64_t ldy, void* stream) {
+    return feat_project_impl(X, x_dtype, N, ldx, D, prep, eps, Y, ldy, nullptr, stream);
+}
+
+// Training forward: as vlsa_feat_project, and stats [N][4] receives (row mean, 1 / sqrt(var + eps)) of the pre-LayerNorm
+// activations in columns 0, 1 (columns 2, 3 are filled by vlsa_feat_project_rowstats in the backward pass).
+extern "C" int vlsa_feat_project_train(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
+                                       int64_t ldy, float* stats, void* stream) {
+    if (!stats) return VLSA_EINVAL;
+    return feat_project_impl(X, x_dtype, N, ldx, D, prep, eps, Y, ldy, stats, stream);
 }

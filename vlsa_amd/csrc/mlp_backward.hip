@@ -1,0 +1,518 @@
+// Backward of the two N-sized "linear layer + row-wise non-linearity" pieces of the path:
+//
+//   (Gated_)Attention_Pooling scores (model/layers.py:103-122,137-153):  a_n = w2 . (tanh(Wa x_n + ba) [* sigmoid(Wg x_n + bg)]) + c
+//        given da_n = dL/da_n:  dWa, dba, dWg, dbg, dw2, dc
+//   Feat_Projecter (model/layers.py:65-82):  y_n = LayerNorm(W x_n + b) * gamma + beta
+//        given dy_n = dL/dy_n:  dW, db, dgamma, dbeta
+//
+// PyTorch autograd (and round 2 here) does this with the [N, 256] / [N, 512] hidden activations saved in memory, two library
+// GEMMs and ~10 elementwise kernels.  Here ONE kernel per layer, no N-sized intermediate: per tile of rows the hidden
+// pre-activations are RECOMPUTED on the matrix pipe (same packed bf16 hi + lo weight fragments as the forward kernels), turned
+// into the pre-activation gradient dH in registers, and dW += dH^T X is a second MFMA contraction over the rows of the tile.
+//
+//   * wave = 16 hidden units (one branch) x all 512 input columns: dW accumulator = 32 column tiles = 128 registers per lane.
+//     The recomputed H tile comes out of the MFMA as C[row][hidden] with the hidden unit on the lane index and 4 rows per
+//     register group -- which IS the A-fragment layout of the second contraction (M = hidden, K = rows) once k-slot (g, j) is
+//     mapped to tile row 16 (j >> 2) + 4 g + (j & 3): dH never leaves registers (the trick of the streaming kernels' p X
+//     contraction).  Its B fragments X[rows][16 columns] are hardware-transposed LDS reads (ds_read_b64_tr_b16) of the same X
+//     tile the recomputation read row-wise.
+//   * workgroup = 8 waves = one SLICE of the hidden units: gated 4 tiles x 2 branches (the pair exchanges tanh / sigmoid
+//     through LDS: dHa needs s, dHg needs t), tanh-only 8 tiles, projecter 8 output tiles.  Slices x row chunks = 256
+//     workgroups (one per CU); a chunk's slices sit on the same XCD (blockIdx -> (slice, chunk) below) so that the X tile they
+//     all read comes out of that XCD's L2 after the first miss.
+//   * persistent over rows: a workgroup walks its range of row tiles (of all bags of the launch: the weights are shared by
+//     the bags of an optimizer step, so dW sums over bags), the next tile's global loads in flight during the dW contraction;
+//     one partial per workgroup at the end, reduced in a fixed order by k_mb_reduce (deterministic, no atomics).
+//   * X: bf16 rows are consumed exactly (64-row tiles); fp32 rows (the reference's feature format; the projected bag) are
+//     split into bf16 hi + lo images on the fly (32-row tiles, 3 product terms).  dH is split hi + lo as well.
+// MFMA-bound: per row 2 x (512 x H) recompute + 2 x (512 x H) for dW, both as 2 bf16 terms (H = 512 gated, 256 tanh, 512
+// projecter): 2.1 MFLOP per row for the gated scores = 4 x the algorithmic forward.
+#include "vlsa_common.h"
+
+namespace vlsa {
+
+typedef bf16x8 __attribute__((may_alias)) bf16x8_mb;
+typedef bf16x4 __attribute__((may_alias)) bf16x4_mb;
+typedef f32x4 __attribute__((may_alias)) f32x4_mb;
+typedef float __attribute__((may_alias)) float_mb;
+typedef unsigned int u32x4_mb_t __attribute__((ext_vector_type(4)));
+typedef u32x4_mb_t __attribute__((may_alias)) u32x4_mb;
+
+namespace mb {
+constexpr int kD = 512;
+constexpr int kTileBytes = 65536;            // bf16: 64 rows x 1 KiB; fp32: hi + lo bf16 images of 32 rows
+constexpr int kExchOff = kTileBytes;         // gated: tanh / sigmoid exchange (32 KiB); projecter: dy slice [64][132] fp32
+constexpr int kExchBytes = 64 * 132 * 4;     // 33,792 B
+constexpr int kLds = kExchOff + kExchBytes;
+constexpr int kDyPitch = 132;
+enum { kTanh = 0, kGated = 1, kLN = 2 };
+}  // namespace mb
+
+struct MbBag {
+    const void* X;
+    long long N, ldx;
+};
+
+struct MbArgs {
+    const MbBag* bags;          // [B] rows of the layer input
+    const MbBag* dy;            // projecter: [B] upstream gradient rows (fp32 [N, 512]); else null
+    const int* tile_start;      // [B + 1] first row tile of every bag (tiles of mb rows: 64 bf16 / 32 fp32)
+    const long long* row_off;   // [B] offset of bag b's rows in `rowvec`
+    const float* rowvec;        // scores: da [sum N]; projecter: stats [sum N][4] = (mean, rstd, c1, c2)
+    const unsigned char* wpack; // fragment-packed weights of the forward kernel
+    const float* bias_a;        // scores: pre-scaled ba (exp2 domain); projecter: b
+    const float* bias_g;        // gated: pre-scaled bg
+    const float* vec;           // scores: w2 [256]; projecter: gamma [512]
+    float* part_w;              // [C][U][512] partial dW, U = rows of the stacked weight matrix
+    float* part_v;              // [C][3][512] partial vectors
+    int B, n_tiles, C;
+};
+
+__device__ __forceinline__ int mb_swz(int row, int byte_off) { return row * 256 + (byte_off ^ ((row & 7) << 5)); }
+
+// MODE: mb::kTanh / kGated / kLN.  XF32: fp32 input rows.
+template <int MODE, bool XF32>
+__global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
+    using namespace mb;
+    constexpr int RT = XF32 ? 2 : 4;             // 16-row tiles per step
+    constexpr int ROWS = 16 * RT;
+    constexpr int QB = ROWS * 256;               // one column quarter of one bf16 image
+    constexpr int IMG = 4 * QB;                  // one bf16 image of the tile (fp32: hi image, lo image behind it)
+    constexpr int NSL = MODE == kTanh ? 2 : 4;   // hidden slices
+    constexpr int U = MODE == kTanh ? 256 : 512; // rows of the stacked dW
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    // blockIdx -> (slice, chunk): consecutive workgroups go round-robin over the 8 XCDs, so chunk c lives on XCD c % 8 with all
+    // of its slices
+    const int j = blockIdx.x;
+    const int c = (j & 7) + 8 * (j / (8 * NSL));
+    const int sl = (j >> 3) % NSL;
+    if (c >= a.C) return;
+    const int br = MODE == kGated ? (w >> 2) : 0;
+    const int unit = MODE == kGated ? 4 * sl + (w & 3) : 8 * sl + w;     // 16-wide tile of hidden units / outputs
+    const int urow = (MODE == kGated ? br * 256 : 0) + 16 * unit;        // first row of this wave's block in the stacked dW
+    // fragment address of (k step, term): scores: GatedPrepLayout.wpack; projecter: FeatProjLayout.wpack
+    const unsigned char* wp;
+    int ks_stride;
+    if constexpr (MODE == kLN) {
+        wp = a.wpack + ((size_t)(unit >> 2) * 16 * 8 + (unit & 3) * 2) * 1024 + lane * 16;
+        ks_stride = 8 * 1024;
+    } else {
+        constexpr int NF = MODE == kGated ? 4 : 2;
+        wp = a.wpack + ((size_t)unit * 16 * NF + br * 2) * 1024 + lane * 16;
+        ks_stride = NF * 1024;
+    }
+    const float hb = (MODE == kGated && br == 1) ? a.bias_g[16 * unit + i16] : a.bias_a[16 * unit + i16];
+    const float hv = a.vec[16 * unit + i16];      // w2 of the hidden unit / gamma of the output
+
+    const int t0 = (int)((long long)a.n_tiles * c / a.C), t1 = (int)((long long)a.n_tiles * (c + 1) / a.C);
+
+    f32x4 accw[32];
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) accw[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;          // scores: db, dw2, dc;  projecter: db, dgamma, dbeta
+
+    // ---- tile lookup + register staging of a tile's rows -------------------------------------------------------------------
+    struct Tile { const unsigned char* x; const float* dy; const float* rv; long long ldx, lddy; int nrows; };
+    auto find = [&](int t) -> Tile {
+        const int ts = lane < a.B ? a.tile_start[lane] : 0x7fffffff;
+        const int b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ts <= t)) - 1;
+        const MbBag bag = a.bags[b];
+        const long long row0 = (long long)(t - a.tile_start[b]) * ROWS;
+        Tile r;
+        r.ldx = bag.ldx;
+        r.nrows = (int)((bag.N - row0) < ROWS ? (bag.N - row0) : ROWS);
+        r.x = static_cast<const unsigned char*>(bag.X) + row0 * bag.ldx * (XF32 ? 4 : 2);
+        r.rv = a.rowvec + (a.row_off[b] + row0) * (MODE == kLN ? 4 : 1);
+        r.dy = nullptr;
+        r.lddy = 0;
+        if constexpr (MODE == kLN) {
+            const MbBag d = a.dy[b];
+            r.dy = static_cast<const float*>(d.X) + row0 * d.ldx;
+            r.lddy = d.ldx;
+        }
+        return r;
+    };
+    u32x4_mb_t st[8];
+    u32x4_mb_t sd[MODE == kLN ? (XF32 ? 2 : 4) : 1];
+    auto stage_load = [&](const Tile& T) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = tid + 512 * k;
+            const int row = XF32 ? (p >> 7) : (p >> 6), ch = XF32 ? (p & 127) : (p & 63);
+            st[k] = u32x4_mb_t{0u, 0u, 0u, 0u};
+            if (row < T.nrows) st[k] = *reinterpret_cast<const u32x4_mb_t*>(T.x + ((size_t)row * T.ldx * (XF32 ? 4 : 2)) + ch * 16);
+        }
+        if constexpr (MODE == kLN) {          // this slice's 128 columns of dy: [ROWS][128] fp32
+#pragma unroll
+            for (int k = 0; k < (XF32 ? 2 : 4); ++k) {
+                const int p = tid + 512 * k;
+                const int row = p >> 5, ch = p & 31;
+                sd[k] = u32x4_mb_t{0u, 0u, 0u, 0u};
+                if (row < T.nrows) sd[k] = *reinterpret_cast<const u32x4_mb_t*>(T.dy + (size_t)row * T.lddy + 128 * sl + 4 * ch);
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = tid + 512 * k;
+            if constexpr (XF32) {
+                const int row = p >> 7, c4 = p & 127;
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int bits = st[k][e];
+                    const float f = __uint_as_float(bits);
+                    hi[e] = (__bf16)f;
+                    lo[e] = (__bf16)(f - (float)hi[e]);
+                }
+                const int off = (c4 >> 5) * QB + mb_swz(row, (c4 & 31) * 8);
+                *reinterpret_cast<bf16x4_mb*>(smem + off) = hi;
+                *reinterpret_cast<bf16x4_mb*>(smem + IMG + off) = lo;
+            } else {
+                const int row = p >> 6, ch = p & 63;
+                *reinterpret_cast<u32x4_mb*>(smem + (ch >> 4) * QB + mb_swz(row, (ch & 15) * 16)) = st[k];
+            }
+        }
+        if constexpr (MODE == kLN) {
+#pragma unroll
+            for (int k = 0; k < (XF32 ? 2 : 4); ++k) {
+                const int p = tid + 512 * k;
+                const int row = p >> 5, ch = p & 31;
+                *reinterpret_cast<u32x4_mb*>(smem + kExchOff + (row * kDyPitch + 4 * ch) * 4) = sd[k];
+            }
+        }
+    };
+
+    if (t0 < t1) {
+        for (int t = t0; t < t1; ++t) {
+            const Tile cur = find(t);
+            stage_load(cur);
+            stage_store();
+            __syncthreads();
+            // per-row inputs of this lane's rows (C layout: rows 16 rt + 4 g + r)
+            f32x4 rv[RT];             // scores: da of the 4 rows
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (MODE != kLN) {
+                    const int row = 16 * rt + 4 * g;
+                    if (row + 3 < cur.nrows) {
+                        rv[rt] = f32x4{cur.rv[row], cur.rv[row + 1], cur.rv[row + 2], cur.rv[row + 3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rv[rt][r] = (row + r < cur.nrows) ? cur.rv[row + r] : 0.f;
+                    }
+                }
+            }
+            // ---- phase 1: recompute the pre-activations of this wave's 16 units for the tile's rows ----------------------
+            f32x4 acch[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acch[rt] = f32x4{hb, hb, hb, hb};
+            {
+                bf16x8 B0[2], B1[2];
+                auto load_b = [&](int ks, bf16x8 (&dst)[2]) {
+                    dst[0] = *reinterpret_cast<const bf16x8*>(wp + (size_t)ks * ks_stride);
+                    dst[1] = *reinterpret_cast<const bf16x8*>(wp + (size_t)ks * ks_stride + 1024);
+                };
+                auto kstep = [&](int ks, const bf16x8 (&Bc)[2]) {
+                    const int qoff = (ks >> 2) * QB, boff = (ks & 3) * 64 + g * 16;
+                    bf16x8 A[RT], AL[XF32 ? RT : 1];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        A[rt] = *reinterpret_cast<const bf16x8_mb*>(smem + qoff + mb_swz(16 * rt + i16, boff));
+                        if constexpr (XF32) AL[rt] = *reinterpret_cast<const bf16x8_mb*>(smem + IMG + qoff + mb_swz(16 * rt + i16, boff));
+                    }
+#pragma unroll
+                    for (int term = 0; term < 2; ++term)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acch[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt], Bc[term], acch[rt], 0, 0, 0);
+                    if constexpr (XF32) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            acch[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[rt], Bc[0], acch[rt], 0, 0, 0);
+                    }
+                };
+                load_b(0, B0);
+#pragma unroll 1
+                for (int ks = 0; ks < 16; ks += 2) {      // rolled on purpose: unrolled, the scheduler hoists all 32 weight loads
+                    load_b(ks + 1, B1);
+                    kstep(ks, B0);
+                    if (ks + 2 < 16) load_b(ks + 2, B0);
+                    kstep(ks + 1, B1);
+                }
+            }
+            // ---- phase 2a (scores): activations in place of the accumulators; the gated pair exchanges them through LDS --------
+            // accumulators are the exp2 arguments: branch a: u = e^{-2x}, tanh = (1 - u) / (1 + u); branch g: v = e^{-y},
+            // sigmoid = 1 / (1 + v)   (weights and biases pre-scaled by k_prepare_gated_weights)
+            unsigned char* ex = smem + kExchOff + (w & 3) * 8192;
+            if constexpr (MODE != kLN) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (br == 0) {
+                            const float u = fast_exp2(fminf(acch[rt][r], 43.f));
+                            acch[rt][r] = (1.f - u) * __builtin_amdgcn_rcpf(1.f + u);
+                        } else {
+                            const float v = fast_exp2(fminf(acch[rt][r], 57.f));
+                            acch[rt][r] = __builtin_amdgcn_rcpf(1.f + v);
+                        }
+                    }
+                if constexpr (MODE == kGated) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4_mb*>(ex + br * 4096 + (rt * 64 + lane) * 16) = acch[rt];
+                    __syncthreads();
+                }
+            }
+            // ---- per 32 rows: phase 2b: the pre-activation gradient dH of the lane's (rows, unit) entries; phase 3:
+            // dW[unit][:] += dH^T X over those rows ---------------------------------------------------------------------------------
+#pragma unroll
+            for (int q32 = 0; q32 < RT / 2; ++q32) {
+                bf16x8 ahi, alo;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rt = 2 * q32 + h;
+                    f32x4 other = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if constexpr (MODE == kGated) other = *reinterpret_cast<const f32x4_mb*>(ex + (br ^ 1) * 4096 + (rt * 64 + lane) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float d;
+                        if constexpr (MODE == kLN) {
+                            const float_mb* dys = reinterpret_cast<const float_mb*>(smem + kExchOff);
+                            const int row = 16 * rt + 4 * g + r;
+                            const float dyv = dys[row * kDyPitch + 16 * w + i16];     // 0 for rows past the bag's end
+                            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};                       // (mean, rstd, c1, c2) of the row
+                            if (row < cur.nrows) s4 = *reinterpret_cast<const f32x4*>(cur.rv + 4 * row);
+                            const float zh = (acch[rt][r] - s4[0]) * s4[1];
+                            d = s4[1] * (dyv * hv - s4[2] - zh * s4[3]);
+                            v0 += d;
+                            v1 += dyv * zh;
+                            v2 += dyv;
+                        } else {
+                            const float m = acch[rt][r], dav = rv[rt][r];
+                            const float dfac = br == 0 ? (1.f - m * m) : m * (1.f - m);     // tanh' / sigmoid'
+                            d = dav * hv * dfac * other[r];
+                            v0 += d;
+                            if (br == 0) {
+                                v1 += dav * m * other[r];
+                                v2 += dav;
+                            }
+                        }
+                        const __bf16 hi = (__bf16)d;
+                        ahi[4 * h + r] = hi;
+                        alo[4 * h + r] = (__bf16)(d - (float)hi);
+                    }
+                }
+                const int rr = 32 * q32 + 4 * g + (i16 >> 2);
+#pragma unroll
+                for (int ct = 0; ct < 32; ++ct) {
+                    const int off = (ct >> 3) * QB, c_off = (ct & 7) * 32 + (i16 & 3) * 8;
+                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + off + mb_swz(rr, c_off)));
+                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + off + mb_swz(16 + rr, c_off)));
+                    const bf16x8 bh = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    accw[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bh, accw[ct], 0, 0, 0);
+                    accw[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, accw[ct], 0, 0, 0);
+                    if constexpr (XF32) {
+                        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + IMG + off + mb_swz(rr, c_off)));
+                        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(smem + IMG + off + mb_swz(16 + rr, c_off)));
+                        const bf16x8 bl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        accw[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bl, accw[ct], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();          // every wave is done with the tile (and the exchange area)
+        }
+    }
+
+    // ---- the workgroup's partial: dW block of this wave, vectors ---------------------------------------------------------------
+    float* pw = a.part_w + ((size_t)c * U + urow) * kD;
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(size_t)(4 * g + r) * kD + 16 * ct + i16] = accw[ct][r];
+    v0 = quad_rows_sum(v0);
+    v1 = quad_rows_sum(v1);
+    v2 = quad_rows_sum(v2);
+    float* pv = a.part_v + (size_t)c * 3 * kD;
+    if (g == 0) {
+        if constexpr (MODE == kLN) {
+            pv[16 * unit + i16] = v0;
+            pv[kD + 16 * unit + i16] = v1;
+            pv[2 * kD + 16 * unit + i16] = v2;
+        } else {
+            pv[br * 256 + 16 * unit + i16] = v0;                       // db: [ba | bg]
+            if (br == 0) pv[kD + 16 * unit + i16] = v1;                // dw2
+            if (br == 0 && unit == 0 && i16 == 0) pv[2 * kD] = v2;     // dc = sum of da (every lane of the wave holds it)
+        }
+    }
+}
+
+// out[i] = sum_c part[c][i], fixed order; float4 per thread
+__global__ __launch_bounds__(256) void k_mb_reduce(const float* __restrict__ part, int C, long long total, float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + i);
+    for (int c = 1; c < C; ++c) s += *reinterpret_cast<const f32x4*>(part + (size_t)c * total + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+// Per-row LayerNorm-backward scalars of the projecter (one wave per row): c1 = mean_o(dy gamma), c2 = mean_o(dy (y - beta))
+// [= mean_o(dy gamma zhat): no division by gamma], written behind the forward's (mean, rstd) into stats[row][2..3].
+__global__ __launch_bounds__(256) void k_ln_bwd_rowstats(const float* __restrict__ dy, long long lddy, const float* __restrict__ y,
+                                                          long long ldy, long long N, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int col = 4 * lane + 256 * k;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * lddy + col);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + row * ldy + col);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + col);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += d[e] * gm[e];
+            s2 += d[e] * (v[e] - bt[e]);
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        stats[row * 4 + 2] = s1 * (1.f / 512.f);
+        stats[row * 4 + 3] = s2 * (1.f / 512.f);
+    }
+}
+
+}  // namespace vlsa
+
+using namespace vlsa;
+
+namespace {
+struct GatedPrepOffsets {      // mirrors GatedPrepLayout (gated_scores.hip)
+    size_t wpack, ba, bg, w2, c;
+    explicit GatedPrepOffsets(int gated) {
+        wpack = 0;
+        ba = wpack + (size_t)2 * 8 * 16 * (gated ? 4 : 2) * 1024;
+        bg = ba + 256 * 4;
+        w2 = bg + 256 * 4;
+        c = w2 + 256 * 4;
+    }
+};
+struct FeatProjOffsets {       // mirrors FeatProjLayout (feat_proj.hip)
+    size_t wpack = 0, bias = (size_t)8 * 16 * 8 * 1024, gamma = bias + 512 * 4, beta = gamma + 512 * 4;
+};
+int chunks_for(int n_tiles, int nsl) {
+    int C = 256 / nsl;
+    if (n_tiles < C) C = n_tiles;
+    return C < 1 ? 1 : C;
+}
+template <int MODE, bool XF32>
+int launch(const MbArgs& a, int nsl, hipStream_t st) {
+    static DeviceOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)k_mlp_backward<MODE, XF32>, hipFuncAttributeMaxDynamicSharedMemorySize, mb::kLds);
+    const unsigned int grid = 8u * nsl * ((a.C + 7) / 8);
+    hipLaunchKernelGGL((k_mlp_backward<MODE, XF32>), dim3(grid), dim3(512), mb::kLds, st, a);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+}  // namespace
+
+extern "C" int vlsa_mlp_bwd_tile_rows(int x_dtype) { return x_dtype == VLSA_DT_F32 ? 32 : 64; }
+
+// workspace (partials) of one backward launch over n_tiles row tiles
+extern "C" size_t vlsa_mlp_bwd_workspace_bytes(int mode, int n_tiles) {
+    const int nsl = mode == mb::kTanh ? 2 : 4, U = mode == mb::kTanh ? 256 : 512;
+    return (size_t)chunks_for(n_tiles < 1 ? 1 : n_tiles, nsl) * (U + 3) * 512 * sizeof(float);
+}
+
+// Backward of the (gated) attention scores of B bags.  bag_desc: device table of vlsa_bag_desc {X, N, ldx}; tile_start [B + 1]
+// (device, int32) in tiles of vlsa_mlp_bwd_tile_rows(x_dtype) rows; da: dL/da of all bags' rows, bag b at da + a_off[b] (device
+// int64 offsets); prep: the block of vlsa_prepare_gated_weights.  Outputs: dW [gated ? 2 : 1][256][512] (dWa, dWg),
+// dvec [3][512]: row 0 = (dba [256] | dbg [256]), row 1 = dw2 [256], dvec[2][0] = dc.
+extern "C" int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated,
+                                         const int* tile_start, int n_tiles, const float* da, const int64_t* a_off, void* ws,
+                                         float* dW, float* dvec, void* stream) {
+    if (!bag_desc || !prep || !tile_start || !da || !a_off || !ws || !dW || !dvec || B < 1 || B > 64 || n_tiles < 1) return VLSA_EINVAL;
+    if (D != mb::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    const int mode = gated ? mb::kGated : mb::kTanh, nsl = gated ? 4 : 2, U = gated ? 512 : 256;
+    const GatedPrepOffsets L(gated ? 1 : 0);
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+    MbArgs a{};
+    a.bags = static_cast<const MbBag*>(bag_desc);
+    a.tile_start = tile_start;
+    a.row_off = reinterpret_cast<const long long*>(a_off);
+    a.rowvec = da;
+    a.wpack = pp + L.wpack;
+    a.bias_a = reinterpret_cast<const float*>(pp + L.ba);
+    a.bias_g = reinterpret_cast<const float*>(pp + L.bg);
+    a.vec = reinterpret_cast<const float*>(pp + L.w2);
+    a.B = B;
+    a.n_tiles = n_tiles;
+    a.C = chunks_for(n_tiles, nsl);
+    a.part_w = static_cast<float*>(ws);
+    a.part_v = a.part_w + (size_t)a.C * U * 512;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const bool f32 = x_dtype == VLSA_DT_F32;
+    if (mode == mb::kGated) rc = f32 ? launch<mb::kGated, true>(a, nsl, st) : launch<mb::kGated, false>(a, nsl, st);
+    else rc = f32 ? launch<mb::kTanh, true>(a, nsl, st) : launch<mb::kTanh, false>(a, nsl, st);
+    if (rc != VLSA_OK) return rc;
+    const long long tw = (long long)U * 512, tv = 3 * 512;
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 255) / 256)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 255) / 256)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// c1, c2 of the projecter's LayerNorm backward for one bag: stats [N][4] holds (mean, rstd) from the training forward
+// (vlsa_feat_project_train); columns 2, 3 are written here from dy and the projected rows y.
+extern "C" int vlsa_feat_project_rowstats(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t N, const void* prep,
+                                          float* stats, void* stream) {
+    if (!dy || !y || !prep || !stats || N < 1 || lddy < 512 || ldy < 512) return VLSA_EINVAL;
+    const FeatProjOffsets L;
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+    hipLaunchKernelGGL(k_ln_bwd_rowstats, dim3((unsigned int)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, (long long)lddy, y,
+                       (long long)ldy, (long long)N, reinterpret_cast<const float*>(pp + L.gamma), reinterpret_cast<const float*>(pp + L.beta),
+                       stats);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// Backward of Feat_Projecter over B bags.  bag_desc / dy_desc: device tables {ptr, N, ld} of the input rows (bf16 or fp32) and of
+// the upstream gradient rows (fp32 [N, 512]); stats: [sum N][4] (mean, rstd, c1, c2), bag b at row row_off[b]; prep: the block of
+// vlsa_prepare_featproj.  Outputs: dW [512][512], dvec [3][512] = (db, dgamma, dbeta).
+extern "C" int vlsa_feat_project_backward(const void* bag_desc, const void* dy_desc, int B, int x_dtype, const void* prep,
+                                          const int* tile_start, int n_tiles, const float* stats, const int64_t* row_off, void* ws,
+                                          float* dW, float* dvec, void* stream) {
+    if (!bag_desc || !dy_desc || !prep || !tile_start || !stats || !row_off || !ws || !dW || !dvec || B < 1 || B > 64 || n_tiles < 1)
+        return VLSA_EINVAL;
+    if (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) return VLSA_EUNSUPPORTED;
+    const FeatProjOffsets L;
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+    MbArgs a{};
+    a.bags = static_cast<const MbBag*>(bag_desc);
+    a.dy = static_cast<const MbBag*>(dy_desc);
+    a.tile_start = tile_start;
+    a.row_off = reinterpret_cast<const long long*>(row_off);
+    a.rowvec = stats;
+    a.wpack = pp + L.wpack;
+    a.bias_a = reinterpret_cast<const float*>(pp + L.bias);
+    a.bias_g = nullptr;
+    a.vec = reinterpret_cast<const float*>(pp + L.gamma);
+    a.B = B;
+    a.n_tiles = n_tiles;
+    a.C = chunks_for(n_tiles, 4);
+    a.part_w = static_cast<float*>(ws);
+    a.part_v = a.part_w + (size_t)a.C * 512 * 512;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = x_dtype == VLSA_DT_F32 ? launch<mb::kLN, true>(a, 4, st) : launch<mb::kLN, false>(a, 4, st);
+    if (rc != VLSA_OK) return rc;
+    const long long tw = 512ll * 512, tv = 3 * 512;
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 255) / 256)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 255) / 256)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}

@@ -50,18 +50,6 @@ def logit_pooling(logits: torch.Tensor, method: str):
     return pooled.argmax(dim=1), pooled
 
 
-def _cross_attention_autograd(X2: torch.Tensor, Q: torch.Tensor, gated: bool, scale: float):
-    """The cross attention of model/deepmil.py:187-200 as device torch ops -- taken ONLY when the bag itself carries a
-    gradient (a trainable Feat_Projecter in front of the aggregation): the HIP streaming kernels produce no dX.
-    Returns (out [P, D], A [P, N])."""
-    Xf = X2.float()
-    S = F.normalize(Q.float(), dim=-1) @ F.normalize(Xf, dim=-1).t()
-    if gated:
-        S = S[:-1] - S[-1:]
-    A = torch.softmax(S * scale, dim=-1)
-    return A @ Xf, A
-
-
 class FeatMIL(nn.Module):
     """Feature aggregation only: 'mean' | 'max' over the patches, anything else = identity (zero-shot)."""
 
@@ -227,11 +215,9 @@ class VLFAN(nn.Module):
             assert self._pos_gated_query == -1, "The gated query is placed at the end by default."
             assert Q.shape[0] == self.num_query + 1, f"Query number is expected to be {self.num_query + 1}."
         scale = float(self.coattn_logit_scale.exp())
-        if torch.is_grad_enabled() and X.requires_grad:
-            out, A = _cross_attention_autograd(VF._bag2d(X), Q, self.gated_query, scale)
-            A = A.detach() if ret_with_attn else None
-        else:
-            out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
+        # HIP forward and backward: dQ always, dX as well when the bag carries a gradient (a trainable Feat_Projecter in front:
+        # its output is an fp32 [N, 512] bag; vlsa_vlfan_backward_dx)
+        out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
         pooled_out, pooled_ext = self.forward_query_pooling(out.unsqueeze(0))
         visual_features = self.visual_adapter(pooled_out)
         if ret_with_attn:
@@ -248,14 +234,10 @@ class VLFAN(nn.Module):
         per-bag attention exactly as ``forward(x, ret_with_attn=True)`` hands it out: a list of ``A`` [1, P, N_i], or of
         ``(A, pool_scores)`` when the query pooling is a module (model/deepmil.py:206-215).  ``projected``: the bags already
         went through ``project``."""
-        if self._projecter_trains() or any(torch.is_grad_enabled() and x.requires_grad for x in bags):
-            # gradients have to reach the projecter / the bags: bag by bag through the differentiable torch route of forward()
-            rs = [self.forward(x if x.dim() == 3 else x[None], ret_with_attn=ret_with_attn) for x in bags]
-            if ret_with_attn:
-                return torch.cat([r[0] for r in rs]), [r[1] for r in rs]
-            return torch.cat(rs)
         if self.feat_proj is not None and not projected:
-            bags = [self.feat_proj(x) for x in bags]          # frozen / inference: one fused HIP launch per bag, fp32 out
+            # one fused HIP launch per bag, fp32 out; a projecter that trains records its LayerNorm statistics and receives its
+            # gradient from the HIP backward kernels (the aggregation hands dX back for the projected bags)
+            bags = [self.feat_proj(x) for x in bags]
         outs_cat, attn = self._aggregate_bags(bags, ret_with_attn)
         pooled_out, pooled_ext = self.forward_query_pooling(outs_cat)
         feats = self.visual_adapter(pooled_out)
@@ -267,10 +249,8 @@ class VLFAN(nn.Module):
 
     def aggregate_bags(self, bags):
         """The P aggregated rows of every bag, [B, P, C], differentiable w.r.t. the queries (persistent multi-bag kernels forward
-        and backward) -- ``forward_bags`` without the query pooling and the adapter; None when gradients have to reach the bags
-        or a trainable Feat_Projecter (``forward_bags`` then goes bag by bag through torch ops)."""
-        if self._projecter_trains() or any(torch.is_grad_enabled() and x.requires_grad for x in bags):
-            return None
+        and backward) -- ``forward_bags`` without the query pooling and the adapter.  A trainable Feat_Projecter is part of
+        the graph (HIP forward + backward; the aggregation hands dX back for the projected fp32 bags)."""
         if self.feat_proj is not None:
             bags = [self.feat_proj(x) for x in bags]
         return self._aggregate_bags(bags, False)[0]
@@ -351,6 +331,17 @@ class DeepMIL(nn.Module):
                 return self._fused_scores(X2, lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias,
                                           sg.fc2.weight, sg.fc2.bias)
             return self._fused_scores(X2, lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias)
+        if (need_grad and not X2.requires_grad and not (gated and sg.training and sg.fc1[2].p > 0)
+                and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
+            # the pooling module trains, the bag carries no gradient: fused MFMA forward + the HIP backward that recomputes the
+            # hidden activations tile by tile (vlsa_attn_scores_backward) -- no [N, 256] activations, no library GEMM
+            if not hasattr(self, "_fused_scores"):
+                self._fused_scores = VF.FusedAttnScores()
+            if gated:
+                return VF.attn_scores_autograd(X2, self._fused_scores, lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias,
+                                               sg.fc2.weight, sg.fc2.bias)
+            return VF.attn_scores_autograd(X2, self._fused_scores, lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight,
+                                           sg.attention[2].bias)
         Xf = X2 if X2.dtype == torch.float32 else X2.float()
         if isinstance(sg, Attention_Pooling):
             lin1, lin2 = sg.attention[0], sg.attention[2]

@@ -377,6 +377,24 @@ class VlfanInferencePlan:
 # ------------------------------------------------------------------------------------------------------
 # autograd: cross-attention aggregation with gradient w.r.t. the queries (X has none in the reference)
 # ------------------------------------------------------------------------------------------------------
+def _vlfan_dx(bags, qbuf, P: int, scale: float, dout: torch.Tensor, out: torch.Tensor, m2: torch.Tensor, l: torch.Tensor):
+    """dL/dX of the cross attention for a list of fp32 [N_i, 512] bags (vlsa_vlfan_backward_dx): dout / out [B, P, 512],
+    m2 / l [B, 16].  Returns a list of fp32 [N_i, 512] gradients."""
+    lib = nat.load()
+    dev = bags[0].device
+    for x in bags:
+        if x.dtype != torch.float32 or x.shape[1] != 512:
+            raise VlsaNativeError("the HIP aggregation produces dX for fp32 bags with D == 512 only (the output of a trainable "
+                                  "Feat_Projecter); detach the bag or use such a bag")
+    dxs = [torch.empty(x.shape[0], 512, dtype=torch.float32, device=dev) for x in bags]
+    B = len(bags)
+    keep, p_desc, p_dx, _, p_ts, n_tiles, _ = _row_tables(bags, 64, extra=dxs)
+    delta = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
+    nat.check(lib.vlsa_vlfan_backward_dx(p_desc, p_dx, B, 512, _p(qbuf), P, float(scale), p_ts, n_tiles, _p(_f32c(dout)), _p(out), _p(m2),
+                                         _p(l), _p(delta), _stream()), "vlsa_vlfan_backward_dx")
+    return dxs
+
+
 class _VlfanAggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, Q, gated, coattn_scale, kernel, want_attn):
@@ -387,6 +405,7 @@ class _VlfanAggregateFn(torch.autograd.Function):
         A = attn_normalise(scores, m2, l) if want_attn else torch.empty(0, device=X2.device)
         ctx.save_for_backward(X2, out, m2, l, qp.buf)
         ctx.meta = (qp.nq, qp.P, qp.D, bool(gated), float(coattn_scale))
+        ctx.xshape = tuple(X.shape)
         ctx.mark_non_differentiable(A)
         return out, A
 
@@ -416,7 +435,10 @@ class _VlfanAggregateFn(torch.autograd.Function):
         qhat, qnorm = qp.qhat, qp.qnorm
         dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
         dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
-        return None, dQ, None, None, None, None
+        dX = None
+        if ctx.needs_input_grad[0] and N > 0:       # the bag carries a gradient (trainable Feat_Projecter in front)
+            dX = _vlfan_dx([X2], qbuf, P, scale, dout[None], out[None], m2[None], l[None])[0].reshape(ctx.xshape)
+        return dX, dQ, None, None, None, None
 
 
 def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
@@ -424,7 +446,8 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
     """out[P, D] = softmax_N(coattn_scale * cos(Q, X)) @ X (model/deepmil.py:187-200), differentiable w.r.t. Q.
     Returns (out, A) with A[P, N] the detached attention weights (None unless want_attn)."""
     _need_gpu(X, Q)
-    _no_bag_grad(X)
+    if torch.is_grad_enabled() and X.requires_grad and not (X.dtype == torch.float32 and X.shape[-1] == 512):
+        _no_bag_grad(X)       # dX exists for fp32 D == 512 bags (vlsa_vlfan_backward_dx): anything else is refused loudly
     out, A = _VlfanAggregateFn.apply(X, Q.float(), bool(gated), float(coattn_scale), int(kernel), bool(want_attn))
     return out, (A if want_attn else None)
 
@@ -509,7 +532,9 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
     """out[B, P, D] for B bags sharing the queries Q; differentiable w.r.t. Q (the bags carry no gradient)."""
 
     @staticmethod
-    def forward(ctx, Q, gated, coattn_scale, table, attn=None):
+    def forward(ctx, Q, gated, coattn_scale, table, attn, *bag_tensors):
+        """bag_tensors: the bags of `table` once more, as autograd inputs (a bag that requires grad -- the output of a trainable
+        Feat_Projecter -- receives dX in backward; fp32 only)"""
         lib, s = nat.load(), _stream()
         B, D = table.B, table.D
         dev = table.desc.device
@@ -535,6 +560,7 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
                       "vlsa_attn_normalise_batch")
         ctx.save_for_backward(out, m2, l, qp.buf)
         ctx.table = table
+        ctx.xshapes = [tuple(x.shape) for x in bag_tensors]
         ctx.meta = (qp.nq, P, D, bool(gated), float(coattn_scale))
         return out
 
@@ -570,7 +596,11 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
         qhat, qnorm = qp.qhat, qp.qnorm
         dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
         dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
-        return dQ, None, None, None, None
+        dxs = [None] * B
+        if any(ctx.needs_input_grad[5:]):           # bags that carry a gradient (projected by a trainable Feat_Projecter)
+            got = _vlfan_dx(table.bags, qbuf, P, scale, dout, out, m2, l)
+            dxs = [g.reshape(shape) if need else None for g, shape, need in zip(got, ctx.xshapes, ctx.needs_input_grad[5:])]
+        return (dQ, None, None, None, None, *dxs)
 
 
 def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coattn_scale: float = COATTN_SCALE,
@@ -579,15 +609,16 @@ def vlfan_cross_attention_bags(bags, Q: torch.Tensor, gated: bool = False, coatt
     persistent multi-bag kernels (forward and backward); what one optimizer step of the reference does bag by bag
     (runner/vlsa_handler.py:260-289).  Bags: [N_i, 512] device tensors, N_i >= 1, one dtype per batch.
     want_attn: also return the detached attention weights, a list of [P, N_i] (model/deepmil.py:198,206-215)."""
-    _no_bag_grad(*bags)
+    if torch.is_grad_enabled():
+        _no_bag_grad(*[x for x in bags if not (x.dtype == torch.float32 and x.shape[-1] == 512)])   # dX: fp32 D == 512 bags only
     table = _BagTable(bags)
     if any(x.shape[0] == 0 for x in table.bags):
         raise VlsaNativeError("empty bag in a batch")
     if not want_attn:
-        return _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table)
+        return _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table, None, *bags)
     P = Q.shape[0] - (1 if gated else 0)
     attn = AttnBuffers([x.shape[0] for x in table.bags], P, table.desc.device)
-    out = _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table, attn)
+    out = _VlfanBatchAggregateFn.apply(Q.float(), bool(gated), float(coattn_scale), table, attn, *bags)
     return out, attn.views
 
 
@@ -788,6 +819,74 @@ class FusedAttnScores:
         return a
 
 
+def _row_tables(bags, tile_rows: int, extra=None):
+    """ONE upload for the tables the multi-bag backward kernels take: vlsa_bag_desc [B, 3] (pointer, N, row stride), optionally a
+    second table (``extra``: e.g. the gradient rows), row offsets [B] (int64) and tile_start [B + 1] (int32, tiles of
+    ``tile_rows`` rows).  Returns (device buffer, ptr of desc, ptr of extra desc or None, ptr of row_off, ptr of tile_start,
+    n_tiles, row offsets as a list)."""
+    import numpy as np
+    B = len(bags)
+    rows = [int(x.shape[0]) for x in bags]
+    n64 = 3 * B + (3 * B if extra is not None else 0) + B + (B + 2) // 2
+    host = np.zeros(n64, dtype=np.int64)
+    host[:3 * B] = np.asarray([(x.data_ptr(), n, x.stride(0)) for x, n in zip(bags, rows)], dtype=np.int64).reshape(-1)
+    o = 3 * B
+    if extra is not None:
+        host[o:o + 3 * B] = np.asarray([(x.data_ptr(), n, x.stride(0)) for x, n in zip(extra, rows)], dtype=np.int64).reshape(-1)
+        o += 3 * B
+    offs = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(rows, out=offs[1:])
+    host[o:o + B] = offs[:B]
+    ts = host[o + B:].view(np.int32)
+    ts[0] = 0
+    np.cumsum([(n + tile_rows - 1) // tile_rows for n in rows], out=ts[1:B + 1])
+    n_tiles = int(ts[B])
+    dev = torch.from_numpy(host).to(bags[0].device)
+    base = dev.data_ptr()
+    p_extra = base + 24 * B if extra is not None else None
+    p_off = base + 8 * o
+    return dev, base, p_extra, p_off, p_off + 8 * B, n_tiles, offs
+
+
+class _AttnScoresFn(torch.autograd.Function):
+    """Raw (gated) attention scores a [N] of one bag with a gradient for the pooling module's parameters: forward = the fused MFMA
+    kernel (vlsa_gated_scores), backward = vlsa_attn_scores_backward (hidden activations recomputed tile by tile, dW = dH^T X in
+    the same kernel) -- model/layers.py:103-122,137-153 under autograd without the [N, 256] activations in memory."""
+
+    @staticmethod
+    def forward(ctx, X2, fused, Wa, ba, Wg, bg, w2, c):
+        a = fused(X2, Wa, ba, Wg, bg, w2, c)
+        ctx.save_for_backward(X2, fused._prep)       # the packed weights of THIS parameter version
+        ctx.gated = Wg is not None
+        ctx.shapes = (w2.shape, c.shape)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        lib = nat.load()
+        X2, prep = ctx.saved_tensors
+        gated = ctx.gated
+        dev = X2.device
+        da = _f32c(da).reshape(-1)
+        tile_rows = int(lib.vlsa_mlp_bwd_tile_rows(_dt(X2)))
+        keep, p_desc, _, p_off, p_ts, n_tiles, _ = _row_tables([X2], tile_rows)
+        ws = torch.empty(lib.vlsa_mlp_bwd_workspace_bytes(1 if gated else 0, n_tiles), dtype=torch.uint8, device=dev)
+        dW = torch.empty(2 if gated else 1, 256, 512, dtype=torch.float32, device=dev)
+        dvec = torch.empty(3, 512, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_attn_scores_backward(p_desc, 1, _dt(X2), 512, _p(prep), int(gated), p_ts, n_tiles, _p(da), p_off, _p(ws),
+                                                _p(dW), _p(dvec), _stream()), "vlsa_attn_scores_backward")
+        w2_shape, c_shape = ctx.shapes
+        return (None, None, dW[0], dvec[0, :256], dW[1] if gated else None, dvec[0, 256:] if gated else None,
+                dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape))
+
+
+def attn_scores_autograd(X2: torch.Tensor, fused: "FusedAttnScores", Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
+    """a [N] of (Gated_)Attention_Pooling over a bag, differentiable w.r.t. the module's parameters (not the bag)."""
+    _need_gpu(X2)
+    _no_bag_grad(X2)
+    return _AttnScoresFn.apply(X2, fused, Wa, ba, Wg, bg, w2, c)
+
+
 def mean_pool_bags(bags) -> torch.Tensor:
     """Row means [B, 512] of up to 64 validated [N_i, 512] device bags (one dtype) in two launches (the 'mean' pooling of
     FeatMIL / DeepMIL over a batch: model/deepmil.py:57-58,271-272 per bag)."""
@@ -822,22 +921,72 @@ class FusedFeatProjecter:
         return (X2.is_cuda and X2.dim() == 2 and X2.dtype in (torch.bfloat16, torch.float32) and X2.shape[0] > 0
                 and linear.in_features == 512 and linear.out_features == 512 and tuple(norm.normalized_shape) == (512,))
 
-    def __call__(self, X2: torch.Tensor, W, b, gamma, beta, eps: float) -> torch.Tensor:
+    def packed(self, device, W, b, gamma, beta) -> torch.Tensor:
+        """the fragment-packed weights of this parameter version (re-packed when a parameter changed in place or was replaced)"""
         lib = nat.load()
-        X2 = _bag2d(X2)
         params = [t for t in (W, b, gamma, beta) if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in params) + (X2.device,)
+        key = tuple((id(t), t._version) for t in params) + (device,)
         if key != self._key:
-            prep = torch.empty(lib.vlsa_featproj_prep_bytes(), dtype=torch.uint8, device=X2.device)
+            prep = torch.empty(lib.vlsa_featproj_prep_bytes(), dtype=torch.uint8, device=device)
             keep = [None if t is None else _f32c(t).reshape(-1) for t in (W, b, gamma, beta)]
             nat.check(lib.vlsa_prepare_featproj(*[_p(t) for t in keep], W.shape[1], W.shape[0], _p(prep), _stream()),
                       "vlsa_prepare_featproj")
-            self._key, self._prep = key, prep
+            self._key, self._prep, self._params = key, prep, params      # (the parameters stay alive: their ids are the key)
+        return self._prep
+
+    def autograd(self, X2: torch.Tensor, W, b, gamma, beta, eps: float) -> torch.Tensor:
+        """Y = LayerNorm(X W^T + b) under autograd w.r.t. (W, b, gamma, beta): HIP forward and backward, see _FeatProjectFn."""
+        _need_gpu(X2)
+        _no_bag_grad(X2)
+        return _FeatProjectFn.apply(X2, self, W, b, gamma, beta, eps)
+
+    def __call__(self, X2: torch.Tensor, W, b, gamma, beta, eps: float) -> torch.Tensor:
+        lib = nat.load()
+        X2 = _bag2d(X2)
+        self.packed(X2.device, W, b, gamma, beta)
         N = X2.shape[0]
         Y = torch.empty(N, 512, dtype=torch.float32, device=X2.device)
         nat.check(lib.vlsa_feat_project(_p(X2), _dt(X2), N, X2.stride(0), 512, _p(self._prep), float(eps), _p(Y), 512, _stream()),
                   "vlsa_feat_project")
         return Y
+
+
+class _FeatProjectFn(torch.autograd.Function):
+    """Feat_Projecter (Linear + LayerNorm, model/layers.py:65-82) over all rows of a bag under autograd: forward = ONE kernel
+    that also stores the per-row LayerNorm statistics (vlsa_feat_project_train), backward = a row-statistics pass over (dY, Y)
+    and ONE kernel for dW, db, dgamma, dbeta (vlsa_feat_project_backward).  The bag itself carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, X2, fused, W, b, gamma, beta, eps):
+        lib = nat.load()
+        X2 = _bag2d(X2)
+        prep = fused.packed(X2.device, W, b, gamma, beta)
+        N = X2.shape[0]
+        Y = torch.empty(N, 512, dtype=torch.float32, device=X2.device)
+        stats = torch.empty(N, 4, dtype=torch.float32, device=X2.device)
+        nat.check(lib.vlsa_feat_project_train(_p(X2), _dt(X2), N, X2.stride(0), 512, _p(prep), float(eps), _p(Y), 512, _p(stats),
+                                              _stream()), "vlsa_feat_project_train")
+        ctx.save_for_backward(X2, Y, stats, prep)
+        ctx.has = (b is not None, gamma is not None, beta is not None)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = nat.load()
+        X2, Y, stats, prep = ctx.saved_tensors
+        dev, N, s = X2.device, X2.shape[0], _stream()
+        dY = _f32c(dY).reshape(N, 512)
+        nat.check(lib.vlsa_feat_project_rowstats(_p(dY), dY.stride(0), _p(Y), Y.stride(0), N, _p(prep), _p(stats), s),
+                  "vlsa_feat_project_rowstats")
+        tile_rows = int(lib.vlsa_mlp_bwd_tile_rows(_dt(X2)))
+        keep, p_desc, p_dy, p_off, p_ts, n_tiles, _ = _row_tables([X2], tile_rows, extra=[dY])
+        ws = torch.empty(lib.vlsa_mlp_bwd_workspace_bytes(2, n_tiles), dtype=torch.uint8, device=dev)
+        dW = torch.empty(512, 512, dtype=torch.float32, device=dev)
+        dvec = torch.empty(3, 512, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_feat_project_backward(p_desc, p_dy, 1, _dt(X2), _p(prep), p_ts, n_tiles, _p(stats), p_off, _p(ws), _p(dW),
+                                                 _p(dvec), s), "vlsa_feat_project_backward")
+        hb, hg, hbt = ctx.has
+        return None, None, dW, dvec[0] if hb else None, dvec[1] if hg else None, dvec[2] if hbt else None, None
 
 
 def topk_mean(S: torch.Tensor, k: int, out_scale: float = 1.0) -> torch.Tensor:

@@ -35,14 +35,20 @@ class Feat_Projecter(nn.Module):
 
     def forward(self, x):
         lin, norm = self.projecter[0], self.projecter[1]
-        if x.is_cuda and x.dim() in (2, 3) and not self._needs_autograd(x):
-            # inference on the device: ONE fused HIP kernel per bag (vlsa_feat_project), fp32 out for bf16 or fp32 bags
+        bag_grad = torch.is_grad_enabled() and x.requires_grad
+        if x.is_cuda and x.dim() in (2, 3) and not bag_grad:
+            # on the device: ONE fused HIP kernel per bag (vlsa_feat_project), fp32 out for bf16 or fp32 bags; when the
+            # projecter trains, the same kernel also stores the LayerNorm statistics and the backward is HIP as well
+            # (vlsa_feat_project_backward: dW, db, dgamma, dbeta -- the bags themselves carry no gradient)
             from . import functional as VF
             x2 = x.reshape(-1, x.shape[-1])
             if VF.FusedFeatProjecter.supported(x2, lin, norm) and norm.elementwise_affine:
                 if not hasattr(self, "_fused"):
                     self._fused = VF.FusedFeatProjecter()
-                y = self._fused(x2, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps)
+                if self._needs_autograd(x):
+                    y = self._fused.autograd(x2, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps)
+                else:
+                    y = self._fused(x2, lin.weight, lin.bias, norm.weight, norm.bias, norm.eps)
                 return y.reshape(*x.shape[:-1], 512)
         if x.dtype != lin.weight.dtype:
             x = x.to(lin.weight.dtype)          # bf16 bags of the resident arena: the modules compute in the parameters' dtype
