@@ -375,6 +375,11 @@ int vlsa_query_pool_attention(const float* rows, int B, int P, int D, const floa
 
 /* out[n] = x_n . v  -- the N-sized piece of the attention-pooling backward. */
 int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out, void* stream);
+/* The whole backward of pooled = softmax_N(a) @ X w.r.t. the raw scores a (model/layers.py:114-116,145-147 under autograd) in one
+ * pass over X: da[n] = A_n (x_n . dpooled - pooled . dpooled), A_n = exp2(a_n log2(e) - m2[0]) / l[0] ((m2, l): the forward's
+ * log2-domain softmax statistics from vlsa_vlfan_merge).  16-byte aligned rows, D % 8 == 0 (bf16) / % 4 (fp32). */
+int vlsa_scored_pool_backward(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* a, const float* m2,
+                              const float* l, const float* pooled, const float* dpooled, float* da, void* stream);
 
 /*
  * Replaces: logits.topk(min(k, N), 0).values.mean(0) and logits.mean(0) (logit_pooling, model/deepmil.py:16-37)

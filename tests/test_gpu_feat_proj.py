@@ -69,9 +69,15 @@ def test_module_routes_inference_through_the_kernel(dtype):
         m.projecter[1].weight.uniform_(0.5, 1.5)
         m.projecter[1].bias.uniform_(-0.2, 0.2)
     X = cases.make_bag(777, 5300, "clustered").to(dtype).to(dev)
-    y_train = m(X[None])                                           # parameters require grad: torch modules (autograd)
-    assert y_train.requires_grad and not hasattr(m, "_fused")
+    y_train = m(X[None])                                           # parameters require grad: the fused kernel under autograd
+    assert y_train.requires_grad and hasattr(m, "_fused")          # (vlsa_feat_project_train + vlsa_feat_project_backward)
     with torch.no_grad():
-        y_eval = m(X[None])                                        # no grad: the fused kernel
-    assert hasattr(m, "_fused") and y_eval.shape == (1, 777, 512) and y_eval.dtype == torch.float32
-    assert (y_eval - y_train.detach().float()).abs().max().item() < TOL
+        y_eval = m(X[None])                                        # no grad: the same kernel without the statistics output
+    assert y_eval.shape == (1, 777, 512) and y_eval.dtype == torch.float32
+    assert (y_eval - y_train.detach().float()).abs().max().item() == 0
+    y_torch = m.projecter(X.float())                               # the two torch modules on the same parameters
+    assert (y_eval[0] - y_torch.detach()).abs().max().item() < TOL
+    G = torch.randn(777, 512, device=dev)
+    gw = torch.autograd.grad((y_torch * G).sum(), m.projecter[0].weight)[0]
+    (y_train[0] * G).sum().backward()
+    assert (m.projecter[0].weight.grad - gw).abs().max().item() < 2e-3 * gw.abs().max().item()

@@ -113,9 +113,9 @@ def test_cross_attention_dx_matches_autograd(N, P, gated):
     Xd = X.detach().to(dev).requires_grad_(True)
     Qd = Q.detach().to(dev).requires_grad_(True)
     od, _ = VF.vlfan_cross_attention(Xd, Qd, gated=gated)
-    _close(od, out, "out", rtol=0, atol=1e-4 * max(1.0, float(out.abs().max())))
+    _close(od, out, "out", rtol=0, atol=1e-4 * max(1.0, float(out.detach().abs().max())))
     (od * G.to(dev)).sum().backward()
-    _close(Qd.grad, Q.grad, "dQ")
+    _close(Qd.grad, Q.grad, "dQ", atol=2e-5)        # (N = 1: softmax over one patch, dQ is 0 up to rounding)
     # dX: rows with (near-)zero attention get gradients many orders of magnitude below the attended rows'; compare on the scale
     # of the whole tensor and, row by row, on each row's own scale
     _close(Xd.grad, X.grad, "dX")

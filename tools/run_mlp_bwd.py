@@ -1,0 +1,30 @@
+"""A few launches of the backward kernels for rocprofv3 (kernel-trace / PMC): python tools/run_mlp_bwd.py [N] [dtype]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vlsa_amd import functional as F
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16
+dev = "cuda"
+X = torch.randn(n, 512, device=dev).to(dt)
+for gated in (True, False):
+    Wa = (torch.randn(256, 512, device=dev) / 22).requires_grad_(True); ba = (torch.randn(256, device=dev) * 0.05).requires_grad_(True)
+    Wg = (torch.randn(256, 512, device=dev) / 22).requires_grad_(True) if gated else None
+    bg = (torch.randn(256, device=dev) * 0.05).requires_grad_(True) if gated else None
+    w2 = (torch.randn(1, 256, device=dev) / 16).requires_grad_(True); c = torch.randn(1, device=dev).requires_grad_(True)
+    fs = F.FusedAttnScores()
+    G = torch.randn(n, device=dev)
+    for _ in range(12):
+        F.attn_scores_autograd(X, fs, Wa, ba, Wg, bg, w2, c).backward(G)
+W = (torch.randn(512, 512, device=dev) / 22).requires_grad_(True); b = torch.zeros(512, device=dev, requires_grad=True)
+gm = torch.ones(512, device=dev, requires_grad=True); bt = torch.zeros(512, device=dev, requires_grad=True)
+fp = F.FusedFeatProjecter()
+G = torch.randn(n, 512, device=dev)
+for _ in range(12):
+    fp.autograd(X, W, b, gm, bt, 1e-5).backward(G)
+Q = torch.randn(12, 512, device=dev, requires_grad=True)
+Xg = torch.randn(n, 512, device=dev, requires_grad=True)
+G = torch.randn(12, 512, device=dev)
+for _ in range(12):
+    o, _ = F.vlfan_cross_attention(Xg, Q); o.backward(G)
+torch.cuda.synchronize()

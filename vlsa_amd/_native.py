@@ -115,6 +115,8 @@ _SIGNATURES = {
     "vlsa_query_pool_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_rowdot": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "vlsa_scored_pool_backward": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
     "vlsa_topk_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "vlsa_topk_mean_ws": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "vlsa_topk_values": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -304,21 +304,33 @@ __global__ __launch_bounds__(256) void k_colmax_partial_vec(const XT* __restrict
         part[(size_t)b * D + d] = fmaxf(fmaxf(s[d], s[DW + d]), fmaxf(s[2 * DW + d], s[3 * DW + d]));
 }
 
+// With `a` given: the whole backward of the softmax-weighted row sum w.r.t. the raw scores in one pass,
+//     out[n] = A_n (x_n . v - pooled . v),  A_n = exp2(a_n log2(e) - m2) / l      (v = dL/dpooled)
+// instead of the row dots + four [N]-sized torch kernels.
 template <typename XT, int NC>
 __global__ __launch_bounds__(256) void k_rowdot_vec(const XT* __restrict__ X, int64_t N, int64_t ldx, int D,
-                                                     const float* __restrict__ v, float* __restrict__ out) {
+                                                     const float* __restrict__ v, float* __restrict__ out,
+                                                     const float* __restrict__ a, const float* __restrict__ m2,
+                                                     const float* __restrict__ l, const float* __restrict__ pooled) {
     constexpr int VEC = 16 / (int)sizeof(XT);
     constexpr int U = 4;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
     float vv[NC * VEC];
+    float delta = 0.f, m2v = 0.f, rl = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int d = (64 * c + lane) * VEC + e;
             vv[c * VEC + e] = d < D ? v[d] : 0.f;
+            if (a != nullptr && d < D) delta += pooled[d] * vv[c * VEC + e];
         }
+    if (a != nullptr) {
+        delta = wave_sum(delta);
+        m2v = m2[0];
+        rl = 1.f / l[0];
+    }
     for (int64_t n0 = wave * U; n0 < N; n0 += nw * U) {
         u32x4_p raw[U][NC];
 #pragma unroll
@@ -338,7 +350,10 @@ __global__ __launch_bounds__(256) void k_rowdot_vec(const XT* __restrict__ X, in
                 for (int e = 0; e < VEC; ++e) s += x[e] * vv[c * VEC + e];
             }
             s = wave_sum(s);
-            if (lane == 0 && n0 + u < N) out[n0 + u] = s;
+            if (lane == 0 && n0 + u < N) {
+                if (a != nullptr) s = fast_exp2(a[n0 + u] * kLog2e - m2v) * rl * (s - delta);
+                out[n0 + u] = s;
+            }
         }
     }
 }
@@ -798,8 +813,8 @@ extern "C" int vlsa_query_pool_attention(const float* rows, int B, int P, int D,
     return st();
 }
 
-extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out,
-                           void* stream) {
+static int rowdot_impl(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out, const float* a,
+                       const float* m2, const float* l, const float* pooled, void* stream) {
     if (!X || !v || !out || N < 1 || D < 1 || ldx < D) return VLSA_EINVAL;
     int64_t nb = (N + 3) / 4;
     if (nb > 2048) nb = 2048;
@@ -810,17 +825,32 @@ extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, i
         const int NC = (D + 64 * VEC - 1) / (64 * VEC);
         int64_t nbv = (N + 15) / 16;
         if (nbv > 2048) nbv = 2048;
-#define VLSA_RD(XT, NCV) hipLaunchKernelGGL((k_rowdot_vec<XT, NCV>), dim3((unsigned)nbv), dim3(256), 0, s, (const XT*)X, N, ldx, D, v, out)
+#define VLSA_RD(XT, NCV) hipLaunchKernelGGL((k_rowdot_vec<XT, NCV>), dim3((unsigned)nbv), dim3(256), 0, s, (const XT*)X, N, ldx, D, v, out, a, m2, l, pooled)
         if (x_dtype == VLSA_DT_BF16) { if (NC == 1) VLSA_RD(__bf16, 1); else VLSA_RD(__bf16, 2); }
         else { if (NC == 1) VLSA_RD(float, 1); else if (NC == 2) VLSA_RD(float, 2); else if (NC == 3) VLSA_RD(float, 3); else VLSA_RD(float, 4); }
 #undef VLSA_RD
         return st();
     }
+    if (a != nullptr) return VLSA_EUNSUPPORTED;
     if (x_dtype == VLSA_DT_F32)
         hipLaunchKernelGGL(k_rowdot<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)X, N, ldx, D, v, out);
     else
         hipLaunchKernelGGL(k_rowdot<__bf16>, dim3((unsigned)nb), dim3(256), 0, s, (const __bf16*)X, N, ldx, D, v, out);
     return st();
+}
+
+extern "C" int vlsa_rowdot(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* v, float* out,
+                           void* stream) {
+    return rowdot_impl(X, x_dtype, N, ldx, D, v, out, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// Backward of pooled = softmax_N(a) @ X w.r.t. the raw scores (model/layers.py:114-116,145-147 under autograd), one pass over X:
+// da[n] = A_n (x_n . dpooled - pooled . dpooled), A_n = exp2(a_n log2(e) - m2[0]) / l[0] with the forward's (m2, l) (log2 domain).
+// 16-byte aligned rows, D % 8 == 0 (bf16) / % 4 (fp32), D <= 1024.
+extern "C" int vlsa_scored_pool_backward(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* a, const float* m2,
+                                         const float* l, const float* pooled, const float* dpooled, float* da, void* stream) {
+    if (!a || !m2 || !l || !pooled) return VLSA_EINVAL;
+    return rowdot_impl(X, x_dtype, N, ldx, D, dpooled, da, a, m2, l, pooled, stream);
 }
 
 extern "C" int vlsa_topk_chunks(int64_t N) {

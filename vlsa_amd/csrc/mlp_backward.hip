@@ -193,20 +193,6 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
             stage_load(cur);
             stage_store();
             __syncthreads();
-            // per-row inputs of this lane's rows (C layout: rows 16 rt + 4 g + r)
-            f32x4 rv[RT];             // scores: da of the 4 rows
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                if constexpr (MODE != kLN) {
-                    const int row = 16 * rt + 4 * g;
-                    if (row + 3 < cur.nrows) {
-                        rv[rt] = f32x4{cur.rv[row], cur.rv[row + 1], cur.rv[row + 2], cur.rv[row + 3]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rv[rt][r] = (row + r < cur.nrows) ? cur.rv[row + r] : 0.f;
-                    }
-                }
-            }
             // ---- phase 1: recompute the pre-activations of this wave's 16 units for the tile's rows ----------------------
             f32x4 acch[RT];
 #pragma unroll
@@ -236,13 +222,36 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
                             acch[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[rt], Bc[0], acch[rt], 0, 0, 0);
                     }
                 };
+                // weight fragments come from L2 (~600+ cycles) while a k step is only 8-12 MFMAs: three steps in flight.  The
+                // loop is rolled on purpose: unrolled, the scheduler hoists all 32 weight loads to the top.
+                bf16x8 B2[2], B3[2];
                 load_b(0, B0);
+                load_b(1, B1);
+                load_b(2, B2);
 #pragma unroll 1
-                for (int ks = 0; ks < 16; ks += 2) {      // rolled on purpose: unrolled, the scheduler hoists all 32 weight loads
-                    load_b(ks + 1, B1);
+                for (int ks = 0; ks < 16; ks += 4) {
+                    load_b(ks + 3, B3);
                     kstep(ks, B0);
-                    if (ks + 2 < 16) load_b(ks + 2, B0);
+                    if (ks + 4 < 16) load_b(ks + 4, B0);
                     kstep(ks + 1, B1);
+                    if (ks + 4 < 16) load_b(ks + 5, B1);
+                    kstep(ks + 2, B2);
+                    if (ks + 4 < 16) load_b(ks + 6, B2);
+                    kstep(ks + 3, B3);
+                }
+            }
+            // per-row inputs of this lane's rows (C layout: rows 16 rt + 4 g + r)
+            f32x4 rv[RT];             // scores: da of the 4 rows
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (MODE != kLN) {
+                    const int row = 16 * rt + 4 * g;
+                    if (row + 3 < cur.nrows) {
+                        rv[rt] = f32x4{cur.rv[row], cur.rv[row + 1], cur.rv[row + 2], cur.rv[row + 3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rv[rt][r] = (row + r < cur.nrows) ? cur.rv[row + r] : 0.f;
+                    }
                 }
             }
             // ---- phase 2a (scores): activations in place of the accumulators; the gated pair exchanges them through LDS --------
@@ -351,13 +360,23 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
     }
 }
 
-// out[i] = sum_c part[c][i], fixed order; float4 per thread
+// out[i] = sum_c part[c][i] in a fixed order: 256 threads = 32 float4 columns x 8 partial groups (thread group q sums the
+// partials c = q, q + 8, ...; the 8 group sums are added through LDS in the order of q) -- 8 loads in flight per column
+// instead of one dependent chain over all C partials
 __global__ __launch_bounds__(256) void k_mb_reduce(const float* __restrict__ part, int C, long long total, float* __restrict__ out) {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= total) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(part + i);
-    for (int c = 1; c < C; ++c) s += *reinterpret_cast<const f32x4*>(part + (size_t)c * total + i);
-    *reinterpret_cast<f32x4*>(out + i) = s;
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long long i = ((long long)blockIdx.x * 32 + col) * 4;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < total)
+        for (int c = q; c < C; c += 8) s += *reinterpret_cast<const f32x4*>(part + (size_t)c * total + i);
+    red[q][col] = s;
+    __syncthreads();
+    if (q == 0 && i < total) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += red[k][col];
+        *reinterpret_cast<f32x4*>(out + i) = s;
+    }
 }
 
 // Per-row LayerNorm-backward scalars of the projecter (one wave per row): c1 = mean_o(dy gamma), c2 = mean_o(dy (y - beta))
@@ -464,8 +483,8 @@ extern "C" int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtyp
     else rc = f32 ? launch<mb::kTanh, true>(a, nsl, st) : launch<mb::kTanh, false>(a, nsl, st);
     if (rc != VLSA_OK) return rc;
     const long long tw = (long long)U * 512, tv = 3 * 512;
-    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 255) / 256)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
-    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 255) / 256)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 31) / 32)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 31) / 32)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
@@ -512,7 +531,7 @@ extern "C" int vlsa_feat_project_backward(const void* bag_desc, const void* dy_d
     const int rc = x_dtype == VLSA_DT_F32 ? launch<mb::kLN, true>(a, 4, st) : launch<mb::kLN, false>(a, 4, st);
     if (rc != VLSA_OK) return rc;
     const long long tw = 512ll * 512, tv = 3 * 512;
-    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 255) / 256)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
-    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 255) / 256)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tw / 4 + 31) / 32)), dim3(256), 0, st, a.part_w, a.C, tw, dW);
+    hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 31) / 32)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

@@ -665,11 +665,17 @@ class _ScoredPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpooled):
         X2, a, m2, l, out = ctx.saved_tensors
-        dp = _f32c(dpooled)
-        xd = rowdot(X2, dp)                                    # N-sized piece in HIP
-        A = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]  # [N] vector math
-        da = A * (xd - (out[0] * dp).sum())
-        return None, da
+        dp = _f32c(dpooled).reshape(-1)
+        N, D = X2.shape
+        da = torch.empty(N, dtype=torch.float32, device=X2.device)
+        if D % (8 if X2.dtype == torch.bfloat16 else 4) == 0 and D <= nat.MAX_D:
+            # da_n = A_n (x_n . dp - pooled . dp) in ONE pass over X (was: row dots + four [N]-sized torch kernels)
+            nat.check(nat.load().vlsa_scored_pool_backward(_p(X2), _dt(X2), N, X2.stride(0), D, _p(a), _p(m2), _p(l), _p(out), _p(dp),
+                                                           _p(da), _stream()), "vlsa_scored_pool_backward")
+            return None, da
+        xd = rowdot(X2, dp)                                    # odd feature widths: row dots in HIP, [N] vector math in torch
+        A = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]
+        return None, A * (xd - (out[0] * dp).sum())
 
 
 def scored_pool(X: torch.Tensor, scores: Optional[torch.Tensor]) -> torch.Tensor:
