@@ -535,7 +535,14 @@ int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);
 int vlsa_mlp_bwd_tile_rows(int x_dtype);
 size_t vlsa_mlp_bwd_workspace_bytes(int mode, int n_tiles);   /* mode: 0 attention, 1 gated attention, 2 Feat_Projecter */
 int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
-                              int n_tiles, const float* da, const int64_t* a_off, void* ws, float* dW, float* dvec, void* stream);
+                              int n_tiles, const float* da, const int64_t* a_off, void* ws, float* dW, float* dvec, float drop_p,
+                              unsigned int seed, void* stream);
+/* Training-mode forward of the gated scores: nn.Dropout(drop_p) behind tanh and behind sigmoid (model/layers.py:94,99) with a
+ * counter-based mask generator keyed on (seed, row, hidden unit) that vlsa_attn_scores_backward(drop_p, seed) re-evaluates; the
+ * masks are Bernoulli(1 - drop_p) bits of a hash, not torch's Philox stream (bit parity with the reference's dropout is
+ * impossible either way: SURVEY.md 7.4-8).  drop_p = 0 or gated = 0: identical to vlsa_gated_scores. */
+int vlsa_gated_scores_train(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                            float drop_p, unsigned int seed, void* stream);
 int vlsa_feat_project_train(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, float eps, float* Y,
                             int64_t ldy, float* stats, void* stream);
 int vlsa_feat_project_rowstats(const float* dy, int64_t lddy, const float* y, int64_t ldy, int64_t N, const void* prep, float* stats,

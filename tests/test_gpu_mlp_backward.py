@@ -145,3 +145,71 @@ def test_cross_attention_dx_for_a_batch_of_bags():
             assert bd[i].grad is None
         else:
             _close(bd[i].grad, x.grad, f"dX[{i}]")
+
+
+def _dropout_keep(seed, rows, units, p):
+    """The kernels' counter-based mask (vlsa_common.h: dropout_bits) re-stated with torch integer ops: [rows, units] bool."""
+    M = 0xFFFFFFFF
+    r = torch.arange(rows, dtype=torch.int64)[:, None]
+    u = torch.as_tensor(units, dtype=torch.int64)[None, :]
+    h = (seed ^ ((r * 0x9E3779B1) & M) ^ ((u * 0x85EBCA6B) & M)) & M
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M
+    h = h ^ (h >> 16)
+    thr = max(1, int(p * 4294967296.0))
+    return h >= thr
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gated_scores_training_dropout_forward_and_backward(dtype):
+    """Gated_Attention_Pooling in train mode (nn.Dropout behind tanh and sigmoid, model/layers.py:94,99): the fused kernels with
+    their own counter-based masks against torch autograd through the same arithmetic with the SAME masks."""
+    from vlsa_amd import functional as VF
+    N, p, seed = 3000, 0.25, 123457
+    X = cases.make_bag(N, 8100, "clustered", dtype=dtype)
+    pp = {k: v.clone().requires_grad_(True) for k, v in cases.make_pool_params("gated_attention", 8101).items()}
+    G = torch.randn(N, generator=cases.gen(8102))
+    ka = _dropout_keep(seed, N, range(256), p).float() / (1 - p)
+    kg = _dropout_keep(seed, N, range(256, 512), p).float() / (1 - p)
+    assert abs(float((ka > 0).float().mean()) - (1 - p)) < 0.01 and abs(float((kg > 0).float().mean()) - (1 - p)) < 0.01
+    emb = torch.tanh(X @ pp["wa"].t() + pp["ba"]) * ka
+    scr = torch.sigmoid(X @ pp["wg"].t() + pp["bg"]) * kg
+    raw = ((emb * scr) @ pp["w2"].t() + pp["b2"]).squeeze(-1)
+    (raw * G).sum().backward()
+    dev = torch.device("cuda")
+    gp = {k: v.detach().to(dev).requires_grad_(True) for k, v in pp.items()}
+    a = VF.attn_scores_autograd(X.to(dev).to(dtype), VF.FusedAttnScores(), gp["wa"], gp["ba"], gp["wg"], gp["bg"], gp["w2"], gp["b2"],
+                                drop_p=p, seed=seed)
+    _close(a, raw, "scores under dropout", rtol=0, atol=2e-4)
+    (a * G.to(dev)).sum().backward()
+    for k in pp:
+        _close(gp[k].grad, pp[k].grad, f"d{k}")
+
+
+def test_deepmil_train_mode_runs_the_fused_kernels_with_dropout():
+    """DeepMIL(pooling='gated_attention', drop_rate=0.25).train(): the reference's default training configuration of this encoder.
+    Two forward passes draw different masks (torch's CPU generator seeds them), the mean over many draws approaches the eval-mode
+    scores' pooled vector, and gradients flow to the pooling parameters through the HIP backward."""
+    from vlsa_amd.deepmil import DeepMIL
+    torch.manual_seed(11)
+    enc = DeepMIL(dim_in=512, dim_hid=256, num_cls=512, use_feat_proj=False, drop_rate=0.25, pooling="gated_attention",
+                  pred_head="Adapter").cuda().train()
+    X = cases.make_bag(2000, 8200, "clustered").cuda()[None]
+    torch.manual_seed(5)
+    o1, o2 = enc(X), enc(X)
+    assert hasattr(enc, "_fused_scores") and o1.requires_grad
+    assert float((o1 - o2).detach().abs().max()) > 0                       # different dropout draws
+    o1.sum().backward()
+    assert enc.sigma.fc1[0].weight.grad is not None and float(enc.sigma.fc1[0].weight.grad.abs().max()) > 0
+    torch.manual_seed(5)
+    r1 = enc(X)
+    assert float((r1 - o1).detach().abs().max()) == 0                      # torch.manual_seed governs the masks
+    enc.eval()
+    with torch.no_grad():
+        ev = enc(X)
+    enc.train()
+    with torch.no_grad():
+        mean = torch.stack([enc(X) for _ in range(48)]).mean(0)
+    assert float((mean - ev).abs().max()) < 0.15 * float(ev.abs().max())

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 _LIB_PATH = os.environ.get("VLSA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib",
                                                              "libvlsa_hip.so")
@@ -131,7 +131,8 @@ _SIGNATURES = {
     "vlsa_mlp_bwd_tile_rows": (c_int, [c_int]),
     "vlsa_mlp_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vlsa_attn_scores_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
+    "vlsa_gated_scores_train": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_float, c_uint32, c_void_p]),
     "vlsa_feat_project_train": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
     "vlsa_feat_project_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "vlsa_feat_project_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

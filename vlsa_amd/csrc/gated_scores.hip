@@ -140,6 +140,10 @@ struct GsBatch {
     const int* tile_start;      // [B + 1], tile_start[0] = 0
     const long long* a_off;     // [B] offset (floats) of bag b's scores in a_out
     int B;                      // <= 64
+    // training-mode dropout of Gated_Attention_Pooling (nn.Dropout behind tanh and behind sigmoid, model/layers.py:94,99):
+    // drop_thr = p * 2^32 (0: off), drop_scale = 1 / (1 - p); see dropout_bits()
+    unsigned int drop_thr, drop_seed;
+    float drop_scale;
 };
 
 template <bool GATED, bool FULL, bool XF32, int RT = 16>
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     const long long row0 = (long long)tile * rows_per_tile;
     const int nrows = (int)((N - row0) < rows_per_tile ? (N - row0) : rows_per_tile);
     const GatedPrepLayout L(GATED ? 1 : 0);
+    const unsigned int rid0 = (unsigned int)row0;   // row index inside this bag's score array (dropout counter)
 
     // plain (compiler-tracked) loads only: weight fragments one step ahead (double-buffered registers; a 4-deep ring measured
     // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
@@ -318,7 +323,13 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
         if (rt < nrt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = GATED ? gate_act(acc[rt][0][r], acc[rt][NB - 1][r]) : tanh_act(acc[rt][0][r]);
+            float e = GATED ? gate_act(acc[rt][0][r], acc[rt][NB - 1][r]) : tanh_act(acc[rt][0][r]);
+            if (GATED && bt.drop_thr != 0u) {      // uniform: training-mode dropout on both branches
+                const unsigned int row = rid0 + 16 * rt + 4 * g + r;
+                const bool ka = dropout_bits(bt.drop_seed, row, (unsigned int)h) >= bt.drop_thr;
+                const bool kg = dropout_bits(bt.drop_seed, row, (unsigned int)h + 256u) >= bt.drop_thr;
+                e = (ka && kg) ? e * bt.drop_scale * bt.drop_scale : 0.f;
+            }
             const float v = row16_sum(e * w2v);
             if (i16 == 0) scr[w * kRows + 16 * rt + 4 * g + r] = v;
         }
@@ -347,8 +358,8 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
-extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
-                                 void* stream) {
+static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                             float drop_p, unsigned int seed, void* stream) {
     if (!X || !prep || !a || N < 1 || ldx < D) return VLSA_EINVAL;
     if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
     const bool f32 = x_dtype == VLSA_DT_F32;
@@ -379,11 +390,19 @@ extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0})
+    GsBatch dropb{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f};
+    if (gated && drop_p > 0.f) {
+        if (!(drop_p < 1.f)) return VLSA_EINVAL;
+        dropb.drop_thr = (unsigned int)((double)drop_p * 4294967296.0);
+        if (dropb.drop_thr == 0u) dropb.drop_thr = 1u;
+        dropb.drop_seed = seed;
+        dropb.drop_scale = 1.f / (1.f - drop_p);
+    }
+#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb)
     if (f32) {
         if (gated) {
-            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0});
-            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, GsBatch{nullptr, nullptr, nullptr, 0});
+            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb);
+            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb);
         } else { if (full) VLSA_GS(false, true, true); else VLSA_GS(false, false, true); }
     } else {
         if (gated) { if (full) VLSA_GS(true, true, false); else VLSA_GS(true, false, false); }
@@ -391,6 +410,19 @@ extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t 
     }
 #undef VLSA_GS
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+extern "C" int vlsa_gated_scores(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                                 void* stream) {
+    return gated_scores_impl(X, x_dtype, N, ldx, D, prep, gated, a, 0.f, 0u, stream);
+}
+
+// Training-mode forward of Gated_Attention_Pooling's scores: dropout with probability drop_p behind tanh and behind sigmoid
+// (model/layers.py:94,99), masks from the counter-based generator dropout_bits(seed, row, unit) that vlsa_attn_scores_backward
+// re-evaluates.  drop_p = 0 (or gated = 0: Attention_Pooling has no dropout) is vlsa_gated_scores.
+extern "C" int vlsa_gated_scores_train(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                                       float drop_p, unsigned int seed, void* stream) {
+    return gated_scores_impl(X, x_dtype, N, ldx, D, prep, gated, a, drop_p, seed, stream);
 }
 
 // B bags in ONE launch.  bag_desc: device table of vlsa_bag_desc {X, N, ldx}; tile_start [B + 1] (device, int32): first row tile
@@ -420,7 +452,7 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const bool full = rows_per_tile == max_rows;
     const unsigned int tiles = (unsigned int)n_tiles * gs::kHalves;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B};
+    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
     if (f32) {
         if (gated) { if (full) VLSA_GSB(true, true, true, 8); else VLSA_GSB(true, false, true, 8); }

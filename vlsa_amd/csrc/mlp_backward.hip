@@ -66,6 +66,9 @@ struct MbArgs {
     float* part_w;              // [C][U][512] partial dW, U = rows of the stacked weight matrix
     float* part_v;              // [C][3][512] partial vectors
     int B, n_tiles, C;
+    // gated scores: the training-mode dropout of the forward (vlsa_gated_scores_train), re-evaluated here; drop_thr = 0: off
+    unsigned int drop_thr, drop_seed;
+    float drop_scale;
 };
 
 __device__ __forceinline__ int mb_swz(int row, int byte_off) { return row * 256 + (byte_off ^ ((row & 7) << 5)); }
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;          // scores: db, dw2, dc;  projecter: db, dgamma, dbeta
 
     // ---- tile lookup + register staging of a tile's rows -------------------------------------------------------------------
-    struct Tile { const unsigned char* x; const float* dy; const float* rv; long long ldx, lddy; int nrows; };
+    struct Tile { const unsigned char* x; const float* dy; const float* rv; long long ldx, lddy; int nrows; unsigned int rid; };
     auto find = [&](int t) -> Tile {
         const int ts = lane < a.B ? a.tile_start[lane] : 0x7fffffff;
         const int b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ts <= t)) - 1;
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
         const long long row0 = (long long)(t - a.tile_start[b]) * ROWS;
         Tile r;
         r.ldx = bag.ldx;
+        r.rid = (unsigned int)row0;          // row index inside the bag (the dropout counter of the forward)
         r.nrows = (int)((bag.N - row0) < ROWS ? (bag.N - row0) : ROWS);
         r.x = static_cast<const unsigned char*>(bag.X) + row0 * bag.ldx * (XF32 ? 4 : 2);
         r.rv = a.rowvec + (a.row_off[b] + row0) * (MODE == kLN ? 4 : 1);
@@ -222,22 +226,14 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
                             acch[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[rt], Bc[0], acch[rt], 0, 0, 0);
                     }
                 };
-                // weight fragments come from L2 (~600+ cycles) while a k step is only 8-12 MFMAs: three steps in flight.  The
-                // loop is rolled on purpose: unrolled, the scheduler hoists all 32 weight loads to the top.
-                bf16x8 B2[2], B3[2];
+                // (a three-deep ring measured no faster -- 146 vs 144 us per 50k gated bag -- and spilled in the projecter variant)
                 load_b(0, B0);
-                load_b(1, B1);
-                load_b(2, B2);
 #pragma unroll 1
-                for (int ks = 0; ks < 16; ks += 4) {
-                    load_b(ks + 3, B3);
+                for (int ks = 0; ks < 16; ks += 2) {      // rolled on purpose: unrolled, the scheduler hoists all 32 weight loads
+                    load_b(ks + 1, B1);
                     kstep(ks, B0);
-                    if (ks + 4 < 16) load_b(ks + 4, B0);
+                    if (ks + 2 < 16) load_b(ks + 2, B0);
                     kstep(ks + 1, B1);
-                    if (ks + 4 < 16) load_b(ks + 5, B1);
-                    kstep(ks + 2, B2);
-                    if (ks + 4 < 16) load_b(ks + 6, B2);
-                    kstep(ks + 3, B3);
                 }
             }
             // per-row inputs of this lane's rows (C layout: rows 16 rt + 4 g + r)
@@ -304,10 +300,17 @@ __global__ __launch_bounds__(512) void k_mlp_backward(const MbArgs a) {
                         } else {
                             const float m = acch[rt][r], dav = rv[rt][r];
                             const float dfac = br == 0 ? (1.f - m * m) : m * (1.f - m);     // tanh' / sigmoid'
-                            d = dav * hv * dfac * other[r];
+                            float keep = 1.f;
+                            if (MODE == kGated && a.drop_thr != 0u) {      // uniform: the forward's dropout masks of both branches
+                                const unsigned int row = cur.rid + 16 * rt + 4 * g + r, hu = 16 * unit + i16;
+                                const bool ka = dropout_bits(a.drop_seed, row, hu) >= a.drop_thr;
+                                const bool kg = dropout_bits(a.drop_seed, row, hu + 256u) >= a.drop_thr;
+                                keep = (ka && kg) ? a.drop_scale * a.drop_scale : 0.f;
+                            }
+                            d = dav * hv * dfac * other[r] * keep;
                             v0 += d;
                             if (br == 0) {
-                                v1 += dav * m * other[r];
+                                v1 += dav * m * other[r] * keep;
                                 v2 += dav;
                             }
                         }
@@ -453,10 +456,11 @@ extern "C" size_t vlsa_mlp_bwd_workspace_bytes(int mode, int n_tiles) {
 // Backward of the (gated) attention scores of B bags.  bag_desc: device table of vlsa_bag_desc {X, N, ldx}; tile_start [B + 1]
 // (device, int32) in tiles of vlsa_mlp_bwd_tile_rows(x_dtype) rows; da: dL/da of all bags' rows, bag b at da + a_off[b] (device
 // int64 offsets); prep: the block of vlsa_prepare_gated_weights.  Outputs: dW [gated ? 2 : 1][256][512] (dWa, dWg),
-// dvec [3][512]: row 0 = (dba [256] | dbg [256]), row 1 = dw2 [256], dvec[2][0] = dc.
+// dvec [3][512]: row 0 = (dba [256] | dbg [256]), row 1 = dw2 [256], dvec[2][0] = dc.  drop_p / seed: the dropout the forward
+// ran with (vlsa_gated_scores_train; 0: none).
 extern "C" int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated,
                                          const int* tile_start, int n_tiles, const float* da, const int64_t* a_off, void* ws,
-                                         float* dW, float* dvec, void* stream) {
+                                         float* dW, float* dvec, float drop_p, unsigned int seed, void* stream) {
     if (!bag_desc || !prep || !tile_start || !da || !a_off || !ws || !dW || !dvec || B < 1 || B > 64 || n_tiles < 1) return VLSA_EINVAL;
     if (D != mb::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
     const int mode = gated ? mb::kGated : mb::kTanh, nsl = gated ? 4 : 2, U = gated ? 512 : 256;
@@ -476,6 +480,15 @@ extern "C" int vlsa_attn_scores_backward(const void* bag_desc, int B, int x_dtyp
     a.C = chunks_for(n_tiles, nsl);
     a.part_w = static_cast<float*>(ws);
     a.part_v = a.part_w + (size_t)a.C * U * 512;
+    a.drop_thr = 0u;
+    a.drop_scale = 1.f;
+    if (gated && drop_p > 0.f) {     // same conversion as vlsa_gated_scores_train
+        if (!(drop_p < 1.f)) return VLSA_EINVAL;
+        a.drop_thr = (unsigned int)((double)drop_p * 4294967296.0);
+        if (a.drop_thr == 0u) a.drop_thr = 1u;
+        a.drop_seed = seed;
+        a.drop_scale = 1.f / (1.f - drop_p);
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool f32 = x_dtype == VLSA_DT_F32;

@@ -46,6 +46,19 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Counter-based dropout mask of the fused attention-score kernels (forward and backward recompute the same bits):
+// keep(seed, row, unit) = mix32(seed ^ row * 0x9E3779B1 ^ unit * 0x85EBCA6B) >= thr, thr = p * 2^32 (murmur3 finaliser).
+// `unit` = hidden unit + 256 * branch; `row` = the row's index in the launch's score array.
+__host__ __device__ __forceinline__ unsigned int dropout_bits(unsigned int seed, unsigned int row, unsigned int unit) {
+    unsigned int h = seed ^ (row * 0x9E3779B1u) ^ (unit * 0x85EBCA6Bu);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
 __device__ __forceinline__ float load_as_float(const float* p) { return *p; }
 __device__ __forceinline__ float load_as_float(const __bf16* p) { return (float)*p; }
 

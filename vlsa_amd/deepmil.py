@@ -316,32 +316,26 @@ class DeepMIL(nn.Module):
         return torch.stack([VF.scored_pool(x, self._attention_scores(x)) for x in flat])
 
     def _attention_scores(self, X2):
-        """raw scores a[N] of the pooling module on all patches: hidden projections by rocBLAS, the rest in HIP when
-        no autograd graph is needed (else torch elementwise ops so the pooling parameters get gradients)."""
+        """raw scores a[N] of the pooling module on all patches.  512 -> 256 hidden (the reference's sizes): ONE fused MFMA kernel,
+        hidden activations in registers -- inference, and under autograd as well (HIP backward that recomputes them tile by tile,
+        vlsa_attn_scores_backward), the gated module's training-mode dropout included (counter-based masks inside both kernels).
+        Other widths, or a bag that itself carries a gradient: library GEMMs for the hidden projections + torch / HIP elementwise."""
         sg = self.sigma
-        need_grad = torch.is_grad_enabled() and (X2.requires_grad or any(p.requires_grad for p in sg.parameters()))
         gated = isinstance(sg, Gated_Attention_Pooling)
         lin_a = sg.fc1[0] if gated else sg.attention[0]
-        if (not need_grad and not (gated and sg.training and sg.fc1[2].p > 0)
+        grad_mode = torch.is_grad_enabled()
+        bag_grad = grad_mode and X2.requires_grad
+        need_grad = bag_grad or (grad_mode and any(p.requires_grad for p in sg.parameters()))
+        drop_p = float(sg.fc1[2].p) if (gated and sg.training and sg.fc1[2].p > 0) else 0.0
+        if (not bag_grad and (not gated or sg.fc1[2].p == sg.score[2].p)
                 and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
-            # bf16 bag, 512 -> 256 hidden: the fused MFMA kernel (hidden activations stay in registers)
             if not hasattr(self, "_fused_scores"):
                 self._fused_scores = VF.FusedAttnScores()
-            if gated:
-                return self._fused_scores(X2, lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias,
-                                          sg.fc2.weight, sg.fc2.bias)
-            return self._fused_scores(X2, lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias)
-        if (need_grad and not X2.requires_grad and not (gated and sg.training and sg.fc1[2].p > 0)
-                and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
-            # the pooling module trains, the bag carries no gradient: fused MFMA forward + the HIP backward that recomputes the
-            # hidden activations tile by tile (vlsa_attn_scores_backward) -- no [N, 256] activations, no library GEMM
-            if not hasattr(self, "_fused_scores"):
-                self._fused_scores = VF.FusedAttnScores()
-            if gated:
-                return VF.attn_scores_autograd(X2, self._fused_scores, lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias,
-                                               sg.fc2.weight, sg.fc2.bias)
-            return VF.attn_scores_autograd(X2, self._fused_scores, lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight,
-                                           sg.attention[2].bias)
+            w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
+                 (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
+            if need_grad or drop_p > 0:
+                return VF.attn_scores_autograd(X2, self._fused_scores, *w, drop_p=drop_p)
+            return self._fused_scores(X2, *w)
         Xf = X2 if X2.dtype == torch.float32 else X2.float()
         if isinstance(sg, Attention_Pooling):
             lin1, lin2 = sg.attention[0], sg.attention[2]
@@ -351,7 +345,7 @@ class DeepMIL(nn.Module):
             return VF.attn_scores(H, None, lin1.bias, None, lin2.weight, lin2.bias)
         la, lg, l2 = sg.fc1[0], sg.score[0], sg.fc2
         H, Hg = Xf @ la.weight.t(), Xf @ lg.weight.t()
-        if need_grad or (sg.training and sg.fc1[2].p > 0):
+        if need_grad or drop_p > 0:
             e = sg.fc1[2](torch.tanh(H + la.bias)) * sg.score[2](torch.sigmoid(Hg + lg.bias))
             return (e @ l2.weight.t() + l2.bias).squeeze(-1)
         return VF.attn_scores(H, Hg, la.bias, lg.bias, l2.weight, l2.bias)

@@ -814,12 +814,16 @@ class FusedAttnScores:
         self._keep = (meta_d, bags)                # the kernels read these
         return pooled, a, offs
 
-    def __call__(self, X2, Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
+    def __call__(self, X2, Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
         lib = nat.load()
         gated = Wg is not None
         self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
         N = X2.shape[0]
         a = torch.empty(N, dtype=torch.float32, device=X2.device)
+        if drop_p and gated:      # training-mode dropout of the gated module, counter-based masks (vlsa_gated_scores_train)
+            nat.check(lib.vlsa_gated_scores_train(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(self._prep), 1, _p(a), float(drop_p),
+                                                  int(seed) & 0xFFFFFFFF, _stream()), "vlsa_gated_scores_train")
+            return a
         nat.check(lib.vlsa_gated_scores(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(self._prep), int(gated), _p(a),
                                         _stream()), "vlsa_gated_scores")
         return a
@@ -860,11 +864,12 @@ class _AttnScoresFn(torch.autograd.Function):
     the same kernel) -- model/layers.py:103-122,137-153 under autograd without the [N, 256] activations in memory."""
 
     @staticmethod
-    def forward(ctx, X2, fused, Wa, ba, Wg, bg, w2, c):
-        a = fused(X2, Wa, ba, Wg, bg, w2, c)
+    def forward(ctx, X2, fused, Wa, ba, Wg, bg, w2, c, drop_p, seed):
+        a = fused(X2, Wa, ba, Wg, bg, w2, c, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(X2, fused._prep)       # the packed weights of THIS parameter version
         ctx.gated = Wg is not None
         ctx.shapes = (w2.shape, c.shape)
+        ctx.drop = (float(drop_p), int(seed))
         return a
 
     @staticmethod
@@ -880,17 +885,22 @@ class _AttnScoresFn(torch.autograd.Function):
         dW = torch.empty(2 if gated else 1, 256, 512, dtype=torch.float32, device=dev)
         dvec = torch.empty(3, 512, dtype=torch.float32, device=dev)
         nat.check(lib.vlsa_attn_scores_backward(p_desc, 1, _dt(X2), 512, _p(prep), int(gated), p_ts, n_tiles, _p(da), p_off, _p(ws),
-                                                _p(dW), _p(dvec), _stream()), "vlsa_attn_scores_backward")
+                                                _p(dW), _p(dvec), ctx.drop[0], ctx.drop[1], _stream()), "vlsa_attn_scores_backward")
         w2_shape, c_shape = ctx.shapes
         return (None, None, dW[0], dvec[0, :256], dW[1] if gated else None, dvec[0, 256:] if gated else None,
-                dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape))
+                dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape), None, None)
 
 
-def attn_scores_autograd(X2: torch.Tensor, fused: "FusedAttnScores", Wa, ba, Wg, bg, w2, c) -> torch.Tensor:
-    """a [N] of (Gated_)Attention_Pooling over a bag, differentiable w.r.t. the module's parameters (not the bag)."""
+def attn_scores_autograd(X2: torch.Tensor, fused: "FusedAttnScores", Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0,
+                         seed: Optional[int] = None) -> torch.Tensor:
+    """a [N] of (Gated_)Attention_Pooling over a bag, differentiable w.r.t. the module's parameters (not the bag).
+    drop_p > 0 (gated only): the module's training-mode dropout behind tanh and sigmoid (model/layers.py:94,99), masks from a
+    counter-based generator keyed on ``seed`` (None: drawn from torch's CPU generator, so ``torch.manual_seed`` governs it)."""
     _need_gpu(X2)
     _no_bag_grad(X2)
-    return _AttnScoresFn.apply(X2, fused, Wa, ba, Wg, bg, w2, c)
+    if drop_p and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _AttnScoresFn.apply(X2, fused, Wa, ba, Wg, bg, w2, c, float(drop_p or 0.0), int(seed or 0))
 
 
 def mean_pool_bags(bags) -> torch.Tensor:
