@@ -550,6 +550,15 @@ int vlsa_feat_project_rowstats(const float* dy, int64_t lddy, const float* y, in
 int vlsa_feat_project_backward(const void* bag_desc, const void* dy_desc, int B, int x_dtype, const void* prep, const int* tile_start,
                                int n_tiles, const float* stats, const int64_t* row_off, void* ws, float* dW, float* dvec,
                                void* stream);
+/* dL/dX of the (gated) attention pooling over the patches, for bags that carry a gradient (a trainable Feat_Projecter feeding a
+ * DeepMIL encoder, model/deepmil.py:267-283): dx_n = dHa_n Wa + dHg_n Wg + A_n dpooled.  prep_t: the un-scaled weights packed
+ * [hidden][column] by vlsa_prepare_attn_dx_weights (vlsa_attn_dx_prep_bytes); da / aw: dL/da and the softmax weights of all bags'
+ * rows (bag b at a_off[b]); dpooled [B][512]; aw = dpooled = NULL: scores term only.  Tiles as vlsa_attn_scores_backward. */
+size_t vlsa_attn_dx_prep_bytes(int gated);
+int vlsa_prepare_attn_dx_weights(const float* Wa, const float* Wg, int gated, void* prep_t, void* stream);
+int vlsa_attn_scores_backward_dx(const void* bag_desc, const void* dx_desc, int B, int x_dtype, int D, const void* prep, const void* prep_t,
+                                 int gated, const int* tile_start, int n_tiles, const float* da, const float* aw, const float* dpooled,
+                                 const int64_t* a_off, float drop_p, unsigned int seed, void* stream);
 int vlsa_vlfan_backward_dx(const void* bag_desc, const void* dx_desc, int B, int D, const void* qprep, int P, float coattn_scale,
                            const int* tile_start, int n_tiles, const float* dout, const float* out, const float* m2, const float* l,
                            float* delta_ws, void* stream);

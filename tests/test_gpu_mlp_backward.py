@@ -213,3 +213,35 @@ def test_deepmil_train_mode_runs_the_fused_kernels_with_dropout():
     with torch.no_grad():
         mean = torch.stack([enc(X) for _ in range(48)]).mean(0)
     assert float((mean - ev).abs().max()) < 0.15 * float(ev.abs().max())
+
+
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [1, 33, 64, 200, 4000])
+def test_attention_pooling_dx_matches_autograd(gated, dtype, N):
+    """pooled = softmax(a(X)) @ X with gradients for the module's parameters AND the bag (trainable Feat_Projecter in front of a
+    DeepMIL encoder): the fused node (vlsa_attn_scores_backward + vlsa_attn_scores_backward_dx) vs torch autograd."""
+    from vlsa_amd import functional as VF
+    seed = 8300 + N
+    X = cases.make_bag(N, seed, "clustered" if N > 64 else "iid", dtype=dtype).requires_grad_(True)
+    kind = "gated_attention" if gated else "attention"
+    pp = {k: v.clone().requires_grad_(True) for k, v in cases.make_pool_params(kind, seed + 1).items()}
+    G = torch.randn(512, generator=cases.gen(seed + 2))
+    if gated:
+        pooled, raw, _ = O.gated_attention_pooling(X, pp["wa"], pp["ba"], pp["wg"], pp["bg"], pp["w2"], pp["b2"])
+    else:
+        pooled, raw, _ = O.attention_pooling(X, pp["w1"], pp["b1"], pp["w2"], pp["b2"])
+    (pooled * G).sum().backward()
+    dev = torch.device("cuda")
+    Xd = X.detach().to(dev).to(dtype).requires_grad_(True)
+    gp = {k: v.detach().to(dev).requires_grad_(True) for k, v in pp.items()}
+    w = (gp["wa"], gp["ba"], gp["wg"], gp["bg"], gp["w2"], gp["b2"]) if gated else (gp["w1"], gp["b1"], None, None, gp["w2"], gp["b2"])
+    pd, ad = VF.attn_pool_autograd(Xd, VF.FusedAttnScores(), *w)
+    _close(pd, pooled, "pooled", rtol=0, atol=1e-4)
+    _close(ad, raw, "scores", rtol=0, atol=1e-4)
+    (pd * G.to(dev)).sum().backward()
+    for k in pp:
+        if k != "b2":                       # softmax-invariant shift: gradient 0 up to rounding
+            _close(gp[k].grad, pp[k].grad, f"d{k}", atol=2e-6)
+    tol = RTOL if dtype == torch.float32 else 8e-3      # a bf16 bag receives a bf16 gradient
+    _close(Xd.grad, X.grad, "dX", rtol=tol, atol=1e-6)

@@ -132,6 +132,10 @@ _SIGNATURES = {
     "vlsa_mlp_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vlsa_attn_scores_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
+    "vlsa_attn_dx_prep_bytes": (c_size_t, [c_int]),
+    "vlsa_prepare_attn_dx_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "vlsa_attn_scores_backward_dx": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
     "vlsa_gated_scores_train": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_float, c_uint32, c_void_p]),
     "vlsa_feat_project_train": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p]),
     "vlsa_feat_project_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

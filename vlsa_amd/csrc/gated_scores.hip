@@ -28,6 +28,8 @@
 // the loop is NOT load- or barrier-bound (dropping all loads: -12 %, dropping publish + barrier: 0 %, LDS-DMA ring vs
 // register ring vs deeper prefetch: equal); the activations were (~25 % of a tile with IEEE divisions and ds_bpermute
 // shuffles, now ~15 %): N x 512 transcendental pairs at quarter rate are ~12 us per 50k bag on their own.
+#include <cstdlib>
+
 #include "vlsa_common.h"
 
 namespace vlsa {
@@ -384,6 +386,10 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     if (N <= 128 * (int64_t)max_rows) {
         rows_per_tile = (int)(((N + 127) / 128 + 15) / 16 * 16);
         if (rows_per_tile > max_rows) rows_per_tile = max_rows;
+    }
+    if (const char* e = getenv("VLSA_GS_ROWS")) {          // experiment hook (tools/kbench_gated.py): force the tile height
+        const int v = atoi(e);
+        if (v >= 16 && v <= max_rows && v % 16 == 0) rows_per_tile = v;
     }
     const bool full = rows_per_tile == max_rows;
     const unsigned int tiles = (unsigned int)((N + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)

@@ -548,3 +548,313 @@ extern "C" int vlsa_feat_project_backward(const void* bag_desc, const void* dy_d
     hipLaunchKernelGGL(k_mb_reduce, dim3((unsigned int)((tv / 4 + 31) / 32)), dim3(256), 0, st, a.part_v, a.C, tv, dvec);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
+
+// =================================================================================================================================
+// dL/dX of the (gated) attention pooling over the N patches -- needed only when the bag itself carries a gradient, i.e. when a
+// trainable Feat_Projecter feeds a DeepMIL encoder (model/deepmil.py:267-283):
+//     dx_n = dHa_n Wa + dHg_n Wg + A_n dpooled          (dH as above; A_n = softmax weight of the row, dpooled = dL/d pooled)
+// One kernel, same building blocks as k_mlp_backward: a workgroup owns a 64-row tile (32 fp32 rows) and ALL hidden units (wave w:
+// units [32 w, 32 w + 32) of both branches, so the gate product is wave-local), recomputes the pre-activations, forms dH in
+// registers, publishes it to LDS as bf16 hi + lo in the X tile's own (swizzled, row-major) layout -- the X tile is dead by then --
+// and contracts it over the hidden units against the un-scaled weights packed [k = hidden][n = column] (k_prepare_attn_dx_weights);
+// wave w owns output columns [64 w, 64 w + 64).  3 bf16 terms (dH_hi W_hi + dH_lo W_hi + dH_hi W_lo).
+namespace vlsa {
+namespace adx {
+constexpr int kLds = 2 * 65536;      // X tile (then dH hi) | dH lo
+}
+
+// packedT[((w * KS + ks) * 8 + ct * 2 + term) * 1024 + lane * 16 + 2 e] = term of Wcat[32 ks + 8 (lane >> 4) + e][64 w + 16 ct + (lane & 15)],
+// Wcat = [Wa; Wg] stacked over the hidden units (256 or 512 rows), KS = rows / 32.  grid = 8 * KS * 8 workgroups of 64 threads.
+__global__ __launch_bounds__(64) void k_prepare_attn_dx_weights(const float* __restrict__ Wa, const float* __restrict__ Wg, int gated,
+                                                                 unsigned char* __restrict__ out) {
+    const int KS = gated ? 16 : 8;
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int f = blk & 7, ks = (blk >> 3) % KS, w = blk / (8 * KS);
+    const int term = f & 1, ct = f >> 1;
+    const int col = 64 * w + 16 * ct + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kc = k0 + e;
+        const float x = kc < 256 ? Wa[(size_t)kc * 512 + col] : Wg[(size_t)(kc - 256) * 512 + col];
+        const __bf16 hi = (__bf16)x;
+        o[e] = term ? (__bf16)(x - (float)hi) : hi;
+    }
+    *reinterpret_cast<bf16x8*>(out + (size_t)blk * 1024 + lane * 16) = o;
+}
+
+struct AdxArgs {
+    const MbBag* bags;          // [B] rows (bf16 or fp32)
+    const MbBag* dxs;           // [B] fp32 gradient rows to write
+    const int* tile_start;      // [B + 1] tiles of 64 (bf16) / 32 (fp32) rows
+    const long long* row_off;   // [B] offset of bag b's rows in da / aw
+    const float* da;            // dL/da
+    const float* aw;            // softmax weights A_n of the pooling (nullable: no pooling term)
+    const float* dpooled;       // [B][512] (nullable with aw)
+    const unsigned char* wpack; // forward packing (recompute)
+    const unsigned char* wT;    // k_prepare_attn_dx_weights
+    const float *bias_a, *bias_g, *w2;
+    int B, n_tiles;
+    unsigned int drop_thr, drop_seed;
+    float drop_scale;
+};
+
+template <bool GATED, bool XF32>
+__global__ __launch_bounds__(512) void k_attn_scores_dx(const AdxArgs a) {
+    constexpr int RT = XF32 ? 2 : 4;
+    constexpr int ROWS = 16 * RT;
+    constexpr int QB = ROWS * 256;
+    constexpr int NB = GATED ? 2 : 1;
+    constexpr int NF = GATED ? 4 : 2;
+    constexpr int KS3 = GATED ? 16 : 8;            // k steps of the output contraction (hidden units / 32)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int t = blockIdx.x;
+    // tile lookup
+    const int tsv = lane < a.B ? a.tile_start[lane] : 0x7fffffff;
+    const int b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(tsv <= t)) - 1;
+    const MbBag bag = a.bags[b], ob = a.dxs[b];
+    const long long row0 = (long long)(t - a.tile_start[b]) * ROWS;
+    const int nrows = (int)((bag.N - row0) < ROWS ? (bag.N - row0) : ROWS);
+    const unsigned char* xsrc = static_cast<const unsigned char*>(bag.X) + row0 * bag.ldx * (XF32 ? 4 : 2);
+    const float* dav = a.da + a.row_off[b] + row0;
+
+    // ---- X tile -> LDS (layout of k_mlp_backward) ------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int p = tid + 512 * k;
+        const int row = XF32 ? (p >> 7) : (p >> 6), ch = XF32 ? (p & 127) : (p & 63);
+        u32x4_mb_t v = u32x4_mb_t{0u, 0u, 0u, 0u};
+        if (row < nrows) v = *reinterpret_cast<const u32x4_mb_t*>(xsrc + ((size_t)row * bag.ldx * (XF32 ? 4 : 2)) + ch * 16);
+        if constexpr (XF32) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int bits = v[e];
+                const float f = __uint_as_float(bits);
+                hi[e] = (__bf16)f;
+                lo[e] = (__bf16)(f - (float)hi[e]);
+            }
+            const int off = (ch >> 5) * QB + mb_swz(row, (ch & 31) * 8);
+            *reinterpret_cast<bf16x4_mb*>(smem + off) = hi;
+            *reinterpret_cast<bf16x4_mb*>(smem + 65536 + off) = lo;
+        } else {
+            *reinterpret_cast<u32x4_mb*>(smem + (ch >> 4) * QB + mb_swz(row, (ch & 15) * 16)) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: pre-activations of the wave's 32 hidden units (2 tiles) of both branches --------------------------------------
+    f32x4 acch[RT][2][NB];
+#pragma unroll
+    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int br = 0; br < NB; ++br) {
+            const int h = 16 * (2 * w + ht) + i16;
+            const float bb = br == 0 ? a.bias_a[h] : a.bias_g[h];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acch[rt][ht][br] = f32x4{bb, bb, bb, bb};
+        }
+    {
+        const unsigned char* wp = a.wpack + (size_t)(2 * w) * 16 * NF * 1024 + lane * 16;      // tile 2 w; tile 2 w + 1 is 16 NF KB behind
+        auto load_b = [&](int ks, bf16x8 (&dst)[2][NB][2]) {
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                for (int br = 0; br < NB; ++br)
+#pragma unroll
+                    for (int term = 0; term < 2; ++term)
+                        dst[ht][br][term] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(ht * 16 + ks) * NF + br * 2 + term) * 1024);
+        };
+        auto kstep = [&](int ks, const bf16x8 (&Bc)[2][NB][2]) {
+            const int qoff = (ks >> 2) * QB, boff = (ks & 3) * 64 + g * 16;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 A = *reinterpret_cast<const bf16x8_mb*>(smem + qoff + mb_swz(16 * rt + i16, boff));
+                bf16x8 AL = A;
+                if constexpr (XF32) AL = *reinterpret_cast<const bf16x8_mb*>(smem + 65536 + qoff + mb_swz(16 * rt + i16, boff));
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                    for (int br = 0; br < NB; ++br) {
+                        acch[rt][ht][br] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bc[ht][br][0], acch[rt][ht][br], 0, 0, 0);
+                        acch[rt][ht][br] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, Bc[ht][br][1], acch[rt][ht][br], 0, 0, 0);
+                        if constexpr (XF32) acch[rt][ht][br] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, Bc[ht][br][0], acch[rt][ht][br], 0, 0, 0);
+                    }
+            }
+        };
+        bf16x8 B0[2][NB][2], B1[2][NB][2];
+        load_b(0, B0);
+#pragma unroll 1
+        for (int ks = 0; ks < 16; ks += 2) {
+            load_b(ks + 1, B1);
+            kstep(ks, B0);
+            if (ks + 2 < 16) load_b(ks + 2, B0);
+            kstep(ks + 1, B1);
+        }
+    }
+    __syncthreads();                     // every wave is done with the X tile: its LDS becomes the dH image
+
+    // ---- phase 2: dH -> LDS (bf16 hi at 0, lo at 64 KiB), element (row, kc = 256 br + hidden) in the X tile's layout ---------------
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            const int hu = 16 * (2 * w + ht) + i16;
+            const float w2v = a.w2[hu];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + 4 * g + r;
+                const float dv = row < nrows ? dav[row] : 0.f;
+                const float u = fast_exp2(fminf(acch[rt][ht][0][r], 43.f));
+                const float th = (1.f - u) * __builtin_amdgcn_rcpf(1.f + u);
+                float sg = 1.f, keep = 1.f;
+                if constexpr (GATED) {
+                    const float v = fast_exp2(fminf(acch[rt][ht][1][r], 57.f));
+                    sg = __builtin_amdgcn_rcpf(1.f + v);
+                    if (a.drop_thr != 0u) {
+                        const unsigned int rid = (unsigned int)(row0 + row);
+                        const bool ka = dropout_bits(a.drop_seed, rid, (unsigned int)hu) >= a.drop_thr;
+                        const bool kg = dropout_bits(a.drop_seed, rid, (unsigned int)hu + 256u) >= a.drop_thr;
+                        keep = (ka && kg) ? a.drop_scale * a.drop_scale : 0.f;
+                    }
+                }
+                const float base = dv * w2v * keep;
+                float d[2];
+                d[0] = base * (1.f - th * th) * sg;
+                d[1] = base * th * sg * (1.f - sg);
+#pragma unroll
+                for (int br = 0; br < NB; ++br) {
+                    const int kc = 256 * br + hu;
+                    const __bf16 hi = (__bf16)d[br];
+                    const __bf16 lo = (__bf16)(d[br] - (float)hi);
+                    const int off = (kc >> 7) * QB + mb_swz(row, (kc & 127) * 2);
+                    *reinterpret_cast<__bf16 __attribute__((may_alias))*>(smem + off) = hi;
+                    *reinterpret_cast<__bf16 __attribute__((may_alias))*>(smem + 65536 + off) = lo;
+                }
+            }
+        }
+    __syncthreads();
+
+    // ---- phase 3: dX[rows][64 w .. + 63] = dH [rows][hidden] Wcat[hidden][cols] ----------------------------------------------------
+    f32x4 acco[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acco[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const unsigned char* wt = a.wT + (size_t)w * KS3 * 8 * 1024 + lane * 16;
+        auto load_t = [&](int ks, bf16x8 (&dst)[4][2]) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int term = 0; term < 2; ++term) dst[ct][term] = *reinterpret_cast<const bf16x8*>(wt + ((size_t)ks * 8 + ct * 2 + term) * 1024);
+        };
+        auto ostep = [&](int ks, const bf16x8 (&Bc)[4][2]) {
+            const int qoff = (ks >> 2) * QB, boff = (ks & 3) * 64 + g * 16;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 Ah = *reinterpret_cast<const bf16x8_mb*>(smem + qoff + mb_swz(16 * rt + i16, boff));
+                const bf16x8 Al = *reinterpret_cast<const bf16x8_mb*>(smem + 65536 + qoff + mb_swz(16 * rt + i16, boff));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    acco[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bc[ct][0], acco[rt][ct], 0, 0, 0);
+                    acco[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bc[ct][0], acco[rt][ct], 0, 0, 0);
+                    acco[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bc[ct][1], acco[rt][ct], 0, 0, 0);
+                }
+            }
+        };
+        bf16x8 T0[4][2], T1[4][2];
+        load_t(0, T0);
+#pragma unroll 1
+        for (int ks = 0; ks < KS3; ks += 2) {
+            load_t(ks + 1, T1);
+            ostep(ks, T0);
+            if (ks + 2 < KS3) load_t(ks + 2, T0);
+            ostep(ks + 1, T1);
+        }
+    }
+    // ---- epilogue: + A_n dpooled, store (C layout: lane column i16, rows 4 g + r) ---------------------------------------------------
+    float* dst = static_cast<float*>(const_cast<void*>(ob.X)) + row0 * ob.ldx + 64 * w + i16;
+    const float* awp = a.aw ? a.aw + a.row_off[b] + row0 : nullptr;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * g + r;
+            if (row < nrows) {
+                const float an = awp ? awp[row] : 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float o = acco[rt][ct][r];
+                    if (awp) o = fmaf(an, a.dpooled[(size_t)b * 512 + 64 * w + 16 * ct + i16], o);
+                    dst[(size_t)row * ob.ldx + 16 * ct] = o;
+                }
+            }
+        }
+}
+
+}  // namespace vlsa
+
+extern "C" size_t vlsa_attn_dx_prep_bytes(int gated) { return (size_t)8 * (gated ? 16 : 8) * 8 * 1024; }
+
+extern "C" int vlsa_prepare_attn_dx_weights(const float* Wa, const float* Wg, int gated, void* prep_t, void* stream) {
+    if (!Wa || !prep_t || (gated && !Wg)) return VLSA_EINVAL;
+    hipLaunchKernelGGL(k_prepare_attn_dx_weights, dim3(8 * (gated ? 16 : 8) * 8), dim3(64), 0, (hipStream_t)stream, Wa, Wg, gated ? 1 : 0,
+                       static_cast<unsigned char*>(prep_t));
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// dL/dX of the (gated) attention pooling for B bags whose rows carry a gradient (see k_attn_scores_dx).  dx_desc: table of the fp32
+// gradient rows to write; da / aw: dL/da and the softmax weights A_n of all bags' rows (bag b at a_off[b]); dpooled [B][512] (aw
+// and dpooled may both be NULL: scores term only); prep / prep_t: vlsa_prepare_gated_weights / vlsa_prepare_attn_dx_weights.
+extern "C" int vlsa_attn_scores_backward_dx(const void* bag_desc, const void* dx_desc, int B, int x_dtype, int D, const void* prep,
+                                            const void* prep_t, int gated, const int* tile_start, int n_tiles, const float* da,
+                                            const float* aw, const float* dpooled, const int64_t* a_off, float drop_p, unsigned int seed,
+                                            void* stream) {
+    if (!bag_desc || !dx_desc || !prep || !prep_t || !tile_start || !da || !a_off || B < 1 || B > 64 || n_tiles < 1) return VLSA_EINVAL;
+    if ((aw == nullptr) != (dpooled == nullptr)) return VLSA_EINVAL;
+    if (D != mb::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    const GatedPrepOffsets L(gated ? 1 : 0);
+    const unsigned char* pp = static_cast<const unsigned char*>(prep);
+    AdxArgs a{};
+    a.bags = static_cast<const MbBag*>(bag_desc);
+    a.dxs = static_cast<const MbBag*>(dx_desc);
+    a.tile_start = tile_start;
+    a.row_off = reinterpret_cast<const long long*>(a_off);
+    a.da = da;
+    a.aw = aw;
+    a.dpooled = dpooled;
+    a.wpack = pp + L.wpack;
+    a.wT = static_cast<const unsigned char*>(prep_t);
+    a.bias_a = reinterpret_cast<const float*>(pp + L.ba);
+    a.bias_g = reinterpret_cast<const float*>(pp + L.bg);
+    a.w2 = reinterpret_cast<const float*>(pp + L.w2);
+    a.B = B;
+    a.n_tiles = n_tiles;
+    a.drop_thr = 0u;
+    a.drop_scale = 1.f;
+    if (gated && drop_p > 0.f) {
+        if (!(drop_p < 1.f)) return VLSA_EINVAL;
+        a.drop_thr = (unsigned int)((double)drop_p * 4294967296.0);
+        if (a.drop_thr == 0u) a.drop_thr = 1u;
+        a.drop_seed = seed;
+        a.drop_scale = 1.f / (1.f - drop_p);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    static DeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)k_attn_scores_dx<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, adx::kLds);
+        (void)hipFuncSetAttribute((const void*)k_attn_scores_dx<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, adx::kLds);
+        (void)hipFuncSetAttribute((const void*)k_attn_scores_dx<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, adx::kLds);
+        (void)hipFuncSetAttribute((const void*)k_attn_scores_dx<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, adx::kLds);
+    }
+    const bool f32 = x_dtype == VLSA_DT_F32;
+#define VLSA_ADX(G, F) hipLaunchKernelGGL((k_attn_scores_dx<G, F>), dim3(n_tiles), dim3(512), adx::kLds, st, a)
+    if (gated) { if (f32) VLSA_ADX(true, true); else VLSA_ADX(true, false); }
+    else       { if (f32) VLSA_ADX(false, true); else VLSA_ADX(false, false); }
+#undef VLSA_ADX
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}

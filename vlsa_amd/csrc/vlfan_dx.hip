@@ -145,20 +145,28 @@ __global__ __launch_bounds__(256) void k_vlfan_dx(const DxArgs a) {
         cn = quad_rows_sum(cn) * rinv * rinv;
         // ---- dX^T[c][row] = sum_p dout[p][c] A_p,row + e[p][c] u_p,row - c_row x[row][c] --------------------------------------
 #pragma unroll
-        for (int ct = 0; ct < 32; ++ct) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c2 = 0; c2 < 32; c2 += 2) {      // two column tiles x two products = four independent accumulator chains
+            f32x4 accA[2], accU[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) accA[k] = accU[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = 4 * g + r;
-                const int off = dx_chunk(p, 4 * ct + (i16 >> 2)) + (i16 & 3) * 4;
-                const float dv = *reinterpret_cast<const float_dx*>(smem + kDOff + off);
-                const float ev = *reinterpret_cast<const float_dx*>(smem + kQOff + off);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, Aw[r], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ev, Uw[r], acc, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int off = dx_chunk(p, 4 * (c2 + k) + (i16 >> 2)) + (i16 & 3) * 4;
+                    const float dv = *reinterpret_cast<const float_dx*>(smem + kDOff + off);
+                    const float ev = *reinterpret_cast<const float_dx*>(smem + kQOff + off);
+                    accA[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv, Aw[r], accA[k], 0, 0, 0);
+                    accU[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev, Uw[r], accU[k], 0, 0, 0);
+                }
             }
             if (rok) {
-                const f32x4 o = acc - cn * x[ct];
-                __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(t.dxo + (size_t)i16 * t.lddx + 16 * ct + 4 * g));
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f32x4 o = (accA[k] + accU[k]) - cn * x[c2 + k];
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(t.dxo + (size_t)i16 * t.lddx + 16 * (c2 + k) + 4 * g));
+                }
             }
         }
     };

@@ -355,18 +355,33 @@ class DeepMIL(nn.Module):
         if self.feat_proj is not None:
             X = self.feat_proj(X)
         raw_attn = None
-        x_grad = torch.is_grad_enabled() and X.requires_grad   # trainable Feat_Projecter: pooling as torch ops (dX needed)
+        x_grad = torch.is_grad_enabled() and X.requires_grad   # a trainable Feat_Projecter in front: the pooling must hand dX back
         if self.sigma == "mean":
             out_feat = X.float().mean(dim=1) if x_grad else VF.scored_pool(X, None)[None, :]
         elif self.sigma == "max":
             out_feat = X.float().amax(dim=1) if x_grad else VF.colmax(X)[None, :]
         else:
             X2 = VF._bag2d(X)
-            a = self._attention_scores(X2)
-            if x_grad:
-                out_feat = (torch.softmax(a, dim=0)[None, :] @ X2.float())
+            sg = self.sigma
+            gated = isinstance(sg, Gated_Attention_Pooling)
+            lin_a = sg.fc1[0] if gated else sg.attention[0]
+            if (x_grad and (not gated or sg.fc1[2].p == sg.score[2].p)
+                    and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
+                # scores + pooling as ONE autograd node whose backward is HIP end to end: parameter gradients AND
+                # dX = dHa Wa + dHg Wg + A dpooled (vlsa_attn_scores_backward_dx); 512 -> 256 hidden, the reference's sizes
+                if not hasattr(self, "_fused_scores"):
+                    self._fused_scores = VF.FusedAttnScores()
+                w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
+                     (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
+                drop_p = float(sg.fc1[2].p) if (gated and sg.training and sg.fc1[2].p > 0) else 0.0
+                pooled, a = VF.attn_pool_autograd(X2, self._fused_scores, *w, drop_p=drop_p)
+                out_feat = pooled[None, :]
             else:
-                out_feat = VF.scored_pool(X2, a)[None, :]
+                a = self._attention_scores(X2)
+                if x_grad:         # other layer widths than 512 -> 256: library GEMMs (see _attention_scores) + torch pooling
+                    out_feat = torch.softmax(a, dim=0)[None, :] @ X2.float()
+                else:
+                    out_feat = VF.scored_pool(X2, a)[None, :]
             if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
                 raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
         if self.pred_head == "Adapter":

@@ -756,6 +756,20 @@ class FusedAttnScores:
             self._key, self._prep = key, prep
         return self._prep
 
+    def packed_t(self, device, Wa, Wg) -> torch.Tensor:
+        """the un-scaled weights packed [hidden][column] for the dX contraction (vlsa_prepare_attn_dx_weights), per parameter version"""
+        lib = nat.load()
+        params = [t for t in (Wa, Wg) if t is not None]
+        key = tuple((id(t), t._version) for t in params) + (device,)
+        if key != getattr(self, "_key_t", None):
+            gated = Wg is not None
+            prep = torch.empty(lib.vlsa_attn_dx_prep_bytes(int(gated)), dtype=torch.uint8, device=device)
+            keep = [_f32c(t) for t in params]
+            nat.check(lib.vlsa_prepare_attn_dx_weights(_p(keep[0]), _p(keep[1]) if gated else None, int(gated), _p(prep), _stream()),
+                      "vlsa_prepare_attn_dx_weights")
+            self._key_t, self._prep_t, self._params_t = key, prep, params
+        return self._prep_t
+
     def pool_bags(self, bags, Wa, ba, Wg, bg, w2, c):
         """The N-sized part of DeepMIL for up to 64 bags ([N_i, 512], one dtype, validated by the caller) in three launches:
         raw scores of all bags (vlsa_gated_scores_batch), softmax-weighted row sums (vlsa_scored_pool_partial_batch), fold.
@@ -889,6 +903,58 @@ class _AttnScoresFn(torch.autograd.Function):
         w2_shape, c_shape = ctx.shapes
         return (None, None, dW[0], dvec[0, :256], dW[1] if gated else None, dvec[0, 256:] if gated else None,
                 dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape), None, None)
+
+
+class _AttnPoolFn(torch.autograd.Function):
+    """pooled [512] = softmax_N(a) @ X with a = the (gated) attention scores, for a bag that ITSELF carries a gradient (a trainable
+    Feat_Projecter in front of a DeepMIL encoder, model/deepmil.py:267-283): forward = score kernel + pooling kernels, backward =
+    da in one pass (vlsa_scored_pool_backward), the parameter gradients (vlsa_attn_scores_backward) and
+    dX = dHa Wa + dHg Wg + A dpooled (vlsa_attn_scores_backward_dx).  Returns (pooled, a); a is not differentiable here."""
+
+    @staticmethod
+    def forward(ctx, X2, fused, Wa, ba, Wg, bg, w2, c, drop_p, seed):
+        a = fused(X2, Wa, ba, Wg, bg, w2, c, drop_p=drop_p, seed=seed)
+        m2, l, out = _scored_pool_raw(X2, a)
+        gated = Wg is not None
+        ctx.save_for_backward(X2, a, m2, l, out, fused._prep, fused.packed_t(X2.device, Wa, Wg))
+        ctx.gated, ctx.shapes, ctx.drop = gated, (w2.shape, c.shape), (float(drop_p), int(seed))
+        ctx.mark_non_differentiable(a)
+        return out[0], a
+
+    @staticmethod
+    def backward(ctx, dpooled, _da_unused):
+        lib, s = nat.load(), _stream()
+        X2, a, m2, l, out, prep, prep_t = ctx.saved_tensors
+        gated, dev, N = ctx.gated, X2.device, X2.shape[0]
+        dp = _f32c(dpooled).reshape(-1)
+        da = torch.empty(N, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_scored_pool_backward(_p(X2), _dt(X2), N, X2.stride(0), 512, _p(a), _p(m2), _p(l), _p(out), _p(dp), _p(da), s),
+                  "vlsa_scored_pool_backward")
+        tile_rows = int(lib.vlsa_mlp_bwd_tile_rows(_dt(X2)))
+        dX = torch.empty(N, 512, dtype=torch.float32, device=dev)
+        keep, p_desc, p_dx, p_off, p_ts, n_tiles, _ = _row_tables([X2], tile_rows, extra=[dX])
+        ws = torch.empty(lib.vlsa_mlp_bwd_workspace_bytes(1 if gated else 0, n_tiles), dtype=torch.uint8, device=dev)
+        dW = torch.empty(2 if gated else 1, 256, 512, dtype=torch.float32, device=dev)
+        dvec = torch.empty(3, 512, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_attn_scores_backward(p_desc, 1, _dt(X2), 512, _p(prep), int(gated), p_ts, n_tiles, _p(da), p_off, _p(ws),
+                                                _p(dW), _p(dvec), ctx.drop[0], ctx.drop[1], s), "vlsa_attn_scores_backward")
+        aw = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]          # [N] softmax weights of the pooling
+        nat.check(lib.vlsa_attn_scores_backward_dx(p_desc, p_dx, 1, _dt(X2), 512, _p(prep), _p(prep_t), int(gated), p_ts, n_tiles, _p(da),
+                                                   _p(aw), _p(dp), p_off, ctx.drop[0], ctx.drop[1], s), "vlsa_attn_scores_backward_dx")
+        w2_shape, c_shape = ctx.shapes
+        if X2.dtype != torch.float32:
+            dX = dX.to(X2.dtype)
+        return (dX, None, dW[0], dvec[0, :256], dW[1] if gated else None, dvec[0, 256:] if gated else None,
+                dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape), None, None)
+
+
+def attn_pool_autograd(X2: torch.Tensor, fused: "FusedAttnScores", Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0, seed: Optional[int] = None):
+    """(pooled [512], raw scores a [N]) of (Gated_)Attention_Pooling over a bag, differentiable w.r.t. the module's parameters AND
+    the bag (see _AttnPoolFn)."""
+    _need_gpu(X2)
+    if drop_p and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _AttnPoolFn.apply(X2, fused, Wa, ba, Wg, bg, w2, c, float(drop_p or 0.0), int(seed or 0))
 
 
 def attn_scores_autograd(X2: torch.Tensor, fused: "FusedAttnScores", Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0,
