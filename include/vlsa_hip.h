@@ -484,6 +484,9 @@ typedef struct vlsa_tt_rows {
     int n_seq, M, M_pad, max_len;
     const int *row_seq, *row_pos, *row_src, *seq_row0;
     const unsigned char* cls_keep;
+    int prefix_len;   /* L > 0: the first L positions carry the SAME embedding in every prompt (<sot> + shared context tokens) and
+                         are stored once, as rows 0 .. L-1 (row_seq 0); prompt s then owns rows [seq_row0[s], seq_row0[s + 1]) =
+                         its positions L .. + its CLS row, seq_row0[0] == L; max_len counts the L prefix keys.  0: no sharing. */
 } vlsa_tt_rows;
 
 /*

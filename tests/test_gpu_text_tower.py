@@ -45,6 +45,23 @@ def test_rank_prompts_through_the_tower_forward_and_backward(case):
         ref = fx[key]
         err = np.abs(p.grad.cpu().numpy() - ref).max()
         assert err < TOL * max(1.0, np.abs(ref).max()), (key, err, np.abs(ref).max())
+    # the same with the sentences' shared prefix (<sot> + the context tokens in front of the rank tokens) evaluated ONCE for all
+    # prompts (compact_rows(prefix_len)): exact under the causal mask -- same features, same gradients
+    pl.zero_grad()
+    L = pl.shared_prefix_len
+    with torch.no_grad():
+        fs0 = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=L)
+    assert enc._plan(pl.pseudo_sentence_tokens, fs0.device, L).prefix_len == L and enc._plan(pl.pseudo_sentence_tokens, fs0.device, L).M < K * (
+        int((pl.pseudo_sentence_tokens[0] > 0).sum()) + 2) or K == 1
+    assert np.abs(fs0.cpu().numpy() - fx["text_features"]).max() < TOL
+    fs = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=L)
+    assert np.abs(fs.detach().cpu().numpy() - fx["text_features"]).max() < TOL
+    (fs * torch.from_numpy(fx["G"]).cuda()).sum().backward()
+    for key, p in (("grad_context", pl.context_embeds), ("grad_rank", pl.rank_embeds)):
+        ref = fx[key]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err < TOL * max(1.0, np.abs(ref).max()), ("shared prefix", key, err, np.abs(ref).max())
+    pl.zero_grad()
     # a second forward / backward on the same plan (workspaces are per call) gives the same numbers
     pl.zero_grad()
     feats2 = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)

@@ -106,3 +106,32 @@ def test_compact_rows_follow_the_shifted_cls_mask():
         cols = [c for c in range(128) if keep[s, c]]
         got = [rp["row_pos"][r0[s] + j] for j in range(lens[s]) if rp["cls_keep"][r0[s] + j]]
         assert got == cols
+
+
+def test_compact_rows_with_a_shared_prefix():
+    """K rank prompts `<sot> ctx x 4 | rank x 4 . <eot>`: with prefix_len = 5 the five leading rows are planned once and every prompt
+    keeps its 7 own positions + CLS: 5 + K * 8 rows instead of K * 13; the plan falls back to no sharing when a prompt does not
+    reach past the prefix or one of its prefix positions is padding."""
+    from vlsa_amd.prompt_encoder import compact_rows
+    K, L = 12, 127
+    pt = torch.zeros(K, L, dtype=torch.long)
+    pt[:, :11] = torch.arange(1, 12)
+    full = compact_rows(pt, 128)
+    rp = compact_rows(pt, 128, prefix_len=5)
+    assert full["M"] == K * 13 and rp["M"] == 5 + K * 8 and rp["prefix_len"] == 5
+    assert rp["seq_row0"][0] == 5 and rp["seq_row0"][-1] == rp["M"] and rp["max_len"] == full["max_len"] == 13
+    assert rp["row_pos"][:5] == [0, 1, 2, 3, 4] and rp["row_seq"][:5] == [0] * 5 and rp["row_src"][:5] == [0, 1, 2, 3, 4]
+    for s in range(K):
+        a, b = rp["seq_row0"][s], rp["seq_row0"][s + 1]
+        assert rp["row_pos"][a:b] == list(range(5, 12)) + [127] and rp["row_seq"][a:b] == [s] * 8
+        assert rp["row_src"][a:b] == list(range(5, 12)) + [-1] and rp["cls_keep"][a:b] == [1] * 7 + [0]
+    short = pt.clone(); short[3, 3:] = 0                      # prompt 3 ends inside the would-be prefix
+    assert compact_rows(short, 128, prefix_len=5)["prefix_len"] == 0
+    assert compact_rows(pt[:1], 128, prefix_len=5)["prefix_len"] == 0        # a single prompt has nothing to share
+
+
+def test_learners_report_their_shared_prefix():
+    import text_cases as TC
+    for case, want in ((TC.RANK_CASES[0], 1 + 4), (TC.RANK_CASES[2], 1), (TC.RANK_CASES[3], 1 + 3 // 2)):   # tail / front / middle
+        pl = build_learner(case, __import__("text_helpers").rank_case_inputs(case))
+        assert pl.shared_prefix_len == want, (case[0], pl.shared_prefix_len)

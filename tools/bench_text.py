@@ -17,6 +17,7 @@ case = TC.RANK_CASES[0]
 inp = TH.rank_case_inputs(case)
 enc = build_encoder(case[1], case[2])
 pl = build_learner(case, inp).cuda()
+PREFIX = 0 if "--no-prefix" in sys.argv else pl.shared_prefix_len      # rows of the sentences' shared prefix evaluated once
 
 
 def timed(fn, n=50, warm=10):
@@ -32,20 +33,21 @@ def timed(fn, n=50, warm=10):
 
 def fwd():
     with torch.no_grad():
-        return enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+        return enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=PREFIX)
 
 
 def fwd_bwd():
     pl.zero_grad(set_to_none=True)
-    f = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens)
+    f = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=PREFIX)
     f.sum().backward()
 
 
 t_f, t_fb = timed(fwd), timed(fwd_bwd)
 with torch.no_grad():
     sent = pl()
-t_tower = timed(lambda: enc(prompts_embedding=sent, prompts_pseudo_tokens=pl.pseudo_sentence_tokens))
-print(f"K=12 rank prompts, CONCH-size tower (12 x 768, 85 M weights fp32), 156 compact rows of 1536")
+t_tower = timed(lambda: enc(prompts_embedding=sent, prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=PREFIX))
+rows = enc._plan(pl.pseudo_sentence_tokens, sent.device, PREFIX).M
+print(f"K=12 rank prompts, CONCH-size tower (12 x 768, 85 M weights fp32), {rows} compact rows of 1536 (shared prefix: {PREFIX} positions)")
 print(f"GPU forward (learner + tower, no grad): {t_f * 1e6:.0f} us;  tower alone: {t_tower * 1e6:.0f} us;  forward + backward: {t_fb * 1e6:.0f} us")
 if "--cpu" in sys.argv:
     from oracle import text_oracle as TO

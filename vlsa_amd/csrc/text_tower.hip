@@ -387,28 +387,37 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 // attention of one (prompt, head) over the prompt's compact rows.  Token row i sees rows j <= i (causal); the CLS row (last)
 // sees the rows flagged in cls_keep (model/prompt_encoder.py:245-252,299-303).
+// Shared prefix (prefix_len = L > 0): the first L positions of every prompt carry identical embeddings (<sot> + the shared
+// context tokens of the rank prompts, model/prompt_learners/rank_prompt_learner.py:116-156 with the rank tokens at the tail), so
+// under the causal mask their activations are identical in every layer: they are stored ONCE (rows 0 .. L-1), prompt s owns rows
+// [seq_row0[s], seq_row0[s + 1]) = its positions L .. m_s + its CLS row.  Block (s, h) then attends with the keys [prefix rows |
+// own rows]; one more block per head (s == n_seq) serves the prefix rows themselves (causal among themselves).
 constexpr int kAttnMaxS = 128;
 __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out_t,
                                                     const int* __restrict__ seq_row0, const unsigned char* __restrict__ cls_keep,
-                                                    int heads, int d) {
+                                                    int heads, int d, int n_seq, int L) {
     __shared__ float Ks[kAttnMaxS][kHeadDim + 1];
     __shared__ float Vs[kAttnMaxS][kHeadDim + 1];
     __shared__ float Qs[kAttnMaxS][kHeadDim];
     const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int r0 = seq_row0[seq], S = seq_row0[seq + 1] - r0;
+    const bool pfx_block = seq == n_seq;                       // only launched when L > 0
+    const int r0 = pfx_block ? 0 : seq_row0[seq];
+    const int S = pfx_block ? L : L + seq_row0[seq + 1] - r0;   // keys: [prefix | own rows]
+    const int qbeg = pfx_block ? 0 : L;                        // first query (key index)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    auto grow = [&](int j) { return (pfx_block || j < L) ? j : r0 + (j - L); };     // key / query index -> compact row
     for (int e = tid; e < S * kHeadDim; e += 256) {   // q, k, v of the prompt in ONE round of global loads
         const int j = e >> 6, c = e & 63;
-        const size_t base = (size_t)(r0 + j) * ld + h * kHeadDim + c;
+        const size_t base = (size_t)grow(j) * ld + h * kHeadDim + c;
         const float qv = qkv[base], kv = qkv[base + d], vv = qkv[base + 2 * d];
         Qs[j][c] = qv * 0.125f;   // head_dim^-0.5
         Ks[j][c] = kv;
         Vs[j][c] = vv;
     }
     __syncthreads();
-    for (int i = w; i < S; i += 4) {
+    for (int i = qbeg + w; i < S; i += 4) {
         const float q = Qs[i][lane];
-        const bool is_cls = i == S - 1;
+        const bool is_cls = !pfx_block && i == S - 1;
         float s[2] = {-INFINITY, -INFINITY}, p[2];
         const int halves = S > 64 ? 2 : 1;                 // prompts are short: the second key chunk is rarely needed (uniform)
         for (int half = 0; half < halves; ++half) {
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
 #pragma unroll
             for (int c = 0; c < kHeadDim; ++c)
                 dot = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), c)), Ks[jc][c], dot);
-            const bool ok = j < S && (is_cls ? cls_keep[r0 + jc] != 0 : j <= i);
+            const bool ok = j < S && (is_cls ? cls_keep[grow(jc)] != 0 : j <= i);
             if (half == 0) s[0] = ok ? dot : -INFINITY; else s[1] = ok ? dot : -INFINITY;
         }
         const float m = wave_max(fmaxf(s[0], s[1]));
@@ -433,15 +442,21 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
             o = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[0]), __builtin_amdgcn_readfirstlane(j))), Vs[j][lane], o);
         for (int j = 64; j < S; ++j)
             o = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[1]), __builtin_amdgcn_readfirstlane(j - 64))), Vs[j][lane], o);
-        out_t[tiled_index(r0 + i, h * kHeadDim + lane, d)] = o;    // tiled [M_pad, d]: the A operand of the out_proj product
+        out_t[tiled_index(grow(i), h * kHeadDim + lane, d)] = o;    // tiled [M_pad, d]: the A operand of the out_proj product
     }
 }
 
+// Backward.  With a shared prefix the dK / dV of the prefix rows get a contribution from EVERY block of a head (the n_seq prompts +
+// the prefix block): each block publishes its partial [L][2][64] (write-through stores), takes a ticket on the head's counter, and
+// the last arriver adds the n_seq + 1 partials in block order (deterministic) into dqkv.  pfx: [(n_seq + 1)][heads][L][128] floats,
+// cnt: [heads] zeroed unsigned ints (handed back zeroed).
 constexpr int kAttnBwdMaxS = 64;
 __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ qkv, int ld, const float* __restrict__ dout, int ldo,
                                                     float* __restrict__ dqkv, const int* __restrict__ seq_row0,
-                                                    const unsigned char* __restrict__ cls_keep, int heads, int d) {
+                                                    const unsigned char* __restrict__ cls_keep, int heads, int d, int n_seq, int L,
+                                                    float* __restrict__ pfx, unsigned int* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ bool s_last;
     constexpr int LD = kHeadDim + 1;
     float* Qs = sm;
     float* Ks = Qs + kAttnBwdMaxS * LD;
@@ -450,20 +465,29 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
     float* Pm = Os + kAttnBwdMaxS * LD;      // softmax weights [i][j]
     float* Dm = Pm + kAttnBwdMaxS * LD;      // d scores (scale folded in) [i][j]
     const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int r0 = seq_row0[seq], S = seq_row0[seq + 1] - r0;
+    const bool pfx_block = seq == n_seq;
+    const int r0 = pfx_block ? 0 : seq_row0[seq];
+    const int S = pfx_block ? L : L + seq_row0[seq + 1] - r0;
+    const int qbeg = pfx_block ? 0 : L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    auto grow = [&](int j) { return (pfx_block || j < L) ? j : r0 + (j - L); };
     for (int e = tid; e < S * kHeadDim; e += 256) {
         const int j = e >> 6, c = e & 63;
-        const size_t base = (size_t)(r0 + j) * ld + h * kHeadDim + c;
+        const size_t base = (size_t)grow(j) * ld + h * kHeadDim + c;
         Qs[j * LD + c] = qkv[base];
         Ks[j * LD + c] = qkv[base + d];
         Vs[j * LD + c] = qkv[base + 2 * d];
-        Os[j * LD + c] = dout[(size_t)(r0 + j) * ldo + h * kHeadDim + c];
+        Os[j * LD + c] = dout[(size_t)grow(j) * ldo + h * kHeadDim + c];
     }
     __syncthreads();
     for (int i = w; i < S; i += 4) {   // lane j: score, weight and their gradients for key j of query row i
-        const bool is_cls = i == S - 1;
         const int j = lane;
+        if (i < qbeg) {                // prefix rows are queries of the prefix block only
+            Pm[i * LD + j] = 0.f;
+            Dm[i * LD + j] = 0.f;
+            continue;
+        }
+        const bool is_cls = !pfx_block && i == S - 1;
         float dot = 0.f, dp = 0.f;
         if (j < S) {
 #pragma unroll
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
                 dp = fmaf(Os[i * LD + c], Vs[j * LD + c], dp);
             }
         }
-        const bool ok = j < S && (is_cls ? cls_keep[r0 + j] != 0 : j <= i);
+        const bool ok = j < S && (is_cls ? cls_keep[grow(j < S ? j : 0)] != 0 : j <= i);
         const float s = ok ? dot * 0.125f : -INFINITY;
         const float m = wave_max(s);
         float p = ok ? __expf(s - m) : 0.f;
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
         Dm[i * LD + j] = p * (dp - delta) * 0.125f;
     }
     __syncthreads();
+    const bool shared_keys = L > 0;
     for (int rr = w; rr < S; rr += 4) {   // lane = feature c of row rr: dQ, dK, dV
         float dq = 0.f, dk = 0.f, dv = 0.f;
         for (int j = 0; j < S; ++j) {
@@ -490,10 +515,38 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
             dv = fmaf(Pm[j * LD + rr], Os[j * LD + lane], dv);
         }
         const int col = h * kHeadDim + lane;       // tiled [M_pad, 3 d]: the A operand of the in_proj^T product
-        dqkv[tiled_index(r0 + rr, col, 3 * d)] = dq;
-        dqkv[tiled_index(r0 + rr, col + d, 3 * d)] = dk;
-        dqkv[tiled_index(r0 + rr, col + 2 * d, 3 * d)] = dv;
+        const bool pfx_row = shared_keys && rr < L;
+        if (!pfx_row || pfx_block) dqkv[tiled_index(grow(rr), col, 3 * d)] = dq;
+        if (!pfx_row) {
+            dqkv[tiled_index(grow(rr), col + d, 3 * d)] = dk;
+            dqkv[tiled_index(grow(rr), col + 2 * d, 3 * d)] = dv;
+        } else {                                   // this block's share of a prefix row's dK / dV: published write-through
+            float* pp = pfx + (((size_t)seq * heads + h) * L + rr) * 128;
+            __hip_atomic_store(pp + lane, dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 64 + lane, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (!shared_keys) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(cnt + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (unsigned int)n_seq;                 // n_seq + 1 blocks per head
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int rr = w; rr < L; rr += 4) {
+        float dk = 0.f, dv = 0.f;
+        for (int b = 0; b <= n_seq; ++b) {                 // fixed order
+            const float* pp = pfx + (((size_t)b * heads + h) * L + rr) * 128;
+            dk += __hip_atomic_load(pp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dv += __hip_atomic_load(pp + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int col = h * kHeadDim + lane;
+        dqkv[tiled_index(rr, col + d, 3 * d)] = dk;
+        dqkv[tiled_index(rr, col + 2 * d, 3 * d)] = dv;
+    }
+    if (tid == 0) __hip_atomic_store(cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ticket back to zero
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -639,7 +692,7 @@ using namespace vlsa::tt;
 namespace {
 
 struct Shape {
-    int d, heads, layers, out_dim, M_pad, M, n_seq, ns_pad;
+    int d, heads, layers, out_dim, M_pad, M, n_seq, ns_pad, L;
 };
 
 bool shape_of(const vlsa_tt_model* m, const vlsa_tt_rows* r, Shape& s) {
@@ -657,6 +710,8 @@ bool shape_of(const vlsa_tt_model* m, const vlsa_tt_rows* r, Shape& s) {
     s.M_pad = r->M_pad;
     s.n_seq = r->n_seq;
     s.ns_pad = (r->n_seq + 47) / 48 * 48;
+    s.L = r->prefix_len;
+    if (s.L < 0 || s.L >= r->max_len) return false;
     if (s.M < 1 || s.M_pad < s.M || (s.M_pad % 48) || s.n_seq < 1 || r->max_len < 2 || r->max_len > kAttnMaxS) return false;
     if (!r->row_seq || !r->row_pos || !r->row_src || !r->seq_row0 || !r->cls_keep) return false;
     return true;
@@ -680,9 +735,12 @@ inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 9; }
 struct Scratch {   // behind the layer regions; *_t = tiled
     float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
     float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *dattn, *dqkv_t;                    // backward
+    float* pfx;             // shared prefix: per (block, head) partial dK / dV of the prefix rows [(n_seq + 1)][heads][L][128]
+    unsigned int* cnt;      // [heads] tickets (zero between launches: the workspace is zeroed once by the caller)
 };
+inline size_t pfx_floats(const Shape& s) { return (size_t)(s.n_seq + 1) * s.heads * (s.L > 0 ? s.L : 0) * 128 + 64; }
 inline size_t scratch_floats(const Shape& s) {
-    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim);
+    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s);
 }
 inline Scratch scratch_of(float* p, const Shape& s) {
     const size_t md = (size_t)s.M_pad * s.d;
@@ -703,7 +761,9 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     c.pooled_t = p; p += (size_t)s.ns_pad * s.d;
     c.dpool = p; p += (size_t)s.ns_pad * s.d;
     c.feat = p; p += (size_t)s.ns_pad * s.out_dim;
-    c.dout_t = p;
+    c.dout_t = p; p += (size_t)s.ns_pad * s.out_dim;
+    c.cnt = reinterpret_cast<unsigned int*>(p); p += 64;
+    c.pfx = p;
     return c;
 }
 
@@ -886,11 +946,15 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             // 32-row workgroup tiles when they still fit one round of the CUs (K = 12 prompts: 5 x 48 = 240 workgroups of 2/3 the
             // work instead of 4 x 48 = 192), else 48-row tiles
             const int nt = (3 * d) % 48 == 0 ? (3 * d) / 48 : (3 * d) / 32;
-            if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
+            // few rows (shared prefix: K = 12 prompts are 101 rows = 7 row tiles): 16 x 64 tiles fill the CUs (7 x 36 = 252
+            // workgroups) with 2/3 of the MFMA work of a 32 x 48 tile each
+            if ((3 * d) % 64 == 0 && ((s.M + 15) / 16) * (3 * d / 64) <= 256 && ((s.M + 15) / 16) * 2 < ((s.M + 31) / 32) * 3 && d / 4 / 16 == 12)
+                TT_TRY((launch_gemm_g<1, 4, PRO_LN, 12, 4>(a, Mp, st)));
+            else if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_fwd, dim3(s.n_seq * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0, r->cls_keep,
-                           s.heads, d);
+        hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0,
+                           r->cls_keep, s.heads, d, s.n_seq, s.L);
         TT_LAUNCHED();
         {
             GemmArgs a = gemm_args(c.attn_t, pw.out_w, d, d);
@@ -904,7 +968,9 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             a.M_real = s.M;
             // 32 x 64 workgroup tiles when they fit one round (K = 12 prompts: 5 x 48 = 240 workgroups, 160 instead of 192 rows of
             // f32-MFMA work -- this product is matrix-pipe-bound), else 48 x 48
-            if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
+            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && ((s.M + 15) / 16) * 3 < ((s.M + 31) / 32) * 4 && d / 4 / 16 == 12)
+                TT_TRY((launch_gemm_g<1, 4, PRO_LN, 12, 6>(a, Mp, st)));       // few rows: 16 x 96 tiles (7 x 32 = 224 workgroups)
+            else if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<2, 4, PRO_LN, 12, 4>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
@@ -964,7 +1030,9 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             GemmArgs a = gemm_args(c.dxa_t, pw.proj_w, 4 * d, d);
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
             a.M_real = s.M;
-            if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
+            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && ((s.M + 15) / 16) * 3 < ((s.M + 31) / 32) * 4 && d / 4 / 16 == 12)
+                TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 6>(a, Mp, st)));
+            else if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<2, 4, PRO_NONE, 12, 4>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_NONE, 12>(a, Mp, st)));
         }
@@ -981,8 +1049,8 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             a.Y = c.dattn; a.ldy = d;
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3(s.n_seq * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d, c.dqkv_t, r->seq_row0,
-                           r->cls_keep, s.heads, d);
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d,
+                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
         TT_LAUNCHED();
         {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);

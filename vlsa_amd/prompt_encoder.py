@@ -37,7 +37,7 @@ class _TTModel(ctypes.Structure):
 class _TTRows(ctypes.Structure):
     _fields_ = [("n_seq", ctypes.c_int), ("M", ctypes.c_int), ("M_pad", ctypes.c_int), ("max_len", ctypes.c_int),
                 ("row_seq", ctypes.c_void_p), ("row_pos", ctypes.c_void_p), ("row_src", ctypes.c_void_p),
-                ("seq_row0", ctypes.c_void_p), ("cls_keep", ctypes.c_void_p)]
+                ("seq_row0", ctypes.c_void_p), ("cls_keep", ctypes.c_void_p), ("prefix_len", ctypes.c_int)]
 
 
 # -- parameter holders with the reference's names (model/conch/transformer.py:191-247,290-322) ---------------------------
@@ -66,43 +66,59 @@ class _Transformer(nn.Module):
         self.resblocks = nn.ModuleList([_Block(width) for _ in range(layers)])
 
 
-def compact_rows(pseudo_tokens: torch.Tensor, ctx_len: int):
+def compact_rows(pseudo_tokens: torch.Tensor, ctx_len: int, prefix_len: int = 0):
     """Host-side row plan for a [n, ctx_len - 1] pseudo-token matrix (0 = pad).  The CLS row (appended last) may attend to
     column 0 and to column j + 1 for every non-pad token j (build_cls_mask, model/prompt_encoder.py:245-252: the pad mask is
     shifted right by one); token rows are causal.  Prompt s therefore needs positions 0..m_s (m_s = last column < ctx_len - 1
-    the CLS row can see) plus the CLS row.  Returns dict of int lists."""
+    the CLS row can see) plus the CLS row.
+
+    prefix_len = L > 0: the caller guarantees that positions 0 .. L-1 carry the same embedding in every prompt (<sot> and the
+    shared context tokens of the CoOp learners).  Under the causal mask those rows are identical in every layer, so they are
+    planned ONCE (rows 0 .. L-1) and prompt s keeps only positions L .. m_s + its CLS row; every CLS row must see all L prefix
+    positions (true for real tokens) and every prompt must reach past the prefix, else the plan falls back to L = 0.
+    Returns dict of int lists (+ 'prefix_len': the L actually used)."""
     pt = pseudo_tokens.detach().to("cpu")
-    n, L = pt.shape
-    if L != ctx_len - 1:
-        raise ValueError(f"expected {ctx_len - 1} token positions, got {L}")
-    row_seq, row_pos, row_src, seq_row0, cls_keep = [], [], [], [0], []
+    n, L_tok = pt.shape
+    if L_tok != ctx_len - 1:
+        raise ValueError(f"expected {ctx_len - 1} token positions, got {L_tok}")
+    keeps, ms = [], []
+    for s in range(n):
+        keep = [True] + [bool(v) for v in (pt[s] != 0).tolist()]          # keep[c]: CLS attends to column c (c = L_tok: itself)
+        keeps.append(keep)
+        ms.append(max(c for c in range(L_tok) if keep[c]))
+    L = int(prefix_len or 0)
+    if L > 0 and not (n > 1 and all(m >= L for m in ms) and all(all(k[:L]) for k in keeps)):
+        L = 0
+    row_seq, row_pos, row_src, seq_row0, cls_keep = [], [], [], [], []
+    for c in range(L):                                                    # the shared prefix, once
+        row_seq.append(0); row_pos.append(c); row_src.append(c); cls_keep.append(1)
+    seq_row0.append(len(row_seq))
     max_len = 0
     for s in range(n):
-        keep = [True] + [bool(v) for v in (pt[s] != 0).tolist()]          # keep[c]: CLS attends to column c (c = L: itself)
-        m = max(c for c in range(L) if keep[c])
-        for c in range(m + 1):
+        keep, m = keeps[s], ms[s]
+        for c in range(L, m + 1):
             row_seq.append(s); row_pos.append(c); row_src.append(c); cls_keep.append(1 if keep[c] else 0)
-        row_seq.append(s); row_pos.append(ctx_len - 1); row_src.append(-1); cls_keep.append(1 if keep[L] else 0)
+        row_seq.append(s); row_pos.append(ctx_len - 1); row_src.append(-1); cls_keep.append(1 if keep[L_tok] else 0)
         seq_row0.append(len(row_seq))
-        max_len = max(max_len, m + 2)
+        max_len = max(max_len, m + 2)                                     # keys of the prompt's CLS row incl. the prefix
     return dict(row_seq=row_seq, row_pos=row_pos, row_src=row_src, seq_row0=seq_row0, cls_keep=cls_keep, max_len=max_len,
-                n_seq=n, M=len(row_seq))
+                n_seq=n, M=len(row_seq), prefix_len=L)
 
 
 class _RowPlan:
     """Device copies of the compact-row tables + the C struct, cached per pseudo-token pattern."""
 
-    def __init__(self, pseudo_tokens, ctx_len, device):
-        rp = compact_rows(pseudo_tokens, ctx_len)
-        self.n_seq, self.M, self.max_len = rp["n_seq"], rp["M"], rp["max_len"]
-        self.M_pad = (self.M + 47) // 48 * 48
+    def __init__(self, pseudo_tokens, ctx_len, device, prefix_len=0):
+        rp = compact_rows(pseudo_tokens, ctx_len, prefix_len)
+        self.n_seq, self.M, self.max_len, self.prefix_len = rp["n_seq"], rp["M"], rp["max_len"], rp["prefix_len"]
+        self.M_pad = (self.M + 95) // 96 * 96      # whole 16-, 32- and 48-row workgroup tiles
         pad = self.M_pad - self.M
         i32 = lambda v, fill: torch.tensor(v + [fill] * pad, dtype=torch.int32).to(device)   # noqa: E731
         self.row_seq, self.row_pos, self.row_src = i32(rp["row_seq"], 0), i32(rp["row_pos"], 0), i32(rp["row_src"], -1)
         self.seq_row0 = torch.tensor(rp["seq_row0"], dtype=torch.int32).to(device)
         self.cls_keep = torch.tensor(rp["cls_keep"] + [0] * pad, dtype=torch.uint8).to(device)
         self.c = _TTRows(self.n_seq, self.M, self.M_pad, self.max_len, self.row_seq.data_ptr(), self.row_pos.data_ptr(),
-                         self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr())
+                         self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr(), self.prefix_len)
         self.ws = None    # inference workspace (no activations kept), allocated on first use
 
 
@@ -296,20 +312,23 @@ class CONCHPromptEncoder(nn.Module):
         self._pk, self._pk_key, self._pk_bwd = buf, key, bool(with_backward)
         return buf
 
-    def _plan(self, pseudo_tokens, device) -> _RowPlan:
+    def _plan(self, pseudo_tokens, device, prefix_len=0) -> _RowPlan:
         # fast path: the very tensor object (a learner's `pseudo_sentence_tokens` buffer) seen last time, unchanged in place;
         # otherwise keyed on CONTENT (the pattern of non-pad positions): `generate_pseudo_tokens` makes a new tensor per call
+        prefix_len = int(prefix_len or 0)
         last = self.__dict__.get("_plan_last")
-        if last is not None and last[0] is pseudo_tokens and last[1] == pseudo_tokens._version and last[2].row_seq.device == device:
+        if (last is not None and last[0] is pseudo_tokens and last[1] == pseudo_tokens._version and last[2].row_seq.device == device
+                and last[3] == prefix_len):
             return last[2]
-        key = (bytes((pseudo_tokens != 0).to("cpu", torch.uint8).contiguous().numpy().data), tuple(pseudo_tokens.shape), str(device))
+        key = (bytes((pseudo_tokens != 0).to("cpu", torch.uint8).contiguous().numpy().data), tuple(pseudo_tokens.shape), str(device),
+               prefix_len)
         plan = self._plans.get(key)
         if plan is None:
             if len(self._plans) > 16:
                 self._plans.clear()
-            plan = _RowPlan(pseudo_tokens, self.context_length, device)
+            plan = _RowPlan(pseudo_tokens, self.context_length, device, prefix_len)
             self._plans[key] = plan
-        self.__dict__["_plan_last"] = (pseudo_tokens, pseudo_tokens._version, plan)
+        self.__dict__["_plan_last"] = (pseudo_tokens, pseudo_tokens._version, plan, prefix_len)
         return plan
 
     # -- reference API ---------------------------------------------------------------------------------------------------
@@ -320,9 +339,12 @@ class CONCHPromptEncoder(nn.Module):
         pos = torch.arange(text.shape[1], device=text.device)[None, :]
         return torch.where(pos < first_pad[:, None], pos + 1, torch.zeros_like(pos)).to(text.dtype)
 
-    def forward(self, prompts_text=None, prompts_embedding=None, prompts_pseudo_tokens=None):
+    def forward(self, prompts_text=None, prompts_embedding=None, prompts_pseudo_tokens=None, shared_prefix_len=0):
         """prompts_text [n, 128] token ids (last slot = CLS placeholder) or prompts_embedding [n, 127, width] with
-        prompts_pseudo_tokens [n, 127] (0 = pad) -> [n, output_dim]   (model/prompt_encoder.py:267-322)."""
+        prompts_pseudo_tokens [n, 127] (0 = pad) -> [n, output_dim]   (model/prompt_encoder.py:267-322).
+        shared_prefix_len (beyond the reference's signature; 0 = off): the caller's promise that positions 0 .. L-1 hold the SAME
+        embedding in every prompt (what the CoOp learners produce: <sot> + shared context, ``learner.shared_prefix_len``); those
+        rows are then evaluated once for all prompts -- exact under the causal mask (see ``compact_rows``)."""
         L = self.context_length - 1
         if prompts_text is not None:
             assert prompts_text.shape[1] == L + 1, "Found invalid input of `prompts_text`."
@@ -341,5 +363,5 @@ class CONCHPromptEncoder(nn.Module):
         if torch.is_grad_enabled() and any(t.requires_grad for t in self._tower_tensors()):
             raise NotImplementedError("the text tower is frozen on this path (vlsa_txt_encoder_frozen: True): freeze its parameters; "
                                       "gradients are produced for prompts_embedding only")
-        plan = self._plan(prompts_pseudo_tokens, x.device)
+        plan = self._plan(prompts_pseudo_tokens, x.device, shared_prefix_len if prompts_text is None else 0)
         return _TextTowerFn.apply(x, self, plan)

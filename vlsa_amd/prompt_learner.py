@@ -188,6 +188,11 @@ class PlainPromptLearner(nn.Module):
             valid[i, :len(seq)] = True
         self.register_buffer("_order", order.to(dev), persistent=False)
         self.register_buffer("_valid", valid.to(dev), persistent=False)
+        # leading sentence positions that hold the same embedding in EVERY rank's sentence: <sot>, then the context tokens that
+        # come before the first rank token (all of them with the rank tokens at the tail, the first half in the middle position,
+        # none at the front) -- unless every rank has its own context.  The text tower evaluates those rows once.
+        lead = {"tail": C, "middle": C // 2, "front": 0}[position]
+        self.shared_prefix_len = 1 + (0 if rank_specific_context else lead)
 
     def _rank_rows(self) -> torch.Tensor:
         return self.rank_embeds                       # [num_ranks, T, dim]

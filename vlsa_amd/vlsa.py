@@ -210,8 +210,12 @@ class VLSA(nn.Module):
 
     def compute_text_features_with_coop(self, prompt_learner):
         """prompt learner's sentence embeddings through the text tower (model/vlsa.py:149-156)."""
+        from .prompt_encoder import CONCHPromptEncoder
+        extra = {}
+        if isinstance(self.prompt_encoder, CONCHPromptEncoder):      # the HIP tower evaluates the sentences' shared prefix once
+            extra["shared_prefix_len"] = int(getattr(prompt_learner, "shared_prefix_len", 0) or 0)
         return self.prompt_encoder(prompts_embedding=prompt_learner(),
-                                   prompts_pseudo_tokens=prompt_learner.pseudo_sentence_tokens)
+                                   prompts_pseudo_tokens=prompt_learner.pseudo_sentence_tokens, **extra)
 
     def _coop_text_features(self):
         return self.compute_text_features_with_coop(self.prompt_learner)
