@@ -192,6 +192,7 @@ class ShardedVlfanBatchPlan:
         self.done_local = [torch.cuda.Event(), torch.cuda.Event()]
         self.done_comm = [torch.cuda.Event(), torch.cuda.Event()]
         self.pipeline = pipeline
+        self.skip_exchange = False    # measurement aid (bench.py): leave the collective out -- timing of the local work only, results invalid
         self._pending = None
         self._i = 0
         self.lib = nat.load()
@@ -258,13 +259,15 @@ class ShardedVlfanBatchPlan:
         ab = self.attn[slot] if self.want_attn else None
         self._local(Q, slot, ab)
         if not self.pipeline:
-            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            if not self.skip_exchange:
+                all_gather_records(self.rec[slot], self.gathered[slot], self.group)
             self._tail(slot, T, logit_scale, W, b, pool_w, ab)
             return self.local.logits
         self.done_local[slot].record(cur)
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self.done_local[slot])
-            all_gather_records(self.rec[slot], self.gathered[slot], self.group)
+            if not self.skip_exchange:
+                all_gather_records(self.rec[slot], self.gathered[slot], self.group)
             self.done_comm[slot].record(self.comm_stream)
         if self._pending is not None:
             self._drain()
