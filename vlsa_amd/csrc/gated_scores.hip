@@ -146,6 +146,7 @@ struct GsBatch {
     // drop_thr = p * 2^32 (0: off), drop_scale = 1 / (1 - p); see dropout_bits()
     unsigned int drop_thr, drop_seed;
     float drop_scale;
+    unsigned int row_base;      // first row of this launch inside the bag's score array (a bag may be covered by two launches)
 };
 
 template <bool GATED, bool FULL, bool XF32, int RT = 16>
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     const long long row0 = (long long)tile * rows_per_tile;
     const int nrows = (int)((N - row0) < rows_per_tile ? (N - row0) : rows_per_tile);
     const GatedPrepLayout L(GATED ? 1 : 0);
-    const unsigned int rid0 = (unsigned int)row0;   // row index inside this bag's score array (dropout counter)
+    const unsigned int rid0 = bt.row_base + (unsigned int)row0;   // row index inside this bag's score array (dropout counter)
 
     // plain (compiler-tracked) loads only: weight fragments one step ahead (double-buffered registers; a 4-deep ring measured
     // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
@@ -360,6 +361,11 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
+static bool gs_round64() {
+    static const bool on = [] { const char* e = getenv("VLSA_GS_R64"); return e && atoi(e) == 1; }();   // (A/B hook; off: +-2 us either way, tools/gs_rows.py)
+    return on;
+}
+
 static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
                              float drop_p, unsigned int seed, void* stream) {
     if (!X || !prep || !a || N < 1 || ldx < D) return VLSA_EINVAL;
@@ -378,25 +384,17 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         (void)hipFuncSetAttribute((const void*)k_gated_scores<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
         (void)hipFuncSetAttribute((const void*)k_gated_scores<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gs::kLds32);
     }
-    // rows per tile.  One round of the 256 CUs covers 2 halves x 128 tiles: bags that fit (N <= 32768) use the smallest multiple
-    // of 16 rows that still fits one round (a 2 798-patch bag runs as 2 x 88 tiles of 32 rows instead of 2 x 11 of 256);
-    // larger bags use the static 256-row kernel (predicated tiles measured slower there than the rounding loss).
+    // Rows per tile.  One round of the 256 CUs covers 2 halves x 128 tiles.  A bag that fits one round (N <= 128 tiles of the
+    // largest height) uses the smallest multiple of 16 rows that still fits it (a 2 798-patch bag runs as 2 x 88 tiles of 32
+    // rows instead of 2 x 11 of 256).  A larger bag is covered by TWO launches: whole rounds of the static 256-row kernel
+    // (every CU busy, every tile full), then the remainder as one more single-round launch with its own, smaller tile height --
+    // instead of a last round in which 256-row tiles occupy a fraction of the CUs for a full tile time (50k patches: 1.53
+    // rounds were paid as 2).
     const int max_rows = (f32 && gated) ? 128 : gs::kRows;     // gated fp32: 8 row tiles per workgroup (register budget)
-    int rows_per_tile = max_rows;
-    if (N <= 128 * (int64_t)max_rows) {
-        rows_per_tile = (int)(((N + 127) / 128 + 15) / 16 * 16);
-        if (rows_per_tile > max_rows) rows_per_tile = max_rows;
-    }
-    if (const char* e = getenv("VLSA_GS_ROWS")) {          // experiment hook (tools/kbench_gated.py): force the tile height
-        const int v = atoi(e);
-        if (v >= 16 && v <= max_rows && v % 16 == 0) rows_per_tile = v;
-    }
-    const bool full = rows_per_tile == max_rows;
-    const unsigned int tiles = (unsigned int)((N + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-    GsBatch dropb{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f};
+    GsBatch dropb{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f, 0u};
     if (gated && drop_p > 0.f) {
         if (!(drop_p < 1.f)) return VLSA_EINVAL;
         dropb.drop_thr = (unsigned int)((double)drop_p * 4294967296.0);
@@ -404,17 +402,45 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         dropb.drop_seed = seed;
         dropb.drop_scale = 1.f / (1.f - drop_p);
     }
-#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb)
-    if (f32) {
-        if (gated) {
-            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb);
-            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, X, (long long)N, (long long)ldx, pp, a, rows_per_tile, dropb);
-        } else { if (full) VLSA_GS(false, true, true); else VLSA_GS(false, false, true); }
-    } else {
-        if (gated) { if (full) VLSA_GS(true, true, false); else VLSA_GS(true, false, false); }
-        else       { if (full) VLSA_GS(false, true, false); else VLSA_GS(false, false, false); }
+    const int64_t round_rows = 128 * (int64_t)max_rows;
+    static const bool split = [] { const char* e = getenv("VLSA_GS_SPLIT"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    int64_t seg_rows[2] = {N, 0};
+    if (split && N > round_rows && N % round_rows != 0) {
+        seg_rows[0] = N / round_rows * round_rows;
+        seg_rows[1] = N - seg_rows[0];
     }
+    int64_t off = 0;
+    for (int sgi = 0; sgi < 2 && seg_rows[sgi] > 0; ++sgi) {
+        const int64_t n = seg_rows[sgi];
+        int rows_per_tile = max_rows;
+        if (n <= round_rows) {
+            rows_per_tile = (int)(((n + 127) / 128 + 15) / 16 * 16);
+            // (optional: whole groups of four 16-row tiles above 64 rows -- helps 30k / 60k patches, hurts 10k / 20k / 50k)
+            if (rows_per_tile > 64 && gs_round64()) rows_per_tile = (rows_per_tile + 63) / 64 * 64;
+            if (rows_per_tile > max_rows) rows_per_tile = max_rows;
+        }
+        if (const char* e = getenv("VLSA_GS_ROWS")) {          // experiment hook (tools/gs_rows.py): force the tile height
+            const int v = atoi(e);
+            if (v >= 16 && v <= max_rows && v % 16 == 0) rows_per_tile = v;
+        }
+        const bool full = rows_per_tile == max_rows;
+        const unsigned int tiles = (unsigned int)((n + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)
+        const void* Xs = static_cast<const unsigned char*>(X) + off * ldx * esz;
+        float* as = a + off;
+        dropb.row_base = (unsigned int)off;
+#define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
+        if (f32) {
+            if (gated) {
+                if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+                else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+            } else { if (full) VLSA_GS(false, true, true); else VLSA_GS(false, false, true); }
+        } else {
+            if (gated) { if (full) VLSA_GS(true, true, false); else VLSA_GS(true, false, false); }
+            else       { if (full) VLSA_GS(false, true, false); else VLSA_GS(false, false, false); }
+        }
 #undef VLSA_GS
+        off += n;
+    }
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
@@ -458,7 +484,7 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const bool full = rows_per_tile == max_rows;
     const unsigned int tiles = (unsigned int)n_tiles * gs::kHalves;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
-    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f};
+    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
     if (f32) {
         if (gated) { if (full) VLSA_GSB(true, true, true, 8); else VLSA_GSB(true, false, true, 8); }
