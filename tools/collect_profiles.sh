@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): full GPU test suite, bench lines, rocprofv3 kernel stats of the bench command, separate PMC
-# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r02/ (copied into profiles/ afterwards).
+# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r03/ (copied into profiles/ afterwards).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02; mkdir -p $O
+O=gpurun_out/r03; mkdir -p $O
 (timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench.err
@@ -102,5 +102,39 @@ python tools/bench_module.py > $O/bench_module.txt 2>&1
 python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2>/dev/null
+# ---- round 3: backward kernels of the N-sized layers, attention-weights traffic, text tower with the shared prefix
+python tools/kbench_mlp_bwd.py > $O/kbench_mlp_bwd.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/mb -- python tools/run_mlp_bwd.py 50000 > /dev/null 2>&1
+cp $(find $O/mb -name "*kernel_stats.csv" | head -1) $O/mlp_bwd_kernel_stats.csv
+pmc mb_a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_mlp_bwd_one.py 50000 gated
+pmc mb_b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE -- python tools/run_mlp_bwd_one.py 50000 gated
+pmc mb_c FETCH_SIZE -- python tools/run_mlp_bwd_one.py 50000 gated
+pmc mb_d WRITE_SIZE -- python tools/run_mlp_bwd_one.py 50000 gated
+pmc at_f FETCH_SIZE -- python tools/run_batch_attn.py
+pmc at_w WRITE_SIZE -- python tools/run_batch_attn.py
+python - <<PY
+import csv, glob, collections, json
+def collect(tags, pats):
+    out = {}
+    for tag in tags:
+        fs = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
+        if not fs: continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(fs[0])):
+            for p in pats:
+                if p in r["Kernel_Name"]:
+                    acc[p][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for p, cs in acc.items():
+            for k, v in cs.items():
+                v = v[3:] or v
+                out.setdefault(p, {})[k] = sum(v) / len(v)
+    return out
+json.dump(collect(("mb_a", "mb_b", "mb_c", "mb_d"), ["k_mlp_backward"]), open("$O/pmc_mlp_backward_gated.json", "w"), indent=1)
+json.dump(collect(("at_f", "at_w"), ["k_vlfan_partial_dma_batch<true>", "k_attn_normalise_batch", "k_vlfan_merge_pool_batch"]),
+          open("$O/pmc_batch_attn_traffic.json", "w"), indent=1)
+PY
+rm -rf $O/mb $O/pmc_mb_a $O/pmc_mb_b $O/pmc_mb_c $O/pmc_mb_d $O/pmc_at_f $O/pmc_at_w
+python tools/bench_text.py --no-prefix 2>&1 | tail -2 > $O/bench_text_noprefix.txt
+for n in 40000 50000 70000 100000; do for sp in 0 1; do VLSA_GS_SPLIT=$sp python tools/gs_rows.py $n 2>/dev/null | sed "s/$/ split=$sp/"; done; done > $O/gs_split.txt
 rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
 cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; cut -c1-200 $O/bench_driver_args.json; cat $O/pmc_gated_scores.json | head -30

@@ -843,11 +843,43 @@ class FusedAttnScores:
         return a
 
 
+class _PinnedRing:
+    """Small ring of pinned int64 staging buffers for the descriptor tables of the multi-bag kernels: the upload is an ASYNC copy
+    on the current stream (a pageable `.to(device)` blocks the host for tens of microseconds per call); a slot is reused only after
+    the copy that read it has completed (event)."""
+
+    def __init__(self, slots: int = 8, words: int = 1024):
+        self.slots, self.words, self.bufs, self.events, self.i = slots, words, None, None, 0
+
+    def stage(self, host_np, device):
+        import numpy as np
+        n = int(host_np.shape[0])
+        if n > self.words or not torch.cuda.is_available():
+            return torch.from_numpy(np.ascontiguousarray(host_np)).to(device)
+        if self.bufs is None:
+            self.bufs = [torch.empty(self.words, dtype=torch.int64).pin_memory() for _ in range(self.slots)]
+            self.events = [None] * self.slots
+        k = self.i % self.slots
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.bufs[k].numpy()[:n] = host_np
+        dev = self.bufs[k][:n].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[k] = ev
+        return dev
+
+
+_TABLE_RING = {}     # per host thread (autograd runs backward functions on its own thread)
+
+
 def _row_tables(bags, tile_rows: int, extra=None):
     """ONE upload for the tables the multi-bag backward kernels take: vlsa_bag_desc [B, 3] (pointer, N, row stride), optionally a
     second table (``extra``: e.g. the gradient rows), row offsets [B] (int64) and tile_start [B + 1] (int32, tiles of
     ``tile_rows`` rows).  Returns (device buffer, ptr of desc, ptr of extra desc or None, ptr of row_off, ptr of tile_start,
     n_tiles, row offsets as a list)."""
+    import threading
     import numpy as np
     B = len(bags)
     rows = [int(x.shape[0]) for x in bags]
@@ -865,7 +897,8 @@ def _row_tables(bags, tile_rows: int, extra=None):
     ts[0] = 0
     np.cumsum([(n + tile_rows - 1) // tile_rows for n in rows], out=ts[1:B + 1])
     n_tiles = int(ts[B])
-    dev = torch.from_numpy(host).to(bags[0].device)
+    ring = _TABLE_RING.setdefault(threading.get_ident(), _PinnedRing())
+    dev = ring.stage(host, bags[0].device)
     base = dev.data_ptr()
     p_extra = base + 24 * B if extra is not None else None
     p_off = base + 8 * o
