@@ -155,6 +155,21 @@ int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, i
                            float* pacc, int G, float* m2, float* l, float* out, float* scores, float* A, void* head_ws,
                            float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
 
+/* The per-bag backward of the same step -- what autograd runs per bag behind `torch.cat([net(x)[0] for x in bags])` in the
+ * reference's training loop (runner/vlsa_handler.py:267-289; model/vlsa.py:181-198, model/deepmil.py:187-204 differentiated) --
+ * as ONE host call: vlsa_head_backward_batch (B = 1) -> d rows, dW, db, dT, d logit_scale; vlsa_vlfan_backward + the
+ * unnormalised vlsa_vlfan_merge -> d e [P, D]; the chain rule through e_p = q^_p - gated q^_gate, q^ = q / |q| -> dQ [nq, D].
+ * Inputs are what vlsa_vlfan_forward_bag (pool_mode = mean) left behind for this bag: qprep / That / tnorm (prepared block),
+ * out / m2 / l (aggregation), pooled / vhat / vnorm / logits (head).  g_vhat [D] / g_That [K, D]: gradients into the returned
+ * unit features, or NULL.  W NULL = identity adapter (dW, db unused).  Scratch: head_ws (D + 1 floats), bwd_prep
+ * (vlsa_bwd_prep_bytes), pm / pl ((G + 1) * 16 floats each), pacc (G * P * D floats), G = vlsa_num_partials(N). */
+int vlsa_vlfan_backward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int nq, int gated,
+                            float coattn_scale, const float* dlogits, const float* g_vhat, const float* g_That,
+                            const float* pooled, const float* vhat, const float* vnorm, const float* That, const float* tnorm,
+                            const float* logits, const float* W, const float* logit_scale, const float* out, const float* m2,
+                            const float* l, int K, float* head_ws, float* drows, float* dW, float* db, float* dT, float* dls,
+                            void* bwd_prep, float* pm, float* pl, float* pacc, int G, float* dE, float* dQ, void* stream);
+
 /* ---- batched forward: B bags per launch ------------------------------------------------------------------- */
 
 /* One bag of a batch (device-resident array of these is passed to vlsa_vlfan_forward_batch). */

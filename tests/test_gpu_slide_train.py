@@ -1,0 +1,148 @@
+"""The per-bag TRAINING route (``VLSA.forward`` with a gradient needed -> ``VF.slide_train``: one autograd node per bag over
+``vlsa_vlfan_forward_bag`` / ``vlsa_vlfan_backward_bag``) -- the loop shape of the reference's handler
+(runner/vlsa_handler.py:267-289: one ``net(X)`` per bag, ``torch.cat``, ONE backward).
+
+The values and gradients of that route are pinned against the reference-generated fixtures by
+tests/test_gpu_modules.py::test_vlsa_vlfan_forward_backward (every mean-pooling case now takes it) and
+tests/test_gpu_handler_loop.py; here: that the route IS taken, that it agrees with the general autograd route and with the
+batched one on a handler-shaped step of ragged bags, gradients through the returned unit features, and the case of a backward
+that runs after the plan's prepared block has moved on."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import helpers as H
+from test_gpu_modules import build_vlsa
+
+pytestmark = pytest.mark.gpu
+
+CASE = ("n2798_shipped", 2798, 12, 12, "mean", "default", False, "iid", 105, True)
+GATED = ("n300_gatedq", 300, 8, 8, "mean", "default", True, "iid", 109, True)
+IDENT = ("n4096_p13_id", 4096, 13, 4, "mean", "Identity", False, "iid", 106, True)
+
+
+def _model(case):
+    X, params, pool = H.vlfan_case_inputs(case)
+    model, tp = build_vlsa(case, params, pool)
+    return model.train(), tp
+
+
+def _trainable(model, tp):
+    enc = model.mil_encoder
+    out = {"logit_scale": model.logit_scale, "T": tp.T}
+    if isinstance(enc.visual_adapter, torch.nn.Linear):
+        out["W"], out["b"] = enc.visual_adapter.weight, enc.visual_adapter.bias
+    out["Q"] = enc.Q if isinstance(enc.Q, torch.nn.Parameter) else enc.Q.residual_features
+    return out
+
+
+def _grads(model, tp):
+    g = {k: p.grad.detach().clone() for k, p in _trainable(model, tp).items()}
+    model.zero_grad(set_to_none=True)
+    tp.zero_grad(set_to_none=True)
+    return g
+
+
+def _close(a, b, what, rtol=2e-3):
+    a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+    assert np.abs(a - b).max() <= rtol * np.abs(b).max() + 2e-6, (what, np.abs(a - b).max(), np.abs(b).max())
+
+
+def _bags(sizes, dtype, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(n, 512, generator=g) + 0.3).to(dtype).cuda() for n in sizes]
+
+
+def test_the_route_is_taken_and_only_when_a_gradient_is_needed():
+    model, tp = _model(CASE)
+    X = _bags([700], torch.bfloat16)[0][None]
+    out = model(X)
+    assert type(out[0].grad_fn).__name__ == "_SlideTrainFnBackward"
+    assert out[0].shape == (1, 12) and out[1].shape == (1, 512) and out[2].shape == (12, 512)
+    with torch.no_grad():
+        ev = model(X)
+    assert ev[0].grad_fn is None
+    assert np.abs(ev[0].cpu().numpy() - out[0].detach().cpu().numpy()).max() < 2e-5
+    # a bag that carries a gradient itself is not this route's business
+    Xg = X.float().clone().requires_grad_(True)
+    assert type(model(Xg)[0].grad_fn).__name__ != "_SlideTrainFnBackward"
+
+
+@pytest.mark.parametrize("case", [CASE, GATED, IDENT], ids=["shipped", "gated_query", "identity_head"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_handler_shaped_step_equals_the_general_and_the_batched_route(case, dtype, monkeypatch):
+    model, tp = _model(case)
+    K = case[3]
+    bags = _bags([1, 37, 300, 2798, 6001, 64], dtype)
+    Gm = torch.randn(len(bags), K, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def step():
+        logits = torch.cat([model(x[None])[0] for x in bags], dim=0)
+        (logits * Gm).sum().backward()
+        return logits.detach().clone(), _grads(model, tp)
+
+    fast_logits, fast = step()
+    # the batched route (persistent multi-bag kernels + batched head)
+    lb = model.forward_bags(bags)[0]
+    (lb * Gm).sum().backward()
+    batched = _grads(model, tp)
+    # the general per-bag route (autograd over the aggregation function + torch ops)
+    monkeypatch.setattr(type(model), "_slide_train", lambda self, X, T: None)
+    gen_logits, general = step()
+    assert np.abs(fast_logits.cpu().numpy() - gen_logits.cpu().numpy()).max() < 1e-4
+    assert np.abs(fast_logits.cpu().numpy() - lb.detach().cpu().numpy()).max() < 1e-4
+    for k in general:
+        _close(fast[k], general[k], f"{k} vs general")
+        _close(fast[k], batched[k], f"{k} vs batched")
+
+
+def test_gradients_through_the_returned_unit_features(monkeypatch):
+    model, tp = _model(CASE)
+    X = _bags([900], torch.float32)[0][None]
+    gen = torch.Generator().manual_seed(11)
+    gv, gt, gl = torch.randn(1, 512, generator=gen).cuda(), torch.randn(12, 512, generator=gen).cuda(), torch.randn(1, 12, generator=gen).cuda()
+
+    def run():
+        logits, img, txt = model(X)
+        ((logits * gl).sum() + (img * gv).sum() + (txt * gt).sum()).backward()
+        return _grads(model, tp)
+
+    fast = run()
+    monkeypatch.setattr(type(model), "_slide_train", lambda self, X, T: None)
+    general = run()
+    for k in general:
+        _close(fast[k], general[k], k)
+
+
+def test_backward_after_the_prepared_block_has_moved_on(monkeypatch):
+    """forward(bag A) -> the query parameters change in place -> forward(bag B) re-prepares the plan's block -> the backward of
+    A's loss must still use A's queries (its block is rebuilt from the tensors the node saved)."""
+    model, tp = _model(CASE)
+    A, Bb = (x[None] for x in _bags([500, 800], torch.bfloat16))
+    gl = torch.randn(1, 12, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run():
+        la = model(A)[0]
+        with torch.no_grad():
+            model.mil_encoder.Q.residual_features.add_(0.05)
+        lb = model(Bb)[0]
+        (la * gl).sum().backward()
+        ga = _grads(model, tp)
+        (lb * gl).sum().backward()
+        gb = _grads(model, tp)
+        with torch.no_grad():                      # back to the start for the second run
+            model.mil_encoder.Q.residual_features.sub_(0.05)
+        return la.detach().clone(), lb.detach().clone(), ga, gb
+
+    la, lb, ga, gb = run()
+    plan = next(iter(model._train_plans.values()))
+    assert plan.gen >= 2                           # bag B did re-prepare
+    monkeypatch.setattr(type(model), "_slide_train", lambda self, X, T: None)
+    la2, lb2, ga2, gb2 = run()
+    assert np.abs(la.cpu().numpy() - la2.cpu().numpy()).max() < 1e-4
+    assert np.abs(lb.cpu().numpy() - lb2.cpu().numpy()).max() < 1e-4
+    assert np.abs(la.cpu().numpy() - lb.cpu().numpy()).max() > 1e-3      # the edit matters
+    for k in ga2:
+        _close(ga[k], ga2[k], f"A:{k}")
+        _close(gb[k], gb2[k], f"B:{k}")

@@ -66,6 +66,30 @@ for label, sizes in (("TCGA-like 2k-12k", [int(x) for x in torch.randint(2000, 1
     torch.cuda.synchronize()
     tt = (time.perf_counter() - t0) / 20
     npatch = sum(sizes)
+
+    # the handler's own loop shape (runner/vlsa_handler.py:267-289): one net(X) per bag, cat, loss, ONE backward
+    def hstep():
+        logits = torch.cat([net(x[None])[0] for x in bags], dim=0)
+        loss = objective(logits, t, e, net.get_logit_scale())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(5):
+        hstep()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(R):
+        hstep()
+    torch.cuda.synchronize()
+    dth = (time.perf_counter() - t0) / R
+    print(f"{label}: handler-shaped step (32 x net(X), cat, one backward): {dth * 1e3:.2f} ms")
+    if "--profile-handler" in sys.argv:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(10):
+            hstep()
+        pr.disable(); torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(40)
     if "--profile" in sys.argv:       # host side of one step (the GPU work of a small-bag step is ~2.4 ms: is the host the limit?)
         import cProfile, pstats
         t0 = time.perf_counter()

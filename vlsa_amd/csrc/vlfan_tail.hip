@@ -715,3 +715,70 @@ extern "C" int vlsa_head_backward_batch(const float* dlogits, const float* g_vha
                        tnorm, logit_scale, dls_part, B, P, D, K, dW, db, drows, dT, dls);
     return launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Per-bag TRAINING step as the reference's handler issues it (runner/vlsa_handler.py:267-289: one net(X) per bag, the predictions
+// concatenated, ONE backward): the forward is vlsa_vlfan_forward_bag with per-call result buffers, the backward of one bag is
+// the head backward (B = 1), the streaming backward pass of the aggregation, its reduction and the chain rule back to the raw
+// queries -- six launches behind ONE host call (that loop is bound by the host side of its ~64 autograd nodes per step).
+namespace vlsa {
+// dQ from d e:  e_p = q^_p - gated * q^_gate,  q^ = q / max(|q|, 1e-12)   (model/deepmil.py:187-193).  block = one query row.
+__global__ __launch_bounds__(256) void k_query_chain(const float* __restrict__ dE, const float* __restrict__ qhat,
+                                                      const float* __restrict__ qnorm, int P, int D, float* __restrict__ dQ) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float d[VLSA_MAX_D / 256];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+        const int c = tid + 256 * i;
+        float v = 0.f;
+        if (c < D) {
+            if (row < P) {
+                v = dE[(size_t)row * D + c];
+            } else {   // the gate row: every effective query carries - q^_gate
+                for (int p = 0; p < P; ++p) v -= dE[(size_t)p * D + c];
+            }
+            dot += v * qhat[(size_t)row * D + c];
+        }
+        d[i] = v;
+    }
+    dot = block_sum_256(dot, red);
+    const float inv = 1.f / qnorm[row];
+#pragma unroll
+    for (int i = 0; i < VLSA_MAX_D / 256; ++i) {
+        const int c = tid + 256 * i;
+        if (c < D) dQ[(size_t)row * D + c] = (d[i] - qhat[(size_t)row * D + c] * dot) * inv;
+    }
+}
+}  // namespace vlsa
+
+extern "C" int vlsa_vlfan_backward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int nq, int gated,
+                                       float coattn_scale, const float* dlogits, const float* g_vhat, const float* g_That,
+                                       const float* pooled, const float* vhat, const float* vnorm, const float* That,
+                                       const float* tnorm, const float* logits, const float* W, const float* logit_scale,
+                                       const float* out, const float* m2, const float* l, int K, float* head_ws, float* drows, float* dW,
+                                       float* db, float* dT, float* dls, void* bwd_prep, float* pm, float* pl, float* pacc, int G,
+                                       float* dE, float* dQ, void* stream) {
+    if (!qprep || !dE || !dQ || nq < 1) return VLSA_EINVAL;
+    const int P = gated ? nq - 1 : nq;
+    if (G != vlsa_num_partials(N)) return VLSA_EINVAL;
+    int rc = vlsa_head_backward_batch(dlogits, g_vhat, g_That, pooled, vhat, vnorm, That, tnorm, logits, W, logit_scale, 1, P, D, K,
+                                      head_ws, drows, dW, db, dT, dls, stream);
+    if (rc != VLSA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (N > 0) {
+        rc = vlsa_vlfan_backward(X, x_dtype, N, ldx, D, qprep, P, coattn_scale, drows, out, m2, l, bwd_prep, pm, pl, pacc, stream);
+        if (rc != VLSA_OK) return rc;
+        // the unnormalised merge also hands back (max, sum) of the partials' bookkeeping columns: parked behind the partials
+        rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 0, pm + (size_t)G * vlsa::kPStride, pl + (size_t)G * vlsa::kPStride, dE, stream);
+        if (rc != VLSA_OK) return rc;
+    } else {
+        if (hipMemsetAsync(dE, 0, (size_t)P * D * sizeof(float), s) != hipSuccess) return VLSA_ELAUNCH;
+    }
+    const vlsa::QPrepLayout L(D);
+    const unsigned char* qp = static_cast<const unsigned char*>(qprep);
+    hipLaunchKernelGGL(vlsa::k_query_chain, dim3(nq), dim3(256), 0, s, dE, reinterpret_cast<const float*>(qp + L.qhat),
+                       reinterpret_cast<const float*>(qp + L.qnorm), P, D, dQ);
+    return launch_status();
+}

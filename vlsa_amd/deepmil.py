@@ -114,6 +114,38 @@ class VLFAN(nn.Module):
         assert self.Q is not None, f"You have to call `reset_query` to reset query for query_type ({self.query_type})."
         return self.Q() if callable(self.Q) else self.Q
 
+    def step_query(self):
+        """``get_query()`` for the per-bag training path: when the queries come from a module (the text PromptAdapter), its
+        output -- WITH its autograd graph -- is shared by all bags that see the same parameter versions, train / eval flag and
+        grad mode (the reference's step evaluates the adapter once per bag: runner/vlsa_handler.py:267-269; same values, 32 x
+        the launches and autograd nodes).  A backward pass through the cached tensor frees that graph: the next call rebuilds."""
+        Qs = self.Q
+        if not isinstance(Qs, nn.Module):
+            return self.get_query()
+        key = [torch.is_grad_enabled()]
+        stack = [Qs]
+        while stack:
+            m = stack.pop()
+            key.append((id(m), m.training))
+            for t in m._parameters.values():
+                if t is not None:
+                    key.append((id(t), t._version, t.requires_grad))
+            for t in m._buffers.values():
+                if t is not None:
+                    key.append((id(t), t._version))
+            stack.extend(c for c in m._modules.values() if c is not None)
+        key = tuple(key)
+        cached = getattr(self, "_step_query", None)
+        if cached is None or cached[0] != key:
+            q = self.get_query()
+            if q.requires_grad and q.grad_fn is not None:
+                q.register_hook(self._drop_step_query)
+            cached = self._step_query = (key, q)
+        return cached[1]
+
+    def _drop_step_query(self, *_):
+        self._step_query = None
+
     def query_div_loss(self, last_div=True, **kws):
         """Diversity penalty on the queries = mean |cosine| (model/deepmil.py:157-168): between the gate query (last row)
         and every other query when there is one and ``last_div``; otherwise over all ordered pairs of distinct queries."""

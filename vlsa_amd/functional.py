@@ -297,6 +297,127 @@ def debug_probe(which: int, device="cuda") -> torch.Tensor:
     return out
 
 
+class SlideTrainPlan:
+    """Scratch and the prepared (queries, text features) block of the per-bag TRAINING path: ``slide_train`` is what
+    ``VLSA.forward`` runs for one bag when a gradient is needed and the encoder is a VLFAN with mean query pooling -- the loop
+    shape of the reference's handler (runner/vlsa_handler.py:267-289: one ``net(X)`` per bag, predictions concatenated, ONE
+    backward).  That loop is bound by the host side of its autograd nodes, so a bag costs ONE autograd node, one Python -> C
+    crossing and one allocation each way (``vlsa_vlfan_forward_bag`` / ``vlsa_vlfan_backward_bag``).  The prepared block
+    (normalised / split queries, unit text features) is rebuilt only when the query or text-feature TENSOR changes: all bags of
+    a step share both.  Everything is stream-ordered on the caller's stream; any bag size (scratch is sized for 256 partials)."""
+
+    def __init__(self, D: int, P: int, K: int, device, gated: bool, identity_head: bool, coattn_scale: float):
+        lib = nat.load()
+        self.lib, self.D, self.P, self.K = lib, int(D), int(P), int(K)
+        self.nq, self.gated, self.identity_head, self.scale = int(P) + (1 if gated else 0), bool(gated), bool(identity_head), float(coattn_scale)
+        G = int(lib.vlsa_num_partials(1 << 40))
+        f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=device)  # noqa: E731
+        self.qprep = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=device)
+        self.That, self.tnorm = f(K, D), f(K)
+        self.pm, self.pl, self.pacc = f(G + 1, nat.P_STRIDE), f(G + 1, nat.P_STRIDE), f(G, P, D)
+        self.head_ws = torch.zeros(lib.vlsa_head_workspace_bytes(D), dtype=torch.uint8, device=device)
+        self.bwd_prep = torch.empty(lib.vlsa_bwd_prep_bytes(D), dtype=torch.uint8, device=device)
+        self.hws = f(D + 4)
+        self._c = {k: getattr(self, k).data_ptr() for k in ("qprep", "That", "tnorm", "pm", "pl", "pacc", "head_ws", "bwd_prep", "hws")}
+        self.gen, self._src, self._That_out = 0, None, None
+        # float offsets of the per-call record: out | m2 | l | pooled | v | vhat | vnorm | logits
+        o, self.off = 0, {}
+        for name, n in (("out", P * D), ("m2", 16), ("l", 16), ("pooled", D), ("v", D), ("vhat", D), ("vnorm", 4), ("logits", (K + 3) // 4 * 4)):
+            self.off[name] = o
+            o += n
+        self.rec_floats = o
+        # ... and of the per-call gradient block: dQ | dW | db | dT | dls | drows | dE
+        o, self.goff = 0, {}
+        for name, n in (("dQ", self.nq * D), ("dW", 0 if identity_head else D * D), ("db", 0 if identity_head else D), ("dT", K * D), ("dls", 4),
+                        ("drows", P * D), ("dE", P * D)):
+            self.goff[name] = o
+            o += n
+        self.grad_floats = o
+
+    def prepared_for(self, Q: torch.Tensor, T: torch.Tensor) -> bool:
+        src = self._src
+        return src is not None and src[0] is Q and src[1] is T and src[2] == Q._version and src[3] == T._version
+
+    def mark_prepared(self, Q, T):
+        self._src = (Q, T, Q._version, T._version)      # the tensors are kept alive: their identity is the key
+        self.gen += 1
+        self._That_out = None
+
+    def unit_text(self):
+        if self._That_out is None:
+            self._That_out = self.That.clone()          # one copy per preparation, shared (read-only) by every bag's output
+        return self._That_out.detach()
+
+
+class _SlideTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X2, Q, W, b, T, logit_scale, plan):
+        lib, s, c, off = plan.lib, _stream(), plan._c, plan.off
+        N = X2.shape[0]
+        dev = X2.device
+        rec = torch.empty(plan.rec_floats, dtype=torch.float32, device=dev)
+        base = rec.data_ptr()
+        fresh = not plan.prepared_for(Q, T)
+        G = int(lib.vlsa_num_partials(N))
+        at = lambda name: base + 4 * off[name]  # noqa: E731
+        nat.check(lib.vlsa_vlfan_forward_bag(_p(X2), _dt(X2), N, X2.stride(0), plan.D, _p(Q) if fresh else None, plan.nq, int(plan.gated),
+                                             plan.scale, _p(T), plan.K, _p(logit_scale), nat.POOL_MEAN, None, _p(W), _p(b), nat.KERNEL_AUTO,
+                                             c["qprep"], c["That"], c["tnorm"], c["pm"], c["pl"], c["pacc"], G, at("m2"), at("l"),
+                                             at("out"), None, None, c["head_ws"], at("pooled"), at("v"), at("vhat"), at("vnorm"),
+                                             at("logits"), None, s), "vlsa_vlfan_forward_bag")
+        if fresh:
+            plan.mark_prepared(Q, T)
+        ctx.plan, ctx.gen, ctx.has = plan, plan.gen, (W is not None, b is not None, tuple(logit_scale.shape))
+        ctx.save_for_backward(X2, Q, T, rec, logit_scale, *([W] if W is not None else []))
+        K, D = plan.K, plan.D
+        return rec[off["logits"]:off["logits"] + K].view(1, K), rec[off["vhat"]:off["vhat"] + D].view(1, D), plan.unit_text()
+
+    @staticmethod
+    def backward(ctx, dlogits, g_vhat, g_That):
+        plan = ctx.plan
+        lib, s, c, off, goff = plan.lib, _stream(), plan._c, plan.off, plan.goff
+        X2, Q, T, rec, ls = ctx.saved_tensors[:5]
+        has_w, has_b, ls_shape = ctx.has
+        W = ctx.saved_tensors[5] if has_w else None
+        N, dev, K, D, P, nq = X2.shape[0], X2.device, plan.K, plan.D, plan.P, plan.nq
+        qprep, That, tnorm = c["qprep"], c["That"], c["tnorm"]
+        keep = None
+        if plan.gen != ctx.gen:
+            # the plan's prepared block has moved on (another forward with new queries / text features ran before this backward):
+            # rebuild this bag's block from the saved tensors
+            keep = (torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=dev), torch.empty(K, D, dtype=torch.float32, device=dev),
+                    torch.empty(K, dtype=torch.float32, device=dev))
+            nat.check(lib.vlsa_prepare_queries_and_text(_p(Q), nq, D, int(plan.gated), plan.scale, _p(keep[0]), _p(T), K, _p(keep[1]),
+                                                        _p(keep[2]), s), "vlsa_prepare_queries_and_text")
+            qprep, That, tnorm = (t.data_ptr() for t in keep)
+        gb = torch.empty(plan.grad_floats, dtype=torch.float32, device=dev)
+        gbase, base = gb.data_ptr(), rec.data_ptr()
+        at = lambda name: base + 4 * off[name]  # noqa: E731
+        gat = lambda name: gbase + 4 * goff[name]  # noqa: E731
+        dl = _f32c(dlogits) if dlogits is not None else torch.zeros(1, K, dtype=torch.float32, device=dev)
+        gv = None if g_vhat is None else _f32c(g_vhat)
+        gt = None if g_That is None else _f32c(g_That)
+        G = int(lib.vlsa_num_partials(N))
+        nat.check(lib.vlsa_vlfan_backward_bag(_p(X2), _dt(X2), N, X2.stride(0), D, qprep, nq, int(plan.gated), plan.scale, _p(dl), _p(gv), _p(gt),
+                                              at("pooled"), at("vhat"), at("vnorm"), That, tnorm, at("logits"), _p(W), _p(ls), at("out"),
+                                              at("m2"), at("l"), K, c["hws"], gat("drows"), gat("dW") if has_w else None,
+                                              gat("db") if has_w else None, gat("dT"), gat("dls"), c["bwd_prep"], c["pm"], c["pl"], c["pacc"], G,
+                                              gat("dE"), gat("dQ"), s), "vlsa_vlfan_backward_bag")
+        def v(name, n, *sh):
+            return gb[goff[name]:goff[name] + n].view(*sh)
+        return (None, v("dQ", nq * D, nq, D), v("dW", D * D, D, D) if has_w else None, v("db", D, D) if (has_w and has_b) else None,
+                v("dT", K * D, K, D), v("dls", 1, ls_shape), None)
+
+
+def slide_train(X2: torch.Tensor, Q: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor, plan: SlideTrainPlan):
+    """Differentiable (logits [1, K], unit image features [1, D], unit text features [K, D]) of ONE bag [N, 512] (bf16 / fp32, no
+    gradient into the bag): cross attention with the queries Q, mean query pooling, Linear / identity adapter, cosine logits
+    (model/deepmil.py:187-204, model/vlsa.py:188-192).  Gradients: Q, W, b, T, logit_scale.  All tensors fp32 contiguous on
+    the bag's device (Q [nq, 512], T [K, 512], logit_scale 0-dim); see ``SlideTrainPlan``."""
+    _need_gpu(X2, Q, T, logit_scale)
+    return _SlideTrainFn.apply(X2, Q, W, b, T, logit_scale, plan)
+
+
 class VlfanInferencePlan:
     """Pre-allocated buffers + raw C-ABI calls for the fused inference forward of one bag shape.
 

@@ -136,6 +136,8 @@ class VLSA(nn.Module):
         else:
             self.logit_scale = nn.Parameter(torch.ones([]) * float(logit_scale))  # CoCa init, model/conch/coca_model.py:187
         self._plans = {}
+        self._train_plans = {}
+        self._tower_lists = None
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ was computed from
 
@@ -183,30 +185,62 @@ class VLSA(nn.Module):
 
     def _provider_key(self):
         """Everything the provider's output depends on that this object can see: identity + in-place version of every
-        parameter and buffer of the provider modules, their train/eval flag (dropout in the 'FC' adapter) and the grad mode.
-        None = the provider is an opaque callable with no declared modules: its output cannot be cached safely."""
+        parameter and buffer of the provider modules, the train / eval flag of every submodule (dropout in the 'FC' adapter)
+        and the grad mode.  None = the provider is an opaque callable with no declared modules: its output cannot be cached.
+
+        The reference's handler calls the model once per bag, so this runs per bag: the text tower (~110 modules, ~150 tensors)
+        is not re-walked every time -- its module / tensor lists are kept and only their flags and versions are read
+        (``_tower_lists``; rebuilt by an exact walk whenever the key misses, on ``_apply`` and on ``load_state_dict``); the
+        small learner / adapter modules are walked exactly on every call."""
         mods = self._provider_modules()
         if not mods:
             return None
+        tower = getattr(self, "prompt_encoder", None)
         key = [torch.is_grad_enabled()]
         for m in mods:
-            key.append((id(m), m.training))
-            # own walk over the module tree (parameters / buffers of every submodule, dict order): nn.Module.parameters() spends
-            # ~0.3 ms per call on a 150-tensor text tower in generator / prefix-string bookkeeping, and this runs once per step
-            stack, seen = [m], set()
-            while stack:
-                x = stack.pop()
-                if id(x) in seen:
-                    continue
-                seen.add(id(x))
-                for t in x._parameters.values():
-                    if t is not None:
-                        key.append((id(t), t._version))
-                for t in x._buffers.values():
-                    if t is not None:
-                        key.append((id(t), t._version))
-                stack.extend(c for c in x._modules.values() if c is not None)
+            if m is tower:
+                tl = self._tower_lists
+                if tl is None or tl[0] is not m:
+                    sub, tensors = self._walk_module(m)
+                    tl = self._tower_lists = (m, sub, tensors)
+                key.append((id(m), len(tl[2]), tuple([x.training for x in tl[1]]), tuple([t._version for t in tl[2]])))
+            else:
+                sub, tensors = self._walk_module(m)
+                key.append((id(m), tuple([(id(x), x.training) for x in sub]), tuple([(id(t), t._version) for t in tensors])))
         return tuple(key)
+
+    @staticmethod
+    def _walk_module(m):
+        """(submodules, parameters + buffers) of a module tree, dict order, every object once (nn.Module.parameters() spends
+        ~0.3 ms on a 150-tensor text tower in generator / prefix-string bookkeeping)."""
+        sub, tensors, stack, seen = [], [], [m], set()
+        while stack:
+            x = stack.pop()
+            if id(x) in seen:
+                continue
+            seen.add(id(x))
+            sub.append(x)
+            tensors.extend(t for t in x._parameters.values() if t is not None)
+            tensors.extend(t for t in x._buffers.values() if t is not None)
+            stack.extend(c for c in x._modules.values() if c is not None)
+        return sub, tensors
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): tensors change under the same Parameter objects and versions -- nothing cached survives
+        if "_plans" in self.__dict__:            # (not yet there when a parent converts a half-built model)
+            self._drop_text_cache()
+            self._tower_lists = None
+            self._plans.clear()
+            self._train_plans.clear()
+            self._prepared_text = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if "_plans" in self.__dict__:
+            self._drop_text_cache()
+            self._tower_lists = None
+        return out
 
     def compute_text_features_with_coop(self, prompt_learner):
         """prompt learner's sentence embeddings through the text tower (model/vlsa.py:149-156)."""
@@ -246,6 +280,8 @@ class VLSA(nn.Module):
         if key is None:
             return provider()
         if self._text_cache is None or key != self._text_cache_key:
+            self._tower_lists = None                 # a miss re-walks the tower: a swapped parameter object is seen here at the latest
+            key = self._provider_key()
             feats = provider()
             if feats.requires_grad and feats.grad_fn is not None:
                 # the cached tensor carries the provider's autograd graph: every bag of the step may hang off it, but once
@@ -323,6 +359,54 @@ class VLSA(nn.Module):
                  query_pool_module=qmod)
         return outs["logits"], outs["vhat"], outs["That"]
 
+    def _slide_train(self, X, text_features):
+        """One bag with a gradient needed, VLFAN encoder with mean query pooling and a Linear / identity adapter (the shipped
+        configuration): ONE autograd node per bag over the HIP forward / backward (``VF.slide_train``).  The reference's handler
+        trains bag by bag (runner/vlsa_handler.py:267-289) and that loop is host-bound.  None: no such form (the general
+        route follows)."""
+        enc = self.mil_encoder
+        if (not isinstance(enc, VLFAN) or not isinstance(X, torch.Tensor) or X.dim() != 3 or X.shape[0] != 1 or not X.is_cuda
+                or X.requires_grad or X.shape[1] == 0):
+            return None
+        spec = enc.fused_head_spec()
+        if spec is None or spec[0] != "mean":
+            return None
+        if enc.feat_proj is not None:
+            if enc._projecter_trains():
+                return None                     # the projecter's gradient comes back through dX: general route
+            with torch.no_grad():
+                X = enc.project(X)
+        X2 = VF._bag2d(X)
+        N, D = X2.shape
+        T = text_features
+        if (D != 512 or X2.dtype not in (torch.float32, torch.bfloat16) or not T.is_cuda or T.dim() != 2 or T.shape[1] != D
+                or not (1 <= T.shape[0] <= 64)):
+            return None
+        Q = enc.step_query()
+        if not isinstance(Q, torch.Tensor) or Q.dim() != 2 or Q.shape[1] != D or not Q.is_cuda:
+            return None
+        P = Q.shape[0] - (1 if enc.gated_query else 0)
+        W, b = spec[2], spec[3]
+        ls = self.logit_scale
+        if not (1 <= P <= VF.nat.MAX_P) or ls.dtype != torch.float32 or not ls.is_cuda:
+            return None
+        if W is not None and (W.dtype != torch.float32 or not W.is_contiguous() or tuple(W.shape) != (D, D) or not W.is_cuda
+                              or (b is not None and (b.dtype != torch.float32 or not b.is_contiguous()))):
+            return None
+        if Q.dtype != torch.float32 or not Q.is_contiguous():
+            Q = Q.float().contiguous()
+        if T.dtype != torch.float32 or not T.is_contiguous():
+            T = T.float().contiguous()
+        K = T.shape[0]
+        scale = float(enc.coattn_logit_scale.exp())
+        key = (D, P, K, X2.device, enc.gated_query, W is None, scale)
+        plan = self._train_plans.get(key)
+        if plan is None:
+            if len(self._train_plans) > 8:
+                self._train_plans.clear()
+            plan = self._train_plans[key] = VF.SlideTrainPlan(D, P, K, X2.device, enc.gated_query, W is None, scale)
+        return VF.slide_train(X2, Q, W, b, T, ls, plan)
+
     def forward(self, X):
         """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm)).
         A list / tuple of bags is routed to ``forward_bags`` (so that wrappers which only hook ``forward`` --
@@ -334,6 +418,10 @@ class VLSA(nn.Module):
             fused = self._fused_vlfan(X, text_features)
             if fused is not None:
                 return fused
+        else:
+            trained = self._slide_train(X, text_features)
+            if trained is not None:
+                return trained
         enc = self.mil_encoder
         if (isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max")
                 and not (torch.is_grad_enabled() and (text_features.requires_grad or X.requires_grad))):
