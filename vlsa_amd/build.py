@@ -46,6 +46,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("VLSA_EXTRA_HIPCC_FLAGS", "").split()     # debug builds (e.g. -DVLSA_TT_DEBUG: cycle stamps in the text GEMM)
     jobs = []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
