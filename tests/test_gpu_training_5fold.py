@@ -8,7 +8,9 @@ EMD loss, the ORDINAL RANK PROMPT LEARNER through the text tower, bf16 resident 
 
 Per optimizer step the losses must agree within 2e-3, per fold the held-out c-index (oracle.concordance_index, pinned to the
 reference's evaluator by tests/golden/cindex.npz) within 0.01.  A last case repeats one fold under 2-rank DDP (gloo, both
-ranks on this GPU): bags are the data-parallel unit and the gradient all-reduce must reproduce the single-process step."""
+ranks on this GPU): bags are the data-parallel unit and the gradient all-reduce must reproduce the single-process step.
+One more case trains fold 0 on slide-sized bags (1 000 - 12 000 patches) with the reference's learning rate through the handler's
+bag-by-bag loop shape."""
 import os
 
 import pytest
@@ -26,12 +28,12 @@ EPOCHS = int(os.environ.get("VLSA_5FOLD_EPOCHS", "2"))    # the reference trains
 TOWER, TSEED, BASE = "train", 9300, 4
 
 
-def cohort():
+def cohort(nmin=60, nmax=320):
     g = cases.gen(9200)
     direction = torch.nn.functional.normalize(torch.randn(512, generator=g), dim=0)
     bags, t, e = [], [], []
     for i in range(NPAT):
-        n = int(torch.randint(60, 320, (1,), generator=g))
+        n = int(torch.randint(nmin, nmax, (1,), generator=g))
         tb = int(torch.randint(0, K, (1,), generator=g))
         # clustered patches (64 tissue-like clusters, sigma 0.1): i.i.d. Gaussian patches make the scale-100 cross attention
         # nearly one-hot; real slides have many near-duplicate patches
@@ -55,10 +57,10 @@ def text_side_inputs():
     return W, table, ctx_key, names
 
 
-def adam(named):
+def adam(named, lr=LR):
     decay = [p for n, p in named if p.dim() >= 2]
     rest = [p for n, p in named if p.dim() < 2]
-    return torch.optim.Adam([{"params": rest, "weight_decay": 0.0}, {"params": decay, "weight_decay": WD}], lr=LR)
+    return torch.optim.Adam([{"params": rest, "weight_decay": 0.0}, {"params": decay, "weight_decay": WD}], lr=lr)
 
 
 def batches(train_idx, epoch):
@@ -96,16 +98,19 @@ def trainable(model, pl):
             ("ctx", pl.context_embeds), ("rank", pl.rank_embeds), ("logit_scale", model.logit_scale)]
 
 
-def gpu_fold(bags_dev, t, e, train_idx, test_idx, params):
+def gpu_fold(bags_dev, t, e, train_idx, test_idx, params, epochs=None, lr=LR, bag_by_bag=False):
     from vlsa_amd.losses import SurvObjective
     model, pl = build_gpu_model(params)
-    opt, objective = adam(trainable(model, pl)), SurvObjective()
+    opt, objective = adam(trainable(model, pl), lr), SurvObjective()
     td, ed = t.cuda(), e.cuda()
     losses = []
     model.train()
-    for ep in range(EPOCHS):
+    for ep in range(EPOCHS if epochs is None else epochs):
         for idx in batches(train_idx, ep):
-            logits = model.forward_bags([bags_dev[i] for i in idx])[0]
+            if bag_by_bag:      # the handler's own loop shape (runner/vlsa_handler.py:267-289): one net(X) per bag, cat, one backward
+                logits = torch.cat([model(bags_dev[i][None])[0] for i in idx], dim=0)
+            else:
+                logits = model.forward_bags([bags_dev[i] for i in idx])[0]
             ii = torch.tensor(idx, device="cuda")
             loss = objective(logits, td[ii], ed[ii], model.get_logit_scale())
             opt.zero_grad(); loss.backward(); opt.step()
@@ -122,7 +127,7 @@ def cpu_text_features(W, leaves, template, interp, pseudo, c):
     return TO.prompt_encoder_forward(W, c["heads"], sent, pseudo, c["layers"])
 
 
-def cpu_fold(bags, t, e, train_idx, test_idx, params):
+def cpu_fold(bags, t, e, train_idx, test_idx, params, epochs=None, lr=LR):
     W, table, ctx_key, names = text_side_inputs()
     c = TC.TOWERS[TOWER]
     E = W["token_embedding.weight"]
@@ -134,7 +139,7 @@ def cpu_fold(bags, t, e, train_idx, test_idx, params):
     pseudo = TO.pseudo_sentence_tokens(K, leaves["ctx"].shape[0], tmax)
     template = TO.sentence_template(E[0], E[1], E[2], E[table["X."][1]], pseudo)
     interp = TO.interpolation_weights(BASE, K)
-    opt = adam(list(leaves.items()))
+    opt = adam(list(leaves.items()), lr)
 
     def fwd(idx):
         T = cpu_text_features(W, leaves, template, interp, pseudo, c)
@@ -142,7 +147,7 @@ def cpu_fold(bags, t, e, train_idx, test_idx, params):
         return torch.cat([O.vlsa_vlfan_forward(bags[i].float(), Q, T, leaves["logit_scale"], head_weight=leaves["W"],
                                                head_bias=leaves["b"])["logits"] for i in idx])
     losses = []
-    for ep in range(EPOCHS):
+    for ep in range(EPOCHS if epochs is None else epochs):
         for idx in batches(train_idx, ep):
             ii = torch.tensor(idx)
             loss = O.vlsa_objective(fwd(idx), t[ii], e[ii], leaves["logit_scale"].exp())
@@ -185,6 +190,32 @@ def test_fold_loss_curve_and_heldout_cindex_match_the_cpu_reference_path(setup, 
     h = len(gl) // 2
     assert sum(gl[h:]) / (len(gl) - h) < sum(gl[:h]) / h       # it trains: the last epoch's mean loss is below the first's
     print(f"fold {fold}: {len(gl)} steps, loss {gl[0]:.4f} -> {gl[-1]:.4f} (cpu {cl[-1]:.4f}), held-out c-index gpu {cg:.4f} cpu {cc:.4f}")
+
+
+BIG_EPOCHS = int(os.environ.get("VLSA_TCGA_EPOCHS", "10"))    # as the reference trains (cfg_vlsa_conch.yaml: epochs 10)
+
+
+def test_tcga_sized_bags_reference_lr_bag_by_bag_loop():
+    """The same cohort shape with slide-sized bags (1 000 - 12 000 patches, the range of the TCGA cohorts: SURVEY.md 8(d)), the
+    reference's learning rate (2e-4) and the HANDLER's loop shape -- one ``net(X)`` per bag, ``torch.cat``, one backward
+    (runner/vlsa_handler.py:267-289) -- on fold 0, against the CPU twin step by step."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    bags, t, e, folds = cohort(1000, 12000)
+    bags_dev = [b.cuda() for b in bags]
+    params = cases.make_params(P, K, 9201)
+    test_idx = folds[0]
+    train_idx = [i for f in range(1, FOLDS) for i in folds[f]]
+    gl, ginc = gpu_fold(bags_dev, t, e, train_idx, test_idx, params, epochs=BIG_EPOCHS, lr=2e-4, bag_by_bag=True)
+    cl, cinc = cpu_fold(bags, t, e, train_idx, test_idx, params, epochs=BIG_EPOCHS, lr=2e-4)
+    assert len(gl) == len(cl) == BIG_EPOCHS * ((len(train_idx) + BATCH - 1) // BATCH)
+    for i, (a, b) in enumerate(zip(gl, cl)):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (i, a, b)
+    y = torch.stack([t[test_idx].float(), e[test_idx]], dim=1)
+    cg, cc = O.concordance_index(y, ginc), O.concordance_index(y, cinc)
+    assert abs(cg - cc) <= 0.01, (cg, cc)
+    assert (ginc - cinc).abs().max().item() < 5e-3
+    print(f"tcga-sized: {sum(b.shape[0] for b in bags)} patches in {NPAT} bags, {len(gl)} steps, loss {gl[0]:.4f} -> {gl[-1]:.4f} "
+          f"(cpu {cl[-1]:.4f}), held-out c-index gpu {cg:.4f} cpu {cc:.4f}")
 
 
 def _ddp_worker(rank, world, port, ret):
