@@ -100,18 +100,73 @@ def test_unreachable_slots_are_ignored_and_reachable_ones_are_not():
         assert (f2 - f0).abs().max().item() > 1e-3
 
 
-def test_frozen_tower_is_enforced_and_cpu_inputs_fail_loudly():
+def test_cpu_inputs_fail_loudly():
     from vlsa_amd._native import VlsaNativeError
     enc = build_encoder("small", 1)
     x = torch.zeros(2, 127, 128, device="cuda", requires_grad=True)
     pt = torch.ones(2, 127, dtype=torch.long, device="cuda")
-    next(enc.transformer.parameters()).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        enc(prompts_embedding=x, prompts_pseudo_tokens=pt)
     with torch.no_grad():
-        enc(prompts_embedding=x, prompts_pseudo_tokens=pt)      # fine without autograd
+        enc(prompts_embedding=x, prompts_pseudo_tokens=pt)
     with pytest.raises(VlsaNativeError):
         enc(prompts_embedding=x.detach().cpu(), prompts_pseudo_tokens=pt)
+
+
+@pytest.mark.parametrize("case", [c for c in TC.RANK_CASES if c[0] in ("rank_conch_k4", "rank_small_k8_front", "rank_mid_k5_middle")],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("prefix", [False, True], ids=["rows", "shared_prefix"])
+def test_trainable_tower_features_and_weight_gradients(case, prefix):
+    """``vlsa_txt_encoder_frozen: False`` (runner/vlsa_handler.py:131): tower parameters that require grad take the torch route
+    over the compact rows.  Text features, d prompts (context / rank embeds) and the gradients of EVERY tower parameter vs the
+    CPU oracle's autograd over the full 128 positions (model/prompt_encoder.py:267-322 restated in oracle/text_oracle.py)."""
+    from oracle import text_oracle as TO
+    (name, tower, seed, K, base, position) = case
+    inp = TH.rank_case_inputs(case)
+    fx = inp["fx"]
+    enc = build_encoder(tower, seed)
+    for p in enc.parameters():
+        p.requires_grad_(True)
+    enc.token_embedding.weight.requires_grad_(False)                 # (the learner reads it at construction only)
+    pl = build_learner(case, inp).cuda()
+    with torch.no_grad():
+        pl.context_embeds.copy_(torch.from_numpy(fx["context_embeds"]))
+        pl.rank_embeds.copy_(torch.from_numpy(fx["rank_embeds"]))
+    L = pl.shared_prefix_len if prefix else 0
+    feats = enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=L)
+    assert feats.grad_fn is not None and type(feats.grad_fn).__name__ != "_TextTowerFnBackward"
+    assert np.abs(feats.detach().cpu().numpy() - fx["text_features"]).max() < TOL
+    G = torch.from_numpy(fx["G"])
+    (feats * G.cuda()).sum().backward()
+    # the oracle with every weight as a leaf
+    W = {k: v.clone().requires_grad_(k != "token_embedding.weight") for k, v in inp["W"].items()}
+    ctx = torch.from_numpy(fx["context_embeds"]).clone().requires_grad_(True)
+    rk = torch.from_numpy(fx["rank_embeds"]).clone().requires_grad_(True)
+    E = inp["W"]["token_embedding.weight"]
+    bos, eos, pad = inp["special"]
+    pseudo = TO.pseudo_sentence_tokens(K, ctx.shape[0], rk.shape[1])
+    template = TO.sentence_template(E[pad], E[bos], E[eos], E[inp["table"]["X."][1]], pseudo)
+    sent = TO.rank_prompt_learner_forward(ctx, rk, template, TO.interpolation_weights(base, K), K, position)
+    ref = TO.prompt_encoder_forward(W, inp["heads"], sent, pseudo, inp["layers"])
+    (ref * G).sum().backward()
+
+    def close(got, want, what):
+        got, want = got.detach().cpu().numpy(), want.detach().numpy()
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, (what, np.abs(got - want).max(), np.abs(want).max())
+    close(pl.context_embeds.grad, ctx.grad, "context")
+    close(pl.rank_embeds.grad, rk.grad, "rank")
+    sd = dict(enc.named_parameters())
+    checked = 0
+    for k, w in W.items():
+        if k == "token_embedding.weight":
+            continue
+        g = sd[k].grad
+        assert g is not None, k
+        if k == "positional_embedding":
+            # positions no compact row uses get no gradient here and an exactly-zero one in the reference ... except position
+            # rows that only feed masked-out attention: compare where the reference is non-zero, and require zeros elsewhere
+            assert float(g.abs().max()) > 0
+        close(g, w.grad, k)
+        checked += 1
+    assert checked == 5 + 12 * inp["layers"]
 
 
 def test_vlsa_end_to_end_with_gpu_text_side():

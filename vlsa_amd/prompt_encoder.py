@@ -7,8 +7,9 @@ prompts_pseudo_tokens)`` -> ``[n_prompts, output_dim]``.
 The 12 pre-LN blocks run in libvlsa_hip.so (vlsa_amd/csrc/text_tower.hip) on the COMPACT rows of the prompts: only the
 positions that can reach the pooled CLS token are evaluated (a 13-row problem per rank prompt instead of 128 -- exact, see
 the kernel file), f32 MFMA throughout.  Differentiable w.r.t. ``prompts_embedding`` (the learnable context / rank
-embeddings of the prompt learner); the tower itself is frozen as in every shipped configuration
-(``vlsa_txt_encoder_frozen: True``, cfg_vlsa_conch.yaml:69) -- a tower parameter that requires grad raises.
+embeddings of the prompt learner); the tower itself is frozen in every shipped configuration
+(``vlsa_txt_encoder_frozen: True``, cfg_vlsa_conch.yaml:69).  A tower whose own parameters require grad
+(``vlsa_txt_encoder_frozen: False``) takes a differentiable torch route over the same compact rows (``_forward_trainable``).
 """
 from __future__ import annotations
 
@@ -120,6 +121,40 @@ class _RowPlan:
         self.c = _TTRows(self.n_seq, self.M, self.M_pad, self.max_len, self.row_seq.data_ptr(), self.row_pos.data_ptr(),
                          self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr(), self.prefix_len)
         self.ws = None    # inference workspace (no activations kept), allocated on first use
+        self._rp, self._dense = rp, None
+
+    def dense_tables(self, device):
+        """For the trainable-tower route (torch ops over the same compact rows): the additive attention mask [M, M] (0 / -inf)
+        that restates which rows a row sees -- prefix rows: causal among themselves; a prompt's token rows: the prefix and the
+        prompt's own rows up to their position; a CLS row: the rows flagged in cls_keep (model/prompt_encoder.py:245-252,
+        299-303) -- plus index tensors for the row gather and the CLS rows."""
+        if self._dense is not None and self._dense[0].device == torch.device(device):
+            return self._dense
+        rp, M, L = self._rp, self.M, self.prefix_len
+        seq, pos, src, keep = rp["row_seq"], rp["row_pos"], rp["row_src"], rp["cls_keep"]
+        allow = torch.zeros(M, M, dtype=torch.bool)
+        for i in range(M):
+            i_prefix, i_cls = i < L, src[i] < 0
+            for j in range(M):
+                j_prefix = j < L
+                if i_prefix:
+                    ok = j_prefix and j <= i
+                elif j_prefix:
+                    ok = bool(keep[j]) if i_cls else True
+                elif seq[j] != seq[i]:
+                    ok = False
+                elif i_cls:
+                    ok = bool(keep[j])
+                else:
+                    ok = src[j] >= 0 and pos[j] <= pos[i]
+                allow[i, j] = ok
+        mask = torch.zeros(M, M).masked_fill_(~allow, float("-inf")).to(device)
+        idx = lambda v: torch.tensor(v, dtype=torch.long, device=device)   # noqa: E731
+        tok_rows = [r for r in range(M) if src[r] >= 0]
+        cls_rows = [r for r in range(M) if src[r] < 0]
+        self._dense = (mask, idx(tok_rows), idx([seq[r] for r in tok_rows]), idx([src[r] for r in tok_rows]), idx(cls_rows),
+                       idx(pos[:M]))
+        return self._dense
 
 
 class _TextTowerFn(torch.autograd.Function):
@@ -360,8 +395,36 @@ class CONCHPromptEncoder(nn.Module):
         if not x.is_cuda:
             raise VlsaNativeError("vlsa_amd runs on MI355X only: got CPU prompt embeddings (there is no CPU fallback; the CPU "
                                   "oracle under oracle/ is test infrastructure)")
-        if torch.is_grad_enabled() and any(t.requires_grad for t in self._tower_tensors()):
-            raise NotImplementedError("the text tower is frozen on this path (vlsa_txt_encoder_frozen: True): freeze its parameters; "
-                                      "gradients are produced for prompts_embedding only")
         plan = self._plan(prompts_pseudo_tokens, x.device, shared_prefix_len if prompts_text is None else 0)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in self._tower_tensors()):
+            return self._forward_trainable(x, plan)      # vlsa_txt_encoder_frozen: False
         return _TextTowerFn.apply(x, self, plan)
+
+    def _forward_trainable(self, emb, plan):
+        """A tower whose own weights train (``vlsa_txt_encoder_frozen: False``, runner/vlsa_handler.py:131; off in every shipped
+        configuration): the HIP kernels produce d prompts_embedding only, so this case runs as differentiable torch ops
+        (library GEMMs) over the SAME compact rows -- 13 rows per rank prompt instead of 128, shared prefix once --
+        model/conch/transformer.py:191-247 restated on [M, width] rows with the plan's dense mask."""
+        ts = self._tower_tensors()
+        for t in ts:
+            if not t.is_cuda or t.device != emb.device:
+                raise VlsaNativeError("the text tower runs on the MI355X only: its weights must be on the device of the prompts")
+        mask, tok_rows, tok_seq, tok_src, cls_rows, pos = plan.dense_tables(emb.device)
+        d, H = self.positional_embedding.shape[1], self.heads
+        M = plan.M
+        x = torch.zeros(M, d, dtype=torch.float32, device=emb.device)
+        x = x.index_put((tok_rows,), emb.float()[tok_seq, tok_src])
+        x = x.index_put((cls_rows,), self.cls_emb.float().expand(cls_rows.numel(), d))
+        x = x + self.positional_embedding[pos]
+        F = torch.nn.functional
+        for blk in self.transformer.resblocks:
+            h = F.layer_norm(x, (d,), blk.ln_1.weight, blk.ln_1.bias, 1e-5)
+            qkv = h @ blk.attn.in_proj_weight.t() + blk.attn.in_proj_bias
+            q, k, v = (t.reshape(M, H, d // H).transpose(0, 1) for t in qkv.chunk(3, dim=-1))        # [H, M, 64]
+            att = torch.softmax(q @ k.transpose(1, 2) * (d // H) ** -0.5 + mask, dim=-1) @ v          # [H, M, 64]
+            x = x + att.transpose(0, 1).reshape(M, d) @ blk.attn.out_proj.weight.t() + blk.attn.out_proj.bias
+            h = F.layer_norm(x, (d,), blk.ln_2.weight, blk.ln_2.bias, 1e-5)
+            h = F.gelu(h @ blk.mlp.c_fc.weight.t() + blk.mlp.c_fc.bias)
+            x = x + h @ blk.mlp.c_proj.weight.t() + blk.mlp.c_proj.bias
+        pooled = F.layer_norm(x[cls_rows], (d,), self.ln_final.weight, self.ln_final.bias, 1e-5)
+        return pooled @ self.text_projection
