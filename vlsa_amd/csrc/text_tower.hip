@@ -178,6 +178,25 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
         for (int u = 0; u < NTW; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // The epilogue's inputs (bias, gelu' argument, residual) of the accumulator registers this wave will finalise (q = w, w + NW, ...)
+    // are fetched NOW: read behind the reduction they are dependent loads that cannot be batched (the stores of one register's
+    // results may alias the next one's loads as far as the compiler knows).  Worth ~1 % of the tower: the whole epilogue is 80 of
+    // 668 us over the 49 products of a forward pass (VLSA_TT_DEBUG_ALL=8).
+    constexpr int QW = (Q + NW - 1) / NW;
+    float e_bias[QW], e_h[QW], e_res[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = w + i * NW;
+        e_bias[i] = 0.f; e_h[i] = 0.f; e_res[i] = 0.f;
+        if (q < Q) {
+            const int t = q / (NTW * 4), u = (q >> 2) % NTW, v = q & 3;
+            const int row = m0 + 16 * t + 4 * g + v, col = n0 + 16 * u + r;
+            if (epi & EPI_BIAS) e_bias[i] = p.bias[col];
+            if (epi & EPI_GELU_BWD) e_h[i] = p.H[(size_t)row * p.ldh + col];
+            if (epi & EPI_RESID) e_res[i] = p.resid[(size_t)row * p.ldr + col];
+        }
+    }
+
     constexpr int PF = MT == 1 ? 8 : 6;    // weight (and, without LayerNorm, activation) register ring: groups in flight
 #ifdef VLSA_TT_DEBUG
     const int dbg = epi >> 8;
@@ -365,19 +384,25 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             for (int v = 0; v < 4; ++v) red[(w * Q + (t * NTW + u) * 4 + v) * 64 + lane] = acc[t][u][v];
     __syncthreads();
     TT_STAMP(7);
-    for (int q = w; q < Q; q += NW) {       // accumulator register q of every lane: summed and stored by wave q % NW
+#ifdef VLSA_TT_DEBUG
+    if (dbg & 8) return;                                    // no epilogue at all
+#endif
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {          // accumulator register q of every lane: summed and stored by wave q % NW
+        const int q = w + i * NW;
+        if (q >= Q) break;
         float val = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) val += red[(ww * Q + q) * 64 + lane];
         const int t = q / (NTW * 4), u = (q >> 2) % NTW, v = q & 3;
         const int row = m0 + 16 * t + 4 * g + v, col = n0 + 16 * u + r;
-        if (epi & EPI_BIAS) val += p.bias[col];
+        if (epi & EPI_BIAS) val += e_bias[i];
         if (epi & EPI_GELU) {
             if (p.Ypre) p.Ypre[(size_t)row * p.ldy + col] = val;
             val = gelu(val);
         }
-        if (epi & EPI_GELU_BWD) val *= gelu_grad(p.H[(size_t)row * p.ldh + col]);
-        if (epi & EPI_RESID) val += p.resid[(size_t)row * p.ldr + col];
+        if (epi & EPI_GELU_BWD) val *= gelu_grad(e_h[i]);
+        if (epi & EPI_RESID) val += e_res[i];
         if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
         if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
@@ -767,8 +792,17 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     return c;
 }
 
+#ifdef VLSA_TT_DEBUG
+static int tt_debug_bits_all() {
+    const char* e = getenv("VLSA_TT_DEBUG_ALL");
+    return e ? (atoi(e) << 8) : 0;
+}
+#endif
 template <int MT, int NW, int PRO, int GT, int NTW = 2>
 int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
+#ifdef VLSA_TT_DEBUG
+    a.epi |= tt_debug_bits_all();     // experiments on EVERY product of the tower (results are then wrong: timing only)
+#endif
     // row groups: only those that hold real rows (the rows behind M_real are padding nobody reads a result from)
     a.MG = a.M_real > 0 ? (a.M_real + 16 * MT - 1) / (16 * MT) : M_pad / (16 * MT);
     if (a.MG * 16 * MT > M_pad) a.MG = M_pad / (16 * MT);
