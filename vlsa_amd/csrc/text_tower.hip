@@ -560,16 +560,24 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
     }
     __syncthreads();
     if (!s_last) return;
-    for (int rr = w; rr < L; rr += 4) {
-        float dk = 0.f, dv = 0.f;
-        for (int b = 0; b <= n_seq; ++b) {                 // fixed order
-            const float* pp = pfx + (((size_t)b * heads + h) * L + rr) * 128;
-            dk += __hip_atomic_load(pp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dv += __hip_atomic_load(pp + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (row, dK | dV) pairs over the four waves; the blocks' shares of a pair are loaded 16 at a time (one L2 round trip per 16 blocks,
+    // not one per block: the loop is a chain of write-through-visible loads) and added in block order
+    for (int pr = w; pr < 2 * L; pr += 4) {
+        const int rr = pr >> 1, which = pr & 1;
+        float acc = 0.f;
+        for (int b0 = 0; b0 <= n_seq; b0 += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = b0 + u;
+                t[u] = b <= n_seq ? __hip_atomic_load(pfx + (((size_t)b * heads + h) * L + rr) * 128 + 64 * which + lane, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += t[u];      // fixed order (the padding adds exact zeros)
         }
-        const int col = h * kHeadDim + lane;
-        dqkv[tiled_index(rr, col + d, 3 * d)] = dk;
-        dqkv[tiled_index(rr, col + 2 * d, 3 * d)] = dv;
+        dqkv[tiled_index(rr, h * kHeadDim + lane + (which ? 2 * d : d), 3 * d)] = acc;
     }
     if (tid == 0) __hip_atomic_store(cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ticket back to zero
 }
