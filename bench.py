@@ -3,22 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A STEP = one pass of the hot path over one batch of 128 HBM-resident bags, issued as FOUR launches of 32 bags (32 = the
-reference's own batch per optimizer step, cfg_vlsa_conch.yaml:117-118; its eval loop is the same independent-bag
-stream): each launch = query / text normalisation, the persistent streaming aggregation kernel, the partial merge and
+A STEP = one pass of the hot path over one batch of 128 HBM-resident bags, issued as TWO launches of 64 bags (64 = the most
+the persistent kernels take per launch; the reference's eval loop is a stream of independent bags, its optimizer step 32 of
+them: cfg_vlsa_conch.yaml:117-118.  Rounds 1-2 issued four launches of 32: the per-launch ramp and tail then cost 2.3 % more
+of the step -- VLSA_BENCH_BPL=32 reproduces that): each launch = query / text normalisation, the persistent streaming aggregation kernel, the partial merge and
 the incidence head (= VLSA.forward in eval mode with cached text features, reference model/vlsa.py:181-198, once per
 bag).  The timed region is EXACTLY K such steps after W untimed ones, bracketed by barrier + synchronize; value =
-patches of all K steps / that time.  Every launch walks the same 32 distinct bags = 1.6 GB > the 256 MiB Infinity
+patches of all K steps / that time.  Every launch walks the same 64 distinct bags = 3.3 GB > the 256 MiB Infinity
 Cache, so every byte comes from HBM each time.  (Why 128 bags per step: the synchronize before the timed region idles
-the GPU, an MI355X drops its clocks at once and needs ~5 ms to ramp back; with one 0.27 ms launch per step a
+the GPU, an MI355X drops its clocks at once and needs ~5 ms to ramp back; with one 0.27 - 0.5 ms launch per step a
 `--steps 20` run would sit entirely inside that ramp and read 5 % low -- profiles/README.md.)
 
 N = 1  -> BASELINE.json configs[2]: 50k x 512 bf16 bags, P = 12 queries, K = 4 rank prompts (the configuration the
           metric is quoted on).  The line also carries `strong_scaling_base`: configs[3]'s 200k-patch, K = 8 bags on
           this one GPU (what the N > 1 runs divide among the ranks).
 N > 1  -> BASELINE.json configs[3], STRONG scaling: 200k x 512 bf16 bags, P = 12, K = 8, every bag patch-sharded
-          across the N ranks (200k / N rows per GPU: 25k at N = 8).  Per step each rank streams its shards of the 32
-          bags, folds them into 32 compact records, ONE RCCL all-gather moves world x 32 x 24.7 KB, every rank merges
+          across the N ranks (200k / N rows per GPU: 25k at N = 8).  Per launch each rank streams its shards of the 64
+          bags, folds them into 64 compact records, ONE RCCL all-gather moves world x 64 x 24.7 KB, every rank merges
           and runs the replicated head; the collective of step i overlaps the streaming kernel of step i+1.
           `weak_scaling` in the same line = the round-1 workload (bags of N x 50k patches, 50k rows per GPU, K = 4).
 """
@@ -38,8 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 D, P = 512, 12
-BAGS_PER_LAUNCH = 32
-LAUNCHES_PER_STEP = 4
+BAGS_PER_LAUNCH = int(os.environ.get("VLSA_BENCH_BPL", "64"))      # 64 = the batch kernels' maximum; 32 = rounds 1-2
+LAUNCHES_PER_STEP = 128 // BAGS_PER_LAUNCH
 BAGS_PER_STEP = BAGS_PER_LAUNCH * LAUNCHES_PER_STEP
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -116,7 +117,9 @@ def cpu_baseline(seconds=10.0):
 
 
 def load_pmc():
-    for name in ("r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json"):
+    names = (("r03_pmc_batch_kernel_b64.json",) if BAGS_PER_LAUNCH == 64 else
+             ("r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -129,7 +132,7 @@ def load_pmc():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (one step = 128 bags = four 32-bag launches)")
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (one step = 128 bags = two 64-bag launches)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent launches alternate between")
     ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs without a streaming workgroup (-1: 32 when N > 1, else 0)")
@@ -266,13 +269,13 @@ def main():
                                          "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4),
                                          "note": "25 600 FLOP per patch (SURVEY.md 8(d)); the split-bf16 repeats are not counted"}}
             # HBM traffic and matrix-pipe occupancy of this kernel / launch configuration from the committed PMC passes
-            # (separate `--pmc` runs of tools/run_batch.py 32 50000; FETCH_SIZE x 2 = the guide's gfx950 16-B/lane
+            # (separate `--pmc` runs of tools/run_batch.py <bags per launch> 50000; FETCH_SIZE x 2 = the guide's gfx950 16-B/lane
             # correction; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs) = how busy the matrix pipes were).
             pmc, src = load_pmc()
             if pmc and rows_local == 50_000 and dist is None:
                 try:
                     roof["traffic"] = int(pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024)
-                    roof["traffic_source"] = f"{src} (rocprofv3 --pmc, 32 x 50k bags per launch)"
+                    roof["traffic_source"] = f"{src} (rocprofv3 --pmc, {BPL} x 50k bags per launch)"
                     # kernel duration in shader cycles: GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_BUSY_CYCLES over the 32 shader engines
                     cyc = pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else pmc["SQ_BUSY_CYCLES"] / 32.0
                     roof["mfma_util"] = round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
@@ -395,7 +398,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu_per_bag": rows // world, "D": D, "P": P, "K": K,
                        "bags_per_step": BPL * LPS, "bags_per_launch": BPL, "distinct_bags": BPL, "patches_per_step": BPL * LPS * rows,
-                       "launch": f"eager, 5 kernel launches per 32-bag launch, launches alternate over {NS} streams, {wgs} streaming "
+                       "launch": f"eager, 5 kernel launches per {BPL}-bag launch, launches alternate over {NS} streams, {wgs} streaming "
                                  f"workgroups + {256 - wgs} CUs for the tail kernels"},
             "roofline": roof,
         }

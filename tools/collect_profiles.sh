@@ -17,6 +17,9 @@ pmc fetch FETCH_SIZE -- python tools/run_batch.py 32 50000
 pmc write WRITE_SIZE -- python tools/run_batch.py 32 50000
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_batch.py 32 50000
 pmc lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE -- python tools/run_batch.py 32 50000
+pmc fetch64 FETCH_SIZE -- python tools/run_batch.py 64 50000
+pmc write64 WRITE_SIZE -- python tools/run_batch.py 64 50000
+pmc lds64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE -- python tools/run_batch.py 64 50000
 pmc gs_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_gated.py 50000
 pmc gs_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS SQ_WAVES GRBM_GUI_ACTIVE -- python tools/run_gated.py 50000
 pmc gs_mem FETCH_SIZE -- python tools/run_gated.py 50000
@@ -36,6 +39,7 @@ def collect(tags, pat):
             out[k] = sum(v) / len(v)
     return out
 json.dump(collect(("fetch", "write", "sq", "lds"), "partial_dma_batch"), open("$O/pmc_batch_kernel.json", "w"), indent=1)
+json.dump(collect(("fetch64", "write64", "lds64"), "partial_dma_batch"), open("$O/pmc_batch_kernel_b64.json", "w"), indent=1)
 json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "k_gated_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)
 PY
 # PMC passes for the fp32 streaming kernel
@@ -136,5 +140,5 @@ PY
 rm -rf $O/mb $O/pmc_mb_a $O/pmc_mb_b $O/pmc_mb_c $O/pmc_mb_d $O/pmc_at_f $O/pmc_at_w
 python tools/bench_text.py --no-prefix 2>&1 | tail -2 > $O/bench_text_noprefix.txt
 for n in 40000 50000 70000 100000; do for sp in 0 1; do VLSA_GS_SPLIT=$sp python tools/gs_rows.py $n 2>/dev/null | sed "s/$/ split=$sp/"; done; done > $O/gs_split.txt
-rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
+rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_fetch64 $O/pmc_write64 $O/pmc_lds64 $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
 cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; cut -c1-200 $O/bench_driver_args.json; cat $O/pmc_gated_scores.json | head -30
