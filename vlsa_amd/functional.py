@@ -328,9 +328,10 @@ class SlideTrainPlan:
         self.hws = f(D + 4)
         self._c = {k: getattr(self, k).data_ptr() for k in ("qprep", "That", "tnorm", "pm", "pl", "pacc", "head_ws", "bwd_prep", "hws")}
         self.gen, self._src, self._That_out = 0, None, None
-        # float offsets of the per-call record: out | m2 | l | pooled | v | vhat | vnorm | logits
+        # float offsets of the per-call record the backward reads: out | m2 | l | pooled | v | vnorm (logits and v^ are the node's
+        # outputs: tensors of their own, so that in-place edits by the caller stay legal)
         o, self.off = 0, {}
-        for name, n in (("out", P * D), ("m2", 16), ("l", 16), ("pooled", D), ("v", D), ("vhat", D), ("vnorm", 4), ("logits", (K + 3) // 4 * 4)):
+        for name, n in (("out", P * D), ("m2", 16), ("l", 16), ("pooled", D), ("v", D), ("vnorm", 4)):
             self.off[name] = o
             o += n
         self.rec_floats = o
@@ -364,6 +365,8 @@ class _SlideTrainFn(torch.autograd.Function):
         N = X2.shape[0]
         dev = X2.device
         rec = torch.empty(plan.rec_floats, dtype=torch.float32, device=dev)
+        logits = torch.empty(1, plan.K, dtype=torch.float32, device=dev)
+        vhat = torch.empty(1, plan.D, dtype=torch.float32, device=dev)
         base = rec.data_ptr()
         fresh = not plan.prepared_for(Q, T)
         G = int(lib.vlsa_num_partials(N))
@@ -371,22 +374,21 @@ class _SlideTrainFn(torch.autograd.Function):
         nat.check(lib.vlsa_vlfan_forward_bag(_p(X2), _dt(X2), N, X2.stride(0), plan.D, _p(Q) if fresh else None, plan.nq, int(plan.gated),
                                              plan.scale, _p(T), plan.K, _p(logit_scale), nat.POOL_MEAN, None, _p(W), _p(b), nat.KERNEL_AUTO,
                                              c["qprep"], c["That"], c["tnorm"], c["pm"], c["pl"], c["pacc"], G, at("m2"), at("l"),
-                                             at("out"), None, None, c["head_ws"], at("pooled"), at("v"), at("vhat"), at("vnorm"),
-                                             at("logits"), None, s), "vlsa_vlfan_forward_bag")
+                                             at("out"), None, None, c["head_ws"], at("pooled"), at("v"), vhat.data_ptr(), at("vnorm"),
+                                             logits.data_ptr(), None, s), "vlsa_vlfan_forward_bag")
         if fresh:
             plan.mark_prepared(Q, T)
         ctx.plan, ctx.gen, ctx.has = plan, plan.gen, (W is not None, b is not None, tuple(logit_scale.shape))
-        ctx.save_for_backward(X2, Q, T, rec, logit_scale, *([W] if W is not None else []))
-        K, D = plan.K, plan.D
-        return rec[off["logits"]:off["logits"] + K].view(1, K), rec[off["vhat"]:off["vhat"] + D].view(1, D), plan.unit_text()
+        ctx.save_for_backward(X2, Q, T, rec, logit_scale, logits, vhat, *([W] if W is not None else []))
+        return logits, vhat, plan.unit_text()
 
     @staticmethod
     def backward(ctx, dlogits, g_vhat, g_That):
         plan = ctx.plan
         lib, s, c, off, goff = plan.lib, _stream(), plan._c, plan.off, plan.goff
-        X2, Q, T, rec, ls = ctx.saved_tensors[:5]
+        X2, Q, T, rec, ls, logits, vhat = ctx.saved_tensors[:7]
         has_w, has_b, ls_shape = ctx.has
-        W = ctx.saved_tensors[5] if has_w else None
+        W = ctx.saved_tensors[7] if has_w else None
         N, dev, K, D, P, nq = X2.shape[0], X2.device, plan.K, plan.D, plan.P, plan.nq
         qprep, That, tnorm = c["qprep"], c["That"], c["tnorm"]
         keep = None
@@ -407,7 +409,7 @@ class _SlideTrainFn(torch.autograd.Function):
         gt = None if g_That is None else _f32c(g_That)
         G = int(lib.vlsa_num_partials(N))
         nat.check(lib.vlsa_vlfan_backward_bag(_p(X2), _dt(X2), N, X2.stride(0), D, qprep, nq, int(plan.gated), plan.scale, _p(dl), _p(gv), _p(gt),
-                                              at("pooled"), at("vhat"), at("vnorm"), That, tnorm, at("logits"), _p(W), _p(ls), at("out"),
+                                              at("pooled"), vhat.data_ptr(), at("vnorm"), That, tnorm, logits.data_ptr(), _p(W), _p(ls), at("out"),
                                               at("m2"), at("l"), K, c["hws"], gat("drows"), gat("dW") if has_w else None,
                                               gat("db") if has_w else None, gat("dT"), gat("dls"), c["bwd_prep"], c["pm"], c["pl"], c["pacc"], G,
                                               gat("dE"), gat("dQ"), s), "vlsa_vlfan_backward_bag")

@@ -434,6 +434,13 @@ class VLSA(nn.Module):
             That, _ = VF.normalize_rows(text_features.detach())
             h = VF.head_forward(feats, "given", None, None, None, That, self.logit_scale.detach())
             return h["logits"][None, :], h["vhat"][None, :], That
+        if (feats.is_cuda and feats.dim() == 2 and feats.shape[0] == 1 and feats.dtype == torch.float32 and feats.shape[1] % 4 == 0
+                and feats.shape[1] <= 1024 and text_features.is_cuda and text_features.dim() == 2 and 1 <= text_features.shape[0] <= 64
+                and text_features.shape[1] == feats.shape[1] and self.logit_scale.is_cuda):
+            # any encoder, gradient needed: both normalisations and the cosine logits as ONE autograd node (two launches each way:
+            # the batched training head with B = P = 1 and an identity adapter) instead of ~12 torch ops and as many backward
+            # nodes -- the bag-by-bag training loop is bound by those
+            return VF.head_train(feats[None], None, None, text_features, self.logit_scale, self._head_tickets)
         text_features = F.normalize(text_features, dim=-1)
         image_features = F.normalize(feats.float(), dim=-1)
         logits = self.logit_scale.exp() * image_features @ text_features.t()
