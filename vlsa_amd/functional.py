@@ -1070,9 +1070,9 @@ class _AttnScoresFn(torch.autograd.Function):
 
 
 class _AttnPoolFn(torch.autograd.Function):
-    """pooled [512] = softmax_N(a) @ X with a = the (gated) attention scores, for a bag that ITSELF carries a gradient (a trainable
-    Feat_Projecter in front of a DeepMIL encoder, model/deepmil.py:267-283): forward = score kernel + pooling kernels, backward =
-    da in one pass (vlsa_scored_pool_backward), the parameter gradients (vlsa_attn_scores_backward) and
+    """pooled [512] = softmax_N(a) @ X with a = the (gated) attention scores, as ONE autograd node (model/deepmil.py:267-283): forward
+    = score kernel + pooling kernels, backward = da in one pass (vlsa_scored_pool_backward), the parameter gradients
+    (vlsa_attn_scores_backward) and -- only for a bag that ITSELF carries a gradient (a trainable Feat_Projecter in front) --
     dX = dHa Wa + dHg Wg + A dpooled (vlsa_attn_scores_backward_dx).  Returns (pooled, a); a is not differentiable here."""
 
     @staticmethod
@@ -1080,7 +1080,7 @@ class _AttnPoolFn(torch.autograd.Function):
         a = fused(X2, Wa, ba, Wg, bg, w2, c, drop_p=drop_p, seed=seed)
         m2, l, out = _scored_pool_raw(X2, a)
         gated = Wg is not None
-        ctx.save_for_backward(X2, a, m2, l, out, fused._prep, fused.packed_t(X2.device, Wa, Wg))
+        ctx.save_for_backward(X2, a, m2, l, out, fused._prep, fused.packed_t(X2.device, Wa, Wg) if ctx.needs_input_grad[0] else None)
         ctx.gated, ctx.shapes, ctx.drop = gated, (w2.shape, c.shape), (float(drop_p), int(seed))
         ctx.mark_non_differentiable(a)
         return out[0], a
@@ -1095,19 +1095,21 @@ class _AttnPoolFn(torch.autograd.Function):
         nat.check(lib.vlsa_scored_pool_backward(_p(X2), _dt(X2), N, X2.stride(0), 512, _p(a), _p(m2), _p(l), _p(out), _p(dp), _p(da), s),
                   "vlsa_scored_pool_backward")
         tile_rows = int(lib.vlsa_mlp_bwd_tile_rows(_dt(X2)))
-        dX = torch.empty(N, 512, dtype=torch.float32, device=dev)
-        keep, p_desc, p_dx, p_off, p_ts, n_tiles, _ = _row_tables([X2], tile_rows, extra=[dX])
+        need_dx = ctx.needs_input_grad[0]          # the bag itself carries a gradient (a trainable Feat_Projecter in front)
+        dX = torch.empty(N, 512, dtype=torch.float32, device=dev) if need_dx else None
+        keep, p_desc, p_dx, p_off, p_ts, n_tiles, _ = _row_tables([X2], tile_rows, extra=[dX] if need_dx else None)
         ws = torch.empty(lib.vlsa_mlp_bwd_workspace_bytes(1 if gated else 0, n_tiles), dtype=torch.uint8, device=dev)
         dW = torch.empty(2 if gated else 1, 256, 512, dtype=torch.float32, device=dev)
         dvec = torch.empty(3, 512, dtype=torch.float32, device=dev)
         nat.check(lib.vlsa_attn_scores_backward(p_desc, 1, _dt(X2), 512, _p(prep), int(gated), p_ts, n_tiles, _p(da), p_off, _p(ws),
                                                 _p(dW), _p(dvec), ctx.drop[0], ctx.drop[1], s), "vlsa_attn_scores_backward")
-        aw = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]          # [N] softmax weights of the pooling
-        nat.check(lib.vlsa_attn_scores_backward_dx(p_desc, p_dx, 1, _dt(X2), 512, _p(prep), _p(prep_t), int(gated), p_ts, n_tiles, _p(da),
-                                                   _p(aw), _p(dp), p_off, ctx.drop[0], ctx.drop[1], s), "vlsa_attn_scores_backward_dx")
+        if need_dx:
+            aw = torch.exp2(a * 1.4426950408889634 - m2[0]) / l[0]          # [N] softmax weights of the pooling
+            nat.check(lib.vlsa_attn_scores_backward_dx(p_desc, p_dx, 1, _dt(X2), 512, _p(prep), _p(prep_t), int(gated), p_ts, n_tiles, _p(da),
+                                                       _p(aw), _p(dp), p_off, ctx.drop[0], ctx.drop[1], s), "vlsa_attn_scores_backward_dx")
+            if X2.dtype != torch.float32:
+                dX = dX.to(X2.dtype)
         w2_shape, c_shape = ctx.shapes
-        if X2.dtype != torch.float32:
-            dX = dX.to(X2.dtype)
         return (dX, None, dW[0], dvec[0, :256], dW[1] if gated else None, dvec[0, 256:] if gated else None,
                 dvec[1, :256].reshape(w2_shape), dvec[2, :1].reshape(c_shape), None, None)
 
