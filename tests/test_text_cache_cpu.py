@@ -120,3 +120,34 @@ def test_opaque_provider_is_never_cached():
         model.forward_text_only()
         model.forward_text_only()
     assert len(calls) == 2
+
+
+def test_deepcopy_and_pickle_drop_the_native_caches():
+    """copy.deepcopy / pickle of the modules go through TransientCaches.__getstate__: plans, ctypes views of the weights and cached
+    results are not state (and ctypes structures with pointers cannot be pickled at all)."""
+    import copy
+    import ctypes
+    import io
+    from vlsa_amd.prompt_encoder import CONCHPromptEncoder
+    model, tower, learner = _model()
+    with torch.no_grad():
+        a = model.forward_text_only().clone()
+    model._plans["x"] = ctypes.pointer(ctypes.c_int(3))            # what a used model holds: native handles
+    model._train_plans["y"] = ctypes.pointer(ctypes.c_int(4))
+    twin = copy.deepcopy(model)
+    assert twin._plans == {} and twin._train_plans == {} and twin._text_cache is None and twin._tower_lists is None
+    with torch.no_grad():
+        assert torch.equal(twin.forward_text_only(), a)            # same parameters, caches rebuilt on use
+    assert twin.prompt_encoder is not tower and twin._tower_lists[0] is twin.prompt_encoder
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    with torch.no_grad():
+        assert torch.equal(back.forward_text_only(), a)
+    enc = CONCHPromptEncoder(width=128, heads=2, layers=1, vocab_size=50, output_dim=64)
+    enc._cm, enc._cm_arr = ctypes.pointer(ctypes.c_int(1)), ctypes.pointer(ctypes.c_int(2))
+    enc.__dict__["_tt_cache"] = (1, [enc.cls_emb])
+    e2 = copy.deepcopy(enc)
+    assert e2._cm is None and "_cm_arr" not in e2.__dict__ and "_tt_cache" not in e2.__dict__
+    assert set(e2.state_dict()) == set(enc.state_dict())

@@ -191,3 +191,21 @@ def check(code: int, what: str):
     if code != 0:
         msg = load().vlsa_error_string(code).decode()
         raise VlsaNativeError(f"{what} failed: {msg} ({code})")
+
+
+class TransientCaches:
+    """nn.Module mixin.  The attributes named in ``_transient`` hold native handles (ctypes structures with device pointers), device
+    scratch or cached results tied to them; none of it is state.  ``copy.deepcopy`` / ``pickle`` / ``torch.save(module)`` go
+    through ``__getstate__``: the entries are dropped there (ctypes objects with pointers cannot even be pickled) and rebuilt on
+    next use.  ``_transient`` maps a name to a zero-argument factory of its empty value, or to ``None`` = delete the attribute."""
+    _transient: dict = {}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for name, make in self._transient.items():
+            if name in state:
+                if make is None:
+                    del state[name]
+                else:
+                    state[name] = make()
+        return state

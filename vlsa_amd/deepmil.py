@@ -67,7 +67,9 @@ class FeatMIL(nn.Module):
         return X.squeeze(0)
 
 
-class VLFAN(nn.Module):
+class VLFAN(VF.nat.TransientCaches, nn.Module):
+    _transient = {"_step_query": None, "_enc_plans": None, "_fused_scores": None}
+
     """Language-guided visual feature aggregation network (model/deepmil.py:74-215).
 
     P query vectors (text prototypes through a query network, or an ``nn.Parameter``) cross-attend over the N
@@ -302,7 +304,9 @@ class VLFAN(nn.Module):
         return (outs[0] if len(outs) == 1 else torch.cat(outs)), attn
 
 
-class DeepMIL(nn.Module):
+class DeepMIL(VF.nat.TransientCaches, nn.Module):
+    _transient = {"_fused_scores": None}
+
     """ABMIL-style encoder (model/deepmil.py:222-292): optional Feat_Projecter, mean / max / (gated-)attention pooling
     over the N patches, Adapter head mixed with ``keep_ratio`` or a Linear head."""
 

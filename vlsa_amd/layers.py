@@ -9,6 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._native import TransientCaches as _TransientCaches
+
 
 class Adapter(nn.Module):
     """Bias-free bottleneck MLP with ReLU after both layers (model/layers.py:50-62). Keys: fc.0.weight, fc.2.weight."""
@@ -23,8 +25,9 @@ class Adapter(nn.Module):
         return self.fc(x)
 
 
-class Feat_Projecter(nn.Module):
+class Feat_Projecter(_TransientCaches, nn.Module):
     """Linear + LayerNorm on every row (model/layers.py:65-82). Keys: projecter.0.*, projecter.1.*."""
+    _transient = {"_fused": None}
 
     def __init__(self, in_dim: int = 1024, out_dim: int = 1024):
         super().__init__()

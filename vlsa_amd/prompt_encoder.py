@@ -202,12 +202,15 @@ class _TextTowerFn(torch.autograd.Function):
         return demb, None, None
 
 
-class CONCHPromptEncoder(nn.Module):
+class CONCHPromptEncoder(nat.TransientCaches, nn.Module):
     """``CONCHPromptEncoder(coca_model)`` adopts the text tower of a CoCa model exactly like the reference does
     (``coca_model.text.{positional_embedding, transformer, ln_final, cls_emb, text_projection, token_embedding, heads,
     pad_id}``, model/prompt_encoder.py:213-243); ``CONCHPromptEncoder(width=..., heads=..., layers=...)`` builds an empty tower
     of the CONCH text architecture to ``load_state_dict`` into (model/conch/model_configs/conch_ViT-B-16.json: 768 / 12 / 12,
     128 positions, 32007 tokens, 512 outputs)."""
+
+    _transient = {"_cm": lambda: None, "_cm_key": lambda: None, "_cm_arr": None, "_plans": dict, "_pk": lambda: None, "_pk_key": lambda: None,
+                  "_pk_bwd": lambda: False, "_tt_cache": None, "_plan_last": None}
 
     def __init__(self, coca_model=None, *, width: int = 768, heads: int = 12, layers: int = 12, context_length: int = 128,
                  vocab_size: int = 32007, output_dim: int = 512):

@@ -18,6 +18,8 @@ from typing import List, Optional, Sequence, Union
 import torch
 import torch.nn as nn
 
+from ._native import TransientCaches as _TransientCaches
+
 __all__ = ["PlainPromptLearner", "RankPromptLearner", "load_prompt_learner"]
 
 
@@ -84,8 +86,9 @@ class _SentenceFn(torch.autograd.Function):
         return dcontext, drank, None
 
 
-class PlainPromptLearner(nn.Module):
+class PlainPromptLearner(_TransientCaches, nn.Module):
     """One learnable embedding block per rank (model/prompt_learners/plain_prompt_learner.py)."""
+    _transient = {"_hip_tables": None}
 
     rank_tokens_position_candidates = {"tail", "middle", "front"}
 

@@ -35,11 +35,14 @@ def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
     return cls(**image_encoder_cfg)
 
 
-class VLSA(nn.Module):
+class VLSA(VF.nat.TransientCaches, nn.Module):
     """``VLSA(text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None, vlsa_api=...,
     path_clip_model=...)`` -- the reference's constructor (model/vlsa.py:22-105), i.e. what ``load_model('VLSA', **arch_cfg)``
     calls from ``VLSAHandler.func_load_model`` (runner/vlsa_handler.py:112-120).  ``VLSA.from_modules(image_encoder_cfg, ...)``
     assembles the same model from ready-made parts (text features / provider / prompt learner + encoder objects)."""
+
+    _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
+                  "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_head_tickets": lambda: VF.HeadTickets()}
 
     def __init__(self, text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None,
                  info_prefix="VLSA-UNI", **kwargs):
