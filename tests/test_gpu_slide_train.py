@@ -146,3 +146,33 @@ def test_backward_after_the_prepared_block_has_moved_on(monkeypatch):
     for k in ga2:
         _close(ga[k], ga2[k], f"A:{k}")
         _close(gb[k], gb2[k], f"B:{k}")
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 4, False), (2, 16, 64, False), (70, 1, 1, False), (513, 15, 3, True)], ids=lambda s: f"N{s[0]}_P{s[1]}_K{s[2]}" + ("_gated" if s[3] else ""))
+def test_edge_shapes_against_the_oracle(shape):
+    """Smallest / largest query and class counts, one- and two-patch bags, rows with a stride: logits and every gradient of the
+    per-bag node vs the CPU oracle's autograd (model/deepmil.py:187-204, model/vlsa.py:188-192 restated in oracle/vlsa_oracle.py)."""
+    from oracle import vlsa_oracle as O
+    N, P, K, gated = shape
+    case = ("edge", N, P, K, "mean", "default", gated, "iid", 700 + N, True)
+    model, tp = _model(case)
+    wide = _bags([N], torch.float32, seed=N)[0].repeat(1, 2)              # [N, 1024]: the bag is the left half, row stride 1024
+    X = wide[:, :512]
+    assert X.stride(0) == 1024
+    G = torch.randn(1, K, generator=torch.Generator().manual_seed(N + 1)).cuda()
+    logits = model(X[None])[0]
+    assert type(logits.grad_fn).__name__ == "_SlideTrainFnBackward"
+    (logits * G).sum().backward()
+    got = _grads(model, tp)
+    enc = model.mil_encoder
+    leaves = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in _trainable(model, tp).items()}
+    if gated:
+        Q = leaves["Q"]
+    else:
+        Q = enc.Q.res_ratio * leaves["Q"] + enc.Q.get_raw_prompt_features().detach().cpu()
+    r = O.vlsa_vlfan_forward(X.detach().cpu(), Q, leaves["T"], leaves["logit_scale"], head_weight=leaves["W"], head_bias=leaves["b"],
+                             gated_query=gated)
+    assert np.abs(logits.detach().cpu().numpy() - r["logits"].detach().numpy()).max() < 1e-4
+    (r["logits"] * G.cpu()).sum().backward()
+    for k, leaf in leaves.items():
+        _close(got[k], leaf.grad, k)
