@@ -35,10 +35,20 @@ __device__ long long vlsa_dbg_batch[64];
 #define BSTAMP(k)                                                                                            \
     do {                                                                                                     \
         const int k_ = (k);                                                                                  \
-        if (blockIdx.x == 3 && threadIdx.x == 0 && k_ < 64) vlsa_dbg_batch[k_] = __builtin_readcyclecounter(); \
+        if (blockIdx.x == 3 && threadIdx.x == 0 && k_ < 40) vlsa_dbg_batch[k_] = __builtin_readcyclecounter(); \
+        if (blockIdx.x == 3 && threadIdx.x == 0 && (k_ == 1 || k_ == 39)) vlsa_dbg_batch[k_ == 1 ? 62 : 63] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define ISTAMP(k, dep)                                                                                                   \
+    do {                                                                                                                 \
+        if (kown == 12) {                                                                                                 \
+            float sink_ = (dep);                                                                                          \
+            asm volatile("v_mov_b32 %0, %0" : "+v"(sink_));                                                              \
+            if (blockIdx.x == 3 && threadIdx.x == 0) vlsa_dbg_batch[40 + (k)] = __builtin_readcyclecounter();            \
+        }                                                                                                                \
     } while (0)
 #else
 #define BSTAMP(k) do {} while (0)
+#define ISTAMP(k, dep) do {} while (0)
 #endif
 
 namespace bt {
@@ -84,6 +94,12 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = w >> 2, cw = w & 3;
     const int g = lane >> 4, i16 = lane & 15;
+#ifdef VLSA_TIMING
+    const int xmode = S >> 8;               // timing experiments (results are then wrong)
+    S &= 255;
+#else
+    constexpr int xmode = 0;
+#endif
     const int Gb = gridDim.x / S;            // workgroups (and partials) per bag
     const int grp = blockIdx.x / Gb, b = blockIdx.x % Gb, G = Gb;
 
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
             if (have) {
                 int nb, nt;
                 next_of(bag, tile, ntiles, nb, nt);
+                ISTAMP(0, 0.f);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
                 if (nb < B) {
                     issue_tile(nb, nt, slot ^ 1);
@@ -244,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                ISTAMP(1, 0.f);
                 bf16x8 xa[2][4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -254,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 f32x4 Sb[2];
                 Sb[0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 Sb[1] = Sb[0];
+                if (!(xmode & 1))
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -265,9 +284,11 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                     }
                 S[0] += Sb[0];
                 S[1] += Sb[1];
+                ISTAMP(2, S[0][0] + S[1][0] + Nd[0][0] + Nd[1][0]);
             }
 
-            VLSA_BAR();  // readers of the previous exchange are done
+            if (!(xmode & 2)) VLSA_BAR();  // readers of the previous exchange are done
+            if (have) ISTAMP(3, 0.f);
             {
                 unsigned char* mine = exch + cw * kExchWave;
                 *reinterpret_cast<f32x4_ma*>(mine + (0 * 64 + lane) * 16) = S[0];
@@ -280,8 +301,9 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                     reinterpret_cast<float_ma*>(mine + 2048)[16 + i16] = d1;
                 }
             }
-            VLSA_BAR();
+            if (!(xmode & 2)) VLSA_BAR();
             if (have) {
+                ISTAMP(4, 0.f);
                 f32x4 T[2], R2[2];
                 {
                     f32x4 tv[2][4], rv[2][4];
@@ -326,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                         if (srow != nullptr) *reinterpret_cast<f32x4*>(srow + row0) = v;
                     }
                 }
+                ISTAMP(5, T[0][0] + T[1][0]);
                 const float tmax = fmaxf(fmaxf(fmaxf(T[0][0], T[0][1]), fmaxf(T[0][2], T[0][3])),
                                          fmaxf(fmaxf(T[1][0], T[1][1]), fmaxf(T[1][2], T[1][3])));
                 if (__builtin_amdgcn_ballot_w64(tmax > M + kThr) != 0) {
@@ -345,12 +368,14 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float wv = fast_exp2(T[h][r] - M);
+                        const float wv = (xmode & 4) ? T[h][r] : fast_exp2(T[h][r] - M);
                         lsum += wv;
                         const __bf16 hi = (__bf16)wv;
                         ahi[4 * h + r] = hi;
                         alo[4 * h + r] = (__bf16)(wv - (float)hi);
                     }
+                ISTAMP(6, lsum);
+                if (!(xmode & 8))
 #pragma unroll
                 for (int ct = 0; ct < 8; ++ct) {
                     const int c_off = ct * 32 + (i16 & 3) * 8;
@@ -361,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bh, acc[ct], 0, 0, 0);
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc[ct], 0, 0, 0);
                 }
+                ISTAMP(7, acc[0][0] + acc[7][0]);
                 ++kown;
             }
             BSTAMP(stamp++);
@@ -430,9 +456,6 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         BSTAMP(stamp++);
     }
 }
-#ifdef VLSA_TIMING
-extern "C" __global__ void k_dummy_batch_dbg() {}
-#endif
 
 // ---- batched merge: grid (D/64, P, B); explicit strides (in floats) so it serves both the local fold of workgroup
 // partials and the fold of all-gathered per-rank records (see vlsa_vlfan_merge_batch_strided in vlsa_hip.h) ----------
@@ -734,13 +757,18 @@ extern "C" int vlsa_vlfan_partial_batch_scores(const void* bag_desc, int B, int 
                                              (hipStream_t)stream);
     }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
+#ifdef VLSA_TIMING
+    static const int xm = getenv("VLSA_EXP") ? atoi(getenv("VLSA_EXP")) : 0;
+#else
+    constexpr int xm = 0;
+#endif
     if (scores_desc)
         hipLaunchKernelGGL(k_vlfan_partial_dma_batch<true>, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
                            static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S,
                            static_cast<const RowsDesc*>(scores_desc));
     else
         hipLaunchKernelGGL(k_vlfan_partial_dma_batch<false>, dim3(WG), dim3(512), bt::kLdsBytes, (hipStream_t)stream,
-                           static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S,
+                           static_cast<const BagDesc*>(bag_desc), B, qsplit, P, pm, pl, pacc, S | (xm << 8),
                            static_cast<const RowsDesc*>(nullptr));
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
