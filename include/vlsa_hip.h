@@ -581,6 +581,12 @@ int vlsa_vlfan_backward_dx(const void* bag_desc, const void* dx_desc, int B, int
                            const int* tile_start, int n_tiles, const float* dout, const float* out, const float* m2, const float* l,
                            float* delta_ws, void* stream);
 
+/* Device-side descriptor tables of ONE bag for the *_backward entry points above (bag_desc [1], optional second table, row
+ * offset [1], tile_start [2]) written from by-value arguments by a one-thread kernel: dst = 64 bytes of device memory.  Returns the
+ * number of tiles (> 0) or a negative error code.  Layout: {X, N, ld} {extra, N, extra_ld}? {0} {int32 0, int32 n_tiles}. */
+int vlsa_fill_one_bag_tables(void* dst, const void* X, int64_t N, int64_t ld, const void* extra, int64_t extra_ld, int tile_rows,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,7 @@ _SIGNATURES = {
                                   c_void_p]),
     "vlsa_vlfan_forward_bag": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_int,
                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] + [c_void_p] * 13),
+    "vlsa_fill_one_bag_tables": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "vlsa_vlfan_backward_bag": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_float] + [c_void_p] * 14 + [c_int]
                                 + [c_void_p] * 10 + [c_int] + [c_void_p] * 3),
     "vlsa_batch_max_bags": (c_int, []),

@@ -858,3 +858,29 @@ extern "C" int vlsa_attn_scores_backward_dx(const void* bag_desc, const void* dx
 #undef VLSA_ADX
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
+
+// The descriptor tables of ONE bag written on the device from by-value arguments (what vlsa_amd.functional._row_tables uploads for a
+// list of bags: [vlsa_bag_desc X | vlsa_bag_desc extra (optional) | row offset 0 | tile_start {0, n_tiles}]): the single-bag backward
+// calls of the bag-by-bag training loop would otherwise stage ~60 bytes through pinned memory per call (~50 us of host time).
+namespace vlsa {
+__global__ void k_fill_one_bag_tables(long long* dst, const void* X, long long N, long long ld, const void* extra, long long extra_ld,
+                                      int n_tiles) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int o = 0;
+    dst[o++] = (long long)(uintptr_t)X; dst[o++] = N; dst[o++] = ld;
+    if (extra) { dst[o++] = (long long)(uintptr_t)extra; dst[o++] = N; dst[o++] = extra_ld; }
+    dst[o++] = 0;                                           // row offset of bag 0
+    int* ts = reinterpret_cast<int*>(dst + o);
+    ts[0] = 0;
+    ts[1] = n_tiles;
+}
+}  // namespace vlsa
+
+extern "C" int vlsa_fill_one_bag_tables(void* dst, const void* X, int64_t N, int64_t ld, const void* extra, int64_t extra_ld,
+                                        int tile_rows, void* stream) {
+    if (!dst || !X || N < 1 || tile_rows < 1) return VLSA_EINVAL;
+    const int n_tiles = (int)((N + tile_rows - 1) / tile_rows);
+    hipLaunchKernelGGL(vlsa::k_fill_one_bag_tables, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<long long*>(dst), X, (long long)N,
+                       (long long)ld, extra, (long long)extra_ld, n_tiles);
+    return hipGetLastError() == hipSuccess ? n_tiles : VLSA_ELAUNCH;
+}

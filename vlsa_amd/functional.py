@@ -1003,6 +1003,7 @@ class _PinnedRing:
 
 
 _TABLE_RING = {}     # per host thread (autograd runs backward functions on its own thread)
+_ONE_BAG_TABLES = {} # (thread, device, stream) -> 64-byte device buffer of the single-bag tables
 
 
 def _row_tables(bags, tile_rows: int, extra=None):
@@ -1011,8 +1012,26 @@ def _row_tables(bags, tile_rows: int, extra=None):
     ``tile_rows`` rows).  Returns (device buffer, ptr of desc, ptr of extra desc or None, ptr of row_off, ptr of tile_start,
     n_tiles, row offsets as a list)."""
     import threading
-    import numpy as np
     B = len(bags)
+    if B == 1 and bags[0].shape[0] > 0:
+        # one bag (the bag-by-bag training loop): the tables are written on the device from by-value arguments -- one launch
+        # instead of numpy bookkeeping + a pinned staging copy + an event per call
+        x, lib = bags[0], nat.load()
+        s = _stream()
+        key = (threading.get_ident(), x.device, s.value or 0)
+        buf = _ONE_BAG_TABLES.get(key)
+        if buf is None:
+            if len(_ONE_BAG_TABLES) > 64:
+                _ONE_BAG_TABLES.clear()
+            buf = _ONE_BAG_TABLES[key] = torch.zeros(8, dtype=torch.int64, device=x.device)   # stream-ordered reuse
+        ex = extra[0] if extra is not None else None
+        n_tiles = lib.vlsa_fill_one_bag_tables(_p(buf), _p(x), x.shape[0], x.stride(0), _p(ex), 0 if ex is None else ex.stride(0), int(tile_rows), s)
+        if n_tiles < 0:
+            nat.check(n_tiles, "vlsa_fill_one_bag_tables")
+        base = buf.data_ptr()
+        o = 6 if ex is not None else 3
+        return buf, base, (base + 24 if ex is not None else None), base + 8 * o, base + 8 * (o + 1), int(n_tiles), [0, int(x.shape[0])]
+    import numpy as np
     rows = [int(x.shape[0]) for x in bags]
     n64 = 3 * B + (3 * B if extra is not None else 0) + B + (B + 2) // 2
     host = np.zeros(n64, dtype=np.int64)
