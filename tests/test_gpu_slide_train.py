@@ -176,3 +176,47 @@ def test_edge_shapes_against_the_oracle(shape):
     (r["logits"] * G.cpu()).sum().backward()
     for k, leaf in leaves.items():
         _close(got[k], leaf.grad, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_trainable_feat_projecter_in_front_of_the_per_bag_node(dtype, monkeypatch):
+    """use_feat_proj=True (the constructor default of the reference's encoders, model/deepmil.py:75) with a projecter that trains:
+    the projecter is its own HIP node, the per-bag node hands dL/dX of the aggregation back to it (vlsa_vlfan_backward_dx).  Against
+    the general route (autograd over the aggregation function + torch ops) on the same bags: logits and every gradient."""
+    from vlsa_amd.prompt_adapter import PromptAdapter
+    from vlsa_amd.vlsa import VLSA
+    from test_gpu_modules import TextParam
+    P = K = 12
+    params = cases.make_params(P, K, 4711)
+    tp = TextParam(params["T"])
+    qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=params["prompt"], res_ratio=0.5)
+    cfg = dict(name="VLFAN", dim_in=512, dim_hid=256, use_feat_proj=True, drop_rate=0.25, num_query=P, query="Text", query_pooling="mean",
+               pred_head="default")
+    torch.manual_seed(3)
+    model = VLSA.from_modules(cfg, text_provider=lambda: tp.T, prompt_learner=tp, query_network=qnet, logit_scale_init=cases.LOGIT_SCALE)
+    with torch.no_grad():
+        model.mil_encoder.Q.residual_features.copy_(params["resid"])
+    model = model.cuda().train()
+    enc = model.mil_encoder
+    assert enc.feat_proj is not None and all(p.requires_grad for p in enc.feat_proj.parameters())
+    bags = _bags([40, 700, 3001], dtype)
+    Gm = torch.randn(len(bags), K, generator=torch.Generator().manual_seed(8)).cuda()
+    named = dict(model.named_parameters())
+    named["T"] = tp.T
+
+    def step():
+        logits = torch.cat([model(x[None])[0] for x in bags], dim=0)
+        (logits * Gm).sum().backward()
+        g = {k: p.grad.detach().clone() for k, p in named.items() if p.grad is not None}
+        model.zero_grad(set_to_none=True); tp.zero_grad(set_to_none=True)
+        return logits, g
+
+    fast_logits, fast = step()
+    assert type(fast_logits.grad_fn.next_functions[0][0]).__name__ == "_SlideTrainFnBackward"
+    monkeypatch.setattr(type(model), "_slide_train", lambda self, X, T: None)
+    gen_logits, general = step()
+    assert type(gen_logits.grad_fn.next_functions[0][0]).__name__ != "_SlideTrainFnBackward"
+    assert np.abs(fast_logits.detach().cpu().numpy() - gen_logits.detach().cpu().numpy()).max() < 1e-4
+    assert set(fast) == set(general) and any(k.startswith("mil_encoder.feat_proj") for k in fast)
+    for k in general:
+        _close(fast[k], general[k], k)

@@ -415,14 +415,22 @@ class _SlideTrainFn(torch.autograd.Function):
                                               gat("dE"), gat("dQ"), s), "vlsa_vlfan_backward_bag")
         def v(name, n, *sh):
             return gb[goff[name]:goff[name] + n].view(*sh)
-        return (None, v("dQ", nq * D, nq, D), v("dW", D * D, D, D) if has_w else None, v("db", D, D) if (has_w and has_b) else None,
+        dX = None
+        if ctx.needs_input_grad[0]:      # the bag is the output of a trainable Feat_Projecter (fp32 [N, 512]): dL/dX of the aggregation
+            dX = torch.empty(N, D, dtype=torch.float32, device=dev)
+            tkeep, p_desc, p_dx, _, p_ts, n_tiles, _ = _row_tables([X2], 64, extra=[dX])
+            delta = torch.empty(1, nat.P_STRIDE, dtype=torch.float32, device=dev)
+            nat.check(lib.vlsa_vlfan_backward_dx(p_desc, p_dx, 1, D, qprep, P, plan.scale, p_ts, n_tiles, gat("drows"), at("out"), at("m2"),
+                                                 at("l"), _p(delta), s), "vlsa_vlfan_backward_dx")
+        return (dX, v("dQ", nq * D, nq, D), v("dW", D * D, D, D) if has_w else None, v("db", D, D) if (has_w and has_b) else None,
                 v("dT", K * D, K, D), v("dls", 1, ls_shape), None)
 
 
 def slide_train(X2: torch.Tensor, Q: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor, plan: SlideTrainPlan):
-    """Differentiable (logits [1, K], unit image features [1, D], unit text features [K, D]) of ONE bag [N, 512] (bf16 / fp32, no
-    gradient into the bag): cross attention with the queries Q, mean query pooling, Linear / identity adapter, cosine logits
-    (model/deepmil.py:187-204, model/vlsa.py:188-192).  Gradients: Q, W, b, T, logit_scale.  All tensors fp32 contiguous on
+    """Differentiable (logits [1, K], unit image features [1, D], unit text features [K, D]) of ONE bag [N, 512] (bf16 / fp32):
+    cross attention with the queries Q, mean query pooling, Linear / identity adapter, cosine logits (model/deepmil.py:187-204,
+    model/vlsa.py:188-192).  Gradients: Q, W, b, T, logit_scale -- and the bag itself when it is an fp32 tensor that requires
+    grad (the output of a trainable Feat_Projecter: vlsa_vlfan_backward_dx).  All tensors fp32 contiguous on
     the bag's device (Q [nq, 512], T [K, 512], logit_scale 0-dim); see ``SlideTrainPlan``."""
     _need_gpu(X2, Q, T, logit_scale)
     return _SlideTrainFn.apply(X2, Q, W, b, T, logit_scale, plan)

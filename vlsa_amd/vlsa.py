@@ -376,9 +376,12 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             return None
         if enc.feat_proj is not None:
             if enc._projecter_trains():
-                return None                     # the projecter's gradient comes back through dX: general route
-            with torch.no_grad():
-                X = enc.project(X)
+                X = enc.project(X)              # its own HIP autograd node; the aggregation node below hands dX back to it
+                if not (X.is_cuda and X.dtype == torch.float32 and X.shape[-1] == 512):
+                    return None
+            else:
+                with torch.no_grad():
+                    X = enc.project(X)
         X2 = VF._bag2d(X)
         N, D = X2.shape
         T = text_features
