@@ -309,7 +309,12 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     def _needs_grad(self, text_features):
         if not torch.is_grad_enabled():
             return False
-        return text_features.requires_grad or any(p.requires_grad for p in self.parameters())
+        # the text side reaches the output through `text_features` only, so its parameters need no look: what is left are the
+        # logit scale and the MIL encoder (a walk over the whole model -- 150 tower tensors first -- cost ~0.3 ms per bag with
+        # frozen prompts, in the loop that calls the model once per bag)
+        if text_features.requires_grad or self.logit_scale.requires_grad:
+            return True
+        return any(p.requires_grad for p in self.mil_encoder.parameters())
 
     def _fused_vlfan(self, X, text_features):
         enc = self.mil_encoder
