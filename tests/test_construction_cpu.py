@@ -175,3 +175,37 @@ def test_reference_handler_builds_the_hip_model_after_one_line_patch(hooks_insta
     ref = json.load(open(os.path.join(GOLDEN, "handler_keys.json")))
     assert {k: list(v.shape) for k, v in model.state_dict().items() if "prompt_encoder" not in k} == ref["saved"]
     assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == ref["requires_grad"]
+
+
+@pytest.mark.skipif(not _ref_import.reference_available(), reason="needs the reference checkout (build container only)")
+def test_patch_reference_can_make_the_handlers_datasets_resident(hooks_installed):
+    """``patch_reference(resident_bags=True)``: the dataset factory the reference's handlers call
+    (runner/sa_handler.py:111-116 -> dataset/utils.py prepare_surv_dataset) hands back its dataset wrapped in ResidentBags."""
+    _ref_import.import_reference()
+    cwd = os.getcwd()
+    os.chdir(_ref_import.REF_ROOT)
+    import dataset.utils as ref_ds
+    import model.deepmil as ref_mil
+    import model.utils as ref_utils
+    import model.vlsa as ref_vlsa
+    import runner.sa_handler as ref_sa
+    from vlsa_amd.ingest import ResidentBags
+    from vlsa_amd.model_utils import patch_reference
+    original = ref_ds.prepare_surv_dataset
+    assert ref_sa.prepare_surv_dataset is original
+    ref_ds.prepare_surv_dataset = lambda *a, **k: ("a dataset", a, k)      # stands in for the file-reading factory
+    ref_sa.prepare_surv_dataset = ref_ds.prepare_surv_dataset
+    saved = patch_reference(resident_bags=True, dtype=torch.float32)
+    try:
+        out = ref_sa.prepare_surv_dataset(["p1"], {"cfg": 1}, meta_data=None)
+        assert isinstance(out, ResidentBags) and out.dataset == ("a dataset", (["p1"], {"cfg": 1}), {"meta_data": None})
+        assert out._dtype == torch.float32
+        assert ref_ds.prepare_surv_dataset is ref_sa.prepare_surv_dataset
+        patch_reference(resident_bags=True)                                # idempotent: not wrapped twice
+        assert not isinstance(ref_sa.prepare_surv_dataset(["p1"], {}).dataset, ResidentBags)
+    finally:
+        ref_ds.prepare_surv_dataset = ref_sa.prepare_surv_dataset = original
+        ref_utils.VLSA, ref_vlsa.VLSA = saved["VLSA_utils"], saved["VLSA_vlsa"]
+        ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = saved["VLFAN"], saved["FeatMIL"], saved["DeepMIL"]
+        ref_mil.logit_pooling = ref_vlsa.logit_pooling = saved["logit_pooling"]
+        os.chdir(cwd)

@@ -116,3 +116,55 @@ def test_arena_feeds_forward_bags():
 def ArenaLayout_rows(sizes):
     from vlsa_amd.ingest import ArenaLayout
     return ArenaLayout.rows_needed(sizes)
+
+
+class _FakePatchDataset(torch.utils.data.Dataset):
+    """items shaped like WSIPatchSurv's 'patch' mode (dataset/PatchWSI.py:197-215)"""
+
+    def __init__(self, sizes, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.feats = [torch.randn(n, 512, generator=g) for n in sizes]
+        self.uid = [f"p{i}" for i in range(len(sizes))]
+        self.hits = 0
+
+    def __len__(self):
+        return len(self.feats)
+
+    def __getitem__(self, i):
+        self.hits += 1
+        return torch.Tensor([i]).to(torch.int), (self.feats[i].to(torch.float), torch.Tensor([0])), torch.Tensor([float(i), 1.0]).to(torch.float)
+
+
+def test_resident_bags_passes_items_through_in_a_loader_worker(monkeypatch):
+    from vlsa_amd.ingest import ResidentBags
+    ds = _FakePatchDataset([5, 9])
+    rb = ResidentBags(ds, device="cuda")              # no device is touched until an item is uploaded
+    assert len(rb) == 2 and rb.uid == ["p0", "p1"]
+    monkeypatch.setattr(torch.utils.data, "get_worker_info", lambda: object())
+    idx, (feats, extra), label = rb[1]
+    assert not feats.is_cuda and torch.equal(feats, ds.feats[1]) and rb.reads == 0 and rb.resident_bytes() == 0
+
+
+@pytest.mark.gpu
+def test_resident_bags_uploads_once_and_feeds_the_handlers_loop():
+    """Two epochs of the handler's loader loop (runner/vlsa_handler.py:195-205: batch_size 1, default collate, ``data_x[0].cuda()``):
+    the wrapped dataset is read once per item, the features arrive on the device as the bf16 rounding of the source."""
+    from vlsa_amd.ingest import ResidentBags
+    sizes = [70, 1, 3000, 257]
+    ds = _FakePatchDataset(sizes)
+    rb = ResidentBags(ds, segment_rows=2048)          # forces a second segment and an oversized bag of its own
+    loader = torch.utils.data.DataLoader(rb, batch_size=1, shuffle=True, num_workers=0, generator=torch.Generator().manual_seed(1))
+    for epoch in range(2):
+        seen = set()
+        for data_idx, data_x, data_y in loader:
+            X = data_x[0].cuda()
+            i = int(data_idx[0, 0])
+            seen.add(i)
+            assert X.is_cuda and X.dtype == torch.bfloat16 and tuple(X.shape) == (1, sizes[i], 512)
+            assert torch.equal(X[0].cpu(), ds.feats[i].to(torch.bfloat16))
+            assert float(data_y[0, 0]) == float(i) and data_x[1].shape == (1, 1)
+        assert seen == set(range(len(sizes)))
+        assert ds.hits == len(sizes) and rb.reads == len(sizes)      # epoch 2 never touched the wrapped dataset
+    assert len(rb._segments) >= 2
+    fp = ResidentBags(_FakePatchDataset(sizes), dtype=torch.float32)
+    assert torch.equal(fp[2][1][0].cpu(), fp.dataset.feats[2])       # fp32: bit for bit

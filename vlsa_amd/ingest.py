@@ -19,6 +19,7 @@ import ctypes
 from typing import Dict, Iterable, List, Sequence, Tuple, Union
 
 import torch
+import torch.utils.data
 
 from . import _native as nat
 from ._native import VlsaNativeError
@@ -202,3 +203,66 @@ class DeviceBagArena:
 
     def __len__(self) -> int:
         return len(self.layout)
+
+
+class ResidentBags(torch.utils.data.Dataset):
+    """Drop-in wrapper for the reference's bag datasets (``WSIPatchSurv`` in 'patch' mode, ``FewShot_WSIPatchSurv``:
+    dataset/PatchWSI.py:143-215): items are ``(index, (feats [N, 512], extra...), label)``.  The first time an item is asked for it is
+    read through the wrapped dataset -- ``.pt`` files, multi-slide concat, ``.to(float)`` exactly as there -- and its features go
+    into HBM once (``DeviceBagArena``: bf16 by default, pinned double-buffered async copies); afterwards the item comes back with
+    ``feats`` as a view of the resident rows, so the handler's ``data_x[0].cuda()`` (runner/vlsa_handler.py:205,324) costs nothing
+    and epochs 2.. never touch the disk or PCIe again.  No handler change: wrap what ``prepare_surv_dataset`` returns
+    (``vlsa_amd.model_utils.patch_reference(resident_bags=True)`` does) and run the loaders with ``num_workers: 0`` -- inside a
+    DataLoader worker process (no device there) items pass through unchanged.
+
+    ``dtype=torch.float32`` keeps the features bit for bit (2 KB per patch).  Segments of ``segment_rows`` rows are allocated as
+    the data arrives (a bag larger than a segment gets its own)."""
+
+    def __init__(self, dataset, device="cuda", dtype: torch.dtype = torch.bfloat16, segment_rows: int = 1 << 21, D: int = 512):
+        self.dataset = dataset
+        self._device, self._dtype, self._segment_rows, self._D = torch.device(device), dtype, int(segment_rows), int(D)
+        self._segments: List[DeviceBagArena] = []
+        self._where: Dict[int, DeviceBagArena] = {}
+        self._rest: Dict[int, tuple] = {}
+        self.reads = 0                    # items fetched from the wrapped dataset so far
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getattr__(self, name):          # uid, get_meta_data, summary, ...: whatever the handler asks the dataset for
+        if name in ("dataset", "_segments", "_where", "_rest"):
+            raise AttributeError(name)
+        return getattr(self.dataset, name)
+
+    def _segment_for(self, n_rows: int) -> DeviceBagArena:
+        need = -(-n_rows // ROW_ALIGN) * ROW_ALIGN
+        if self._segments and self._segments[-1].layout.rows_free() >= need:
+            return self._segments[-1]
+        seg = DeviceBagArena(max(self._segment_rows, need), self._device, D=self._D, dtype=self._dtype)
+        self._segments.append(seg)
+        return seg
+
+    def resident_bytes(self) -> int:
+        return sum(s.data.numel() * s.data.element_size() for s in self._segments)
+
+    def __getitem__(self, i):
+        i = int(i)
+        if torch.utils.data.get_worker_info() is not None:
+            return self.dataset[i]        # a loader worker process: no device here
+        if i not in self._rest:
+            item = self.dataset[i]
+            self.reads += 1
+            try:
+                idx, data_x, label = item
+                feats = data_x[0]
+                ok = (isinstance(feats, torch.Tensor) and not feats.is_cuda and feats.dim() == 2 and feats.shape[1] == self._D
+                      and feats.is_floating_point() and feats.shape[0] > 0)
+            except (TypeError, ValueError, IndexError):
+                ok = False
+            if not ok:
+                return item               # not a bag of patch features (cluster / graph modes, empty bags): untouched
+            seg = self._segment_for(feats.shape[0])
+            seg.add(i, feats)
+            self._where[i], self._rest[i] = seg, (idx, tuple(data_x[1:]), label)
+        idx, rest, label = self._rest[i]
+        return idx, (self._where[i].bag(i), *rest), label

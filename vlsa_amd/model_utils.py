@@ -62,7 +62,7 @@ def load_prompt_adapter(prompt_encoder, cfg: dict):
     return PromptAdapter(prompt_encoder, **cfg)
 
 
-def patch_reference():
+def patch_reference(resident_bags: bool = False, **resident_kw):
     """Point the reference's factory at this package (call once, before the handler is built):
 
         import vlsa_amd.model_utils; vlsa_amd.model_utils.patch_reference()
@@ -71,6 +71,9 @@ def patch_reference():
       model from the handler's unmodified ``arch_cfg``;
     * ``model.deepmil.{VLFAN, FeatMIL, DeepMIL, logit_pooling}`` -> this package's: the name lookup of
       model/utils_vl.py:129-138 and ``utils/model_inference.py`` see the same classes.
+    * ``resident_bags=True``: ``dataset.utils.prepare_surv_dataset`` (and the name ``runner.sa_handler`` imported from it, if already
+      loaded) wraps what it returns in ``vlsa_amd.ingest.ResidentBags`` -- every bag is read and uploaded ONCE, later epochs find it in
+      HBM (bf16; ``dtype=torch.float32`` in ``resident_kw`` keeps fp32).  Needs ``num_workers: 0`` in the run's config.
     Returns the patched reference modules (for un-patching in tests)."""
     import model.deepmil as ref_mil
     import model.utils as ref_utils
@@ -83,4 +86,20 @@ def patch_reference():
     ref_vlsa.VLSA = VLSA
     ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = fast.VLFAN, fast.FeatMIL, fast.DeepMIL
     ref_mil.logit_pooling = ref_vlsa.logit_pooling = fast.logit_pooling
+    if resident_bags:
+        import sys
+        import dataset.utils as ref_ds
+        from .ingest import ResidentBags
+        original = ref_ds.prepare_surv_dataset
+        if not getattr(original, "_vlsa_resident", False):
+            def prepare_surv_dataset(*args, **kwargs):
+                return ResidentBags(original(*args, **kwargs), **resident_kw)
+            prepare_surv_dataset._vlsa_resident = True
+            prepare_surv_dataset.__wrapped__ = original
+            saved["prepare_surv_dataset"] = original
+            ref_ds.prepare_surv_dataset = prepare_surv_dataset
+            for name in ("runner.sa_handler", "runner.vlsa_handler", "runner.base_handler"):
+                mod = sys.modules.get(name)
+                if mod is not None and getattr(mod, "prepare_surv_dataset", None) is original:
+                    mod.prepare_surv_dataset = prepare_surv_dataset
     return saved
