@@ -139,6 +139,10 @@ json.dump(collect(("at_f", "at_w"), ["k_vlfan_partial_dma_batch<true>", "k_attn_
 PY
 rm -rf $O/mb $O/pmc_mb_a $O/pmc_mb_b $O/pmc_mb_c $O/pmc_mb_d $O/pmc_at_f $O/pmc_at_w
 python tools/bench_text.py --no-prefix 2>&1 | tail -2 > $O/bench_text_noprefix.txt
+# what the machine gives next to the product: read-ceiling probe (built here), the product on cache-resident rows
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/hbm_read_probe.hip -o tools/probes/libhbm_read_probe.so 2>/dev/null
+python tools/hbm_read_probe.py 2>&1 | grep -v amdgpu > $O/hbm_read_probe.txt
+python tools/kbench_resident.py 2>&1 | grep -v amdgpu > $O/kbench_resident.txt
 for n in 40000 50000 70000 100000; do for sp in 0 1; do VLSA_GS_SPLIT=$sp python tools/gs_rows.py $n 2>/dev/null | sed "s/$/ split=$sp/"; done; done > $O/gs_split.txt
 rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_fetch64 $O/pmc_write64 $O/pmc_lds64 $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
 cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; cut -c1-200 $O/bench_driver_args.json; cat $O/pmc_gated_scores.json | head -30
