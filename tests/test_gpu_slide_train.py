@@ -220,3 +220,11 @@ def test_trainable_feat_projecter_in_front_of_the_per_bag_node(dtype, monkeypatc
     assert set(fast) == set(general) and any(k.startswith("mil_encoder.feat_proj") for k in fast)
     for k in general:
         _close(fast[k], general[k], k)
+
+
+def test_fuzz_against_the_general_route():
+    """tools/fuzz_slide_train.py, 40 random configurations (N, P, K, dtype, gated query, adapter, row stride)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_slide_train.py"), "40"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "40 random cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
