@@ -988,9 +988,11 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             // 32-row workgroup tiles when they still fit one round of the CUs (K = 12 prompts: 5 x 48 = 240 workgroups of 2/3 the
             // work instead of 4 x 48 = 192), else 48-row tiles
             const int nt = (3 * d) % 48 == 0 ? (3 * d) / 48 : (3 * d) / 32;
-            // few rows (shared prefix: K = 12 prompts are 101 rows = 7 row tiles): 16 x 64 tiles fill the CUs (7 x 36 = 252
-            // workgroups) with 2/3 of the MFMA work of a 32 x 48 tile each
-            if ((3 * d) % 64 == 0 && ((s.M + 15) / 16) * (3 * d / 64) <= 256 && ((s.M + 15) / 16) * 2 < ((s.M + 31) / 32) * 3 && d / 4 / 16 == 12)
+            // few rows (shared prefix: K = 12 prompts are 101 rows = 7 row tiles): whenever 16 x 64 tiles fit ONE round of the CUs
+            // (7 x 36 = 252 workgroups) they are taken -- 2/3 of the MFMA work of a 32 x 48 tile per workgroup, and a launch lasts as long
+            // as one workgroup (forward 660 -> 620 us, forward + backward 1654 -> 1593 us; until the end of round 3 a second condition that
+            // could never hold kept these shapes switched off)
+            if ((3 * d) % 64 == 0 && ((s.M + 15) / 16) * (3 * d / 64) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<1, 4, PRO_LN, 12, 4>(a, Mp, st)));
             else if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
@@ -1010,7 +1012,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             a.M_real = s.M;
             // 32 x 64 workgroup tiles when they fit one round (K = 12 prompts: 5 x 48 = 240 workgroups, 160 instead of 192 rows of
             // f32-MFMA work -- this product is matrix-pipe-bound), else 48 x 48
-            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && ((s.M + 15) / 16) * 3 < ((s.M + 31) / 32) * 4 && d / 4 / 16 == 12)
+            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<1, 4, PRO_LN, 12, 6>(a, Mp, st)));       // few rows: 16 x 96 tiles (7 x 32 = 224 workgroups)
             else if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<2, 4, PRO_LN, 12, 4>(a, Mp, st)));
@@ -1072,7 +1074,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             GemmArgs a = gemm_args(c.dxa_t, pw.proj_w, 4 * d, d);
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
             a.M_real = s.M;
-            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && ((s.M + 15) / 16) * 3 < ((s.M + 31) / 32) * 4 && d / 4 / 16 == 12)
+            if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 6>(a, Mp, st)));
             else if (Mp % 32 == 0 && (4 * d) % 64 == 0 && ((s.M + 31) / 32) * (4 * d / 64) <= 256 && d / 4 / 16 == 12)
                 TT_TRY((launch_gemm_g<2, 4, PRO_NONE, 12, 4>(a, Mp, st)));
