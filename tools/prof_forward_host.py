@@ -1,0 +1,45 @@
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import torch
+import text_cases as TC
+from vlsa_amd.prompt_adapter import PromptAdapter
+from vlsa_amd.prompt_encoder import CONCHPromptEncoder
+from vlsa_amd.prompt_learner import RankPromptLearner
+from vlsa_amd.vlsa import VLSA
+from vlsa_amd import functional as VF
+import gc; gc.collect(); gc.freeze()
+dev = "cuda"; K = P = 12
+c = TC.TOWERS["conch"]
+enc = CONCHPromptEncoder(width=c["width"], heads=c["heads"], layers=c["layers"], vocab_size=c["vocab"], output_dim=c["out_dim"])
+for p_ in enc.parameters(): p_.requires_grad_(False)
+enc = enc.to(dev)
+table, ctx_key, names = TC.synthetic_prompt_table(c["vocab"], 1)
+pl = RankPromptLearner(dict(max_num_tokens=127, embedding_dim=768, embedding_dtype=torch.float32), TC.ReplayTokenizer(table), enc.token_embedding,
+                       num_base_ranks=4, num_ranks=K, num_tokens_per_rank=4, num_context_tokens=8, init_context=ctx_key, init_rank_names=names)
+qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=torch.randn(P, 512), res_ratio=0.5)
+cfg = dict(name="VLFAN", dim_in=512, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean", pred_head="default")
+net = VLSA.from_modules(cfg, prompt_learner=pl, prompt_encoder=enc, query_network=qnet).to(dev).train()
+x = torch.randn(1, 64, 512, device=dev).to(torch.bfloat16)
+def t(fn, n=2000):
+    for _ in range(50): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    dt = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize()
+    return dt
+net(x)
+print(f"net(x) train, tiny bag (host side): {t(lambda: net(x)):6.1f} us")
+print(f"  _text_features():               {t(net._text_features):6.1f} us")
+print(f"  _provider_key():                {t(net._provider_key):6.1f} us")
+tf = net._text_features()
+print(f"  _needs_grad():                  {t(lambda: net._needs_grad(tf)):6.1f} us")
+print(f"  enc.step_query():               {t(net.mil_encoder.step_query):6.1f} us")
+print(f"  fused_head_spec():              {t(net.mil_encoder.fused_head_spec):6.1f} us")
+Q = net.mil_encoder.step_query(); spec = net.mil_encoder.fused_head_spec(); plan = next(iter(net._train_plans.values()))
+X2 = x[0]
+print(f"  VF.slide_train(...) alone:      {t(lambda: VF.slide_train(X2, Q, spec[2], spec[3], tf, net.logit_scale, plan)):6.1f} us")
+print(f"  _slide_train(x, tf):            {t(lambda: net._slide_train(x, tf)):6.1f} us")
+with torch.no_grad():
+    net.eval(); net(x)
+    print(f"net(x) eval, tiny bag:            {t(lambda: net(x)):6.1f} us")

@@ -42,7 +42,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     assembles the same model from ready-made parts (text features / provider / prompt learner + encoder objects)."""
 
     _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
-                  "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_head_tickets": lambda: VF.HeadTickets()}
+                  "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
+                  "_head_tickets": lambda: VF.HeadTickets()}
 
     def __init__(self, text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None,
                  info_prefix="VLSA-UNI", **kwargs):
@@ -142,7 +143,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         self._train_plans = {}
         self._tower_lists = None
         self._head_tickets = VF.HeadTickets()
-        self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ was computed from
+        self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ / queries were computed from
+        self._prepared_query, self._prepared_qver = None, -1
 
     # -- builders of the text side (model/vlsa.py:107-147) -----------------------------------------------------------------
     def _build_prompt_learner(self, prompt_learner_cfg, pretrained_prompt_learner_cfg):
@@ -235,7 +237,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             self._tower_lists = None
             self._plans.clear()
             self._train_plans.clear()
-            self._prepared_text = None
+            self._prepared_text = self._prepared_query = None
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
@@ -325,7 +327,10 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         mode, pw, W, b = spec
         X2 = VF._bag2d(X)
         N, D = X2.shape
-        Q = enc.get_query().detach().float().contiguous()
+        Qsrc = enc.step_query()                     # a text adapter's output is evaluated once per parameter version, not per bag
+        Q = Qsrc.detach()
+        if Q.dtype != torch.float32 or not Q.is_contiguous():
+            Q = Q.float().contiguous()
         P = Q.shape[0] - (1 if enc.gated_query else 0)
         K = text_features.shape[0]
         if not (1 <= P <= 16 and 1 <= K <= 64 and D % 8 == 0 and D <= 1024):
@@ -346,21 +351,19 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         # queries / text features only change with their parameters: in an evaluation loop they are prepared once, not per bag.
         # The key never contains the ADDRESS of a transient tensor (a freed block is handed out again by the caching allocator
         # with `_version == 0`): the text side contributes the identity of the exact tensor object the last preparation read,
-        # which this module keeps alive (`_prepared_text`), the queries the identity + in-place version of their source
-        # parameters / buffers (alive as long as the query network is).  A query source this object cannot enumerate (a plain
-        # callable) gives no key: prepare every call.
-        if isinstance(enc.Q, nn.Module):
-            qsrc = list(enc.Q.parameters()) + list(enc.Q.buffers())
-        elif isinstance(enc.Q, torch.Tensor):
-            qsrc = [enc.Q]
+        # which this module keeps alive (`_prepared_text`), the queries likewise (`_prepared_query`: the tensor `step_query` hands
+        # out, whose own cache follows the query network's parameters).  A query source that is a plain callable gives no key:
+        # prepare every call.
+        if not isinstance(enc.Q, (nn.Module, torch.Tensor)):
+            pkey = None                                  # an opaque callable: a fresh tensor per call, nothing to key on
         else:
-            qsrc = None
-        if qsrc is None:
-            pkey = None
-        else:
-            if self._prepared_text is not text_features:
-                self._prepared_text, self._prepared_gen = text_features, self._prepared_gen + 1
-            pkey = tuple((id(t), t._version) for t in qsrc) + ((self._prepared_gen, text_features._version),)
+            # `step_query` hands out the SAME tensor object as long as the query source's parameters / buffers, flags and the grad
+            # mode are unchanged (a Parameter query: the parameter itself), so identity + in-place version of that object -- kept
+            # alive here -- is the query part of the key
+            if self._prepared_text is not text_features or self._prepared_query is not Qsrc or self._prepared_qver != Qsrc._version:
+                self._prepared_text, self._prepared_query, self._prepared_qver = text_features, Qsrc, Qsrc._version
+                self._prepared_gen += 1
+            pkey = (self._prepared_gen, text_features._version)
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
                  None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey,
