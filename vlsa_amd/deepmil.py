@@ -68,7 +68,7 @@ class FeatMIL(nn.Module):
 
 
 class VLFAN(VF.nat.TransientCaches, nn.Module):
-    _transient = {"_step_query": None, "_enc_plans": None, "_fused_scores": None}
+    _transient = {"_step_query": None, "_enc_plans": None, "_fused_scores": None, "_coattn_scale": None}
 
     """Language-guided visual feature aggregation network (model/deepmil.py:74-215).
 
@@ -107,6 +107,15 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
     # -- reference API ---------------------------------------------------------------------------------
     def get_coattn_logit_scale(self):
         return self.coattn_logit_scale.exp()
+
+    def coattn_scale(self) -> float:
+        """exp(coattn_logit_scale) as a Python float, cached per (tensor object, in-place version): the per-bag routes ask for it
+        once per bag."""
+        t = self.coattn_logit_scale
+        c = self.__dict__.get("_coattn_scale")
+        if c is None or c[0] is not t or c[1] != t._version:
+            c = self.__dict__["_coattn_scale"] = (t, t._version, float(t.detach().exp()))
+        return c[2]
 
     def reset_query(self, query_network):
         assert self.query_type != "Parameter", f"Cannot override Q (query) for query_type ({self.query_type})."
@@ -225,7 +234,7 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
             if len(plans) > 32:
                 plans.clear()
             plan = plans[key] = VF.VlfanInferencePlan(N, 512, P, 1, dev, gated=self.gated_query, pool=mode, identity_head=W is None,
-                                                      want_attn=ret_with_attn, coattn_scale=float(self.coattn_logit_scale.exp()))
+                                                      want_attn=ret_with_attn, coattn_scale=self.coattn_scale())
             plan._dummy = (torch.ones(1, 512, device=dev), torch.zeros((), device=dev))
         outs = {"v": torch.empty(512, dtype=torch.float32, device=dev)}
         if ret_with_attn:
@@ -248,7 +257,7 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
         if self.gated_query:
             assert self._pos_gated_query == -1, "The gated query is placed at the end by default."
             assert Q.shape[0] == self.num_query + 1, f"Query number is expected to be {self.num_query + 1}."
-        scale = float(self.coattn_logit_scale.exp())
+        scale = self.coattn_scale()
         # HIP forward and backward: dQ always, dX as well when the bag carries a gradient (a trainable Feat_Projecter in front:
         # its output is an fp32 [N, 512] bag; vlsa_vlfan_backward_dx)
         out, A = VF.vlfan_cross_attention(X, Q, gated=self.gated_query, coattn_scale=scale, want_attn=ret_with_attn)
@@ -291,7 +300,7 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
 
     def _aggregate_bags(self, bags, ret_with_attn):
         Q = self.get_query()
-        scale = float(self.coattn_logit_scale.exp())
+        scale = self.coattn_scale()
         outs, attn = [], []
         for i in range(0, len(bags), 64):
             r = VF.vlfan_cross_attention_bags(bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale,

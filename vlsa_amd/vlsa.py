@@ -14,6 +14,7 @@ exact: it is recomputed whenever an optimizer step (or any in-place update) touc
 from __future__ import annotations
 
 import math
+import operator
 from typing import Callable, Optional
 
 import torch
@@ -24,6 +25,9 @@ from . import deepmil as mil_encoders
 from . import functional as VF
 from .deepmil import FeatMIL, VLFAN, logit_pooling
 from .prompt_adapter import PromptAdapter
+
+
+_GET_TRAINING, _GET_VERSION = operator.attrgetter("training"), operator.attrgetter("_version")    # C-level loops in _provider_key
 
 
 def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
@@ -208,7 +212,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 if tl is None or tl[0] is not m:
                     sub, tensors = self._walk_module(m)
                     tl = self._tower_lists = (m, sub, tensors)
-                key.append((id(m), len(tl[2]), tuple([x.training for x in tl[1]]), tuple([t._version for t in tl[2]])))
+                key.append((id(m), len(tl[2]), tuple(map(_GET_TRAINING, tl[1])), tuple(map(_GET_VERSION, tl[2]))))
             else:
                 sub, tensors = self._walk_module(m)
                 key.append((id(m), tuple([(id(x), x.training) for x in sub]), tuple([(id(t), t._version) for t in tensors])))
@@ -412,7 +416,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if T.dtype != torch.float32 or not T.is_contiguous():
             T = T.float().contiguous()
         K = T.shape[0]
-        scale = float(enc.coattn_logit_scale.exp())
+        scale = enc.coattn_scale()
         key = (D, P, K, X2.device, enc.gated_query, W is None, scale)
         plan = self._train_plans.get(key)
         if plan is None:
