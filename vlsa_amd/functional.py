@@ -335,20 +335,53 @@ class SlideTrainPlan:
             self.off[name] = o
             o += n
         self.rec_floats = o
-        # ... and of the per-call gradient block: dQ | dW | db | dT | dls | drows | dE
+        # ... and of the per-call gradient block: dQ | dW | db | dT | dls | drows | dE.  Its head (up to and including dls[0]) has
+        # the layout of the step's FLAT parameter tensor Q | W | b | T | logit_scale (``step_params``): a bag hands ONE gradient
+        # tensor to autograd instead of five, and the five parameter gradients are split off once per step.
         o, self.goff = 0, {}
         for name, n in (("dQ", self.nq * D), ("dW", 0 if identity_head else D * D), ("db", 0 if identity_head else D), ("dT", K * D), ("dls", 4),
                         ("drows", P * D), ("dE", P * D)):
             self.goff[name] = o
             o += n
         self.grad_floats = o
+        self.flat_floats = self.goff["dls"] + 1
+        self._flat, self._flat_src, self._zero_b = None, None, None
 
-    def prepared_for(self, Q: torch.Tensor, T: torch.Tensor) -> bool:
+    def step_params(self, Q, W, b, T, logit_scale) -> torch.Tensor:
+        """Q | W | b | T | logit_scale as ONE fp32 tensor (a ``torch.cat``: differentiable), shared -- with its graph -- by every bag
+        that sees the same tensor objects at the same in-place versions; a backward pass through it frees the graph, the next
+        call rebuilds.  (W None: identity adapter, no W / b part; b None: a zero part.)"""
+        vers = (torch.is_grad_enabled(), Q._version, -1 if W is None else W._version, -1 if b is None else b._version, T._version,
+                logit_scale._version)
+        src = self._flat_src
+        if (self._flat is not None and src[0] is Q and src[1] is W and src[2] is b and src[3] is T and src[4] is logit_scale
+                and src[5] == vers):
+            return self._flat
+        parts = [Q.reshape(-1)]
+        if W is not None:
+            if b is None:
+                if self._zero_b is None:
+                    self._zero_b = torch.zeros(self.D, dtype=torch.float32, device=W.device)
+                b_part = self._zero_b
+            else:
+                b_part = b
+            parts += [W.reshape(-1), b_part]
+        parts += [T.reshape(-1), logit_scale.reshape(1)]
+        flat = torch.cat(parts)
+        if flat.requires_grad and flat.grad_fn is not None:
+            flat.register_hook(self._drop_flat)
+        self._flat, self._flat_src = flat, (Q, W, b, T, logit_scale, vers)
+        return flat
+
+    def _drop_flat(self, *_):
+        self._flat = None
+
+    def prepared_for(self, flat: torch.Tensor) -> bool:
         src = self._src
-        return src is not None and src[0] is Q and src[1] is T and src[2] == Q._version and src[3] == T._version
+        return src is not None and src[0] is flat and src[1] == flat._version
 
-    def mark_prepared(self, Q, T):
-        self._src = (Q, T, Q._version, T._version)      # the tensors are kept alive: their identity is the key
+    def mark_prepared(self, flat):
+        self._src = (flat, flat._version)               # the tensor is kept alive: its identity is the key
         self.gen += 1
         self._That_out = None
 
@@ -359,8 +392,17 @@ class SlideTrainPlan:
 
 
 class _SlideTrainFn(torch.autograd.Function):
+    """One bag: X2 [N, 512] and the step's flat parameter tensor (``SlideTrainPlan.step_params``) -> logits, unit features."""
+
     @staticmethod
-    def forward(ctx, X2, Q, W, b, T, logit_scale, plan):
+    def _params(plan, flat):
+        """C pointers of Q, W, b, T, logit_scale inside the flat tensor"""
+        g, fb = plan.goff, flat.data_ptr()
+        ident = plan.identity_head
+        return (fb, None if ident else fb + 4 * g["dW"], None if ident else fb + 4 * g["db"], fb + 4 * g["dT"], fb + 4 * g["dls"])
+
+    @staticmethod
+    def forward(ctx, X2, flat, plan):
         lib, s, c, off = plan.lib, _stream(), plan._c, plan.off
         N = X2.shape[0]
         dev = X2.device
@@ -368,36 +410,36 @@ class _SlideTrainFn(torch.autograd.Function):
         logits = torch.empty(1, plan.K, dtype=torch.float32, device=dev)
         vhat = torch.empty(1, plan.D, dtype=torch.float32, device=dev)
         base = rec.data_ptr()
-        fresh = not plan.prepared_for(Q, T)
+        fresh = not plan.prepared_for(flat)
         G = int(lib.vlsa_num_partials(N))
+        pQ, pW, pb, pT, pls = _SlideTrainFn._params(plan, flat)
         at = lambda name: base + 4 * off[name]  # noqa: E731
-        nat.check(lib.vlsa_vlfan_forward_bag(_p(X2), _dt(X2), N, X2.stride(0), plan.D, _p(Q) if fresh else None, plan.nq, int(plan.gated),
-                                             plan.scale, _p(T), plan.K, _p(logit_scale), nat.POOL_MEAN, None, _p(W), _p(b), nat.KERNEL_AUTO,
+        nat.check(lib.vlsa_vlfan_forward_bag(_p(X2), _dt(X2), N, X2.stride(0), plan.D, pQ if fresh else None, plan.nq, int(plan.gated),
+                                             plan.scale, pT, plan.K, pls, nat.POOL_MEAN, None, pW, pb, nat.KERNEL_AUTO,
                                              c["qprep"], c["That"], c["tnorm"], c["pm"], c["pl"], c["pacc"], G, at("m2"), at("l"),
                                              at("out"), None, None, c["head_ws"], at("pooled"), at("v"), vhat.data_ptr(), at("vnorm"),
                                              logits.data_ptr(), None, s), "vlsa_vlfan_forward_bag")
         if fresh:
-            plan.mark_prepared(Q, T)
-        ctx.plan, ctx.gen, ctx.has = plan, plan.gen, (W is not None, b is not None, tuple(logit_scale.shape))
-        ctx.save_for_backward(X2, Q, T, rec, logit_scale, logits, vhat, *([W] if W is not None else []))
+            plan.mark_prepared(flat)
+        ctx.plan, ctx.gen = plan, plan.gen
+        ctx.save_for_backward(X2, flat, rec, logits, vhat)
         return logits, vhat, plan.unit_text()
 
     @staticmethod
     def backward(ctx, dlogits, g_vhat, g_That):
         plan = ctx.plan
         lib, s, c, off, goff = plan.lib, _stream(), plan._c, plan.off, plan.goff
-        X2, Q, T, rec, ls, logits, vhat = ctx.saved_tensors[:7]
-        has_w, has_b, ls_shape = ctx.has
-        W = ctx.saved_tensors[7] if has_w else None
+        X2, flat, rec, logits, vhat = ctx.saved_tensors
         N, dev, K, D, P, nq = X2.shape[0], X2.device, plan.K, plan.D, plan.P, plan.nq
+        pQ, pW, pb, pT, pls = _SlideTrainFn._params(plan, flat)
         qprep, That, tnorm = c["qprep"], c["That"], c["tnorm"]
         keep = None
         if plan.gen != ctx.gen:
             # the plan's prepared block has moved on (another forward with new queries / text features ran before this backward):
-            # rebuild this bag's block from the saved tensors
+            # rebuild this bag's block from the saved flat tensor
             keep = (torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=dev), torch.empty(K, D, dtype=torch.float32, device=dev),
                     torch.empty(K, dtype=torch.float32, device=dev))
-            nat.check(lib.vlsa_prepare_queries_and_text(_p(Q), nq, D, int(plan.gated), plan.scale, _p(keep[0]), _p(T), K, _p(keep[1]),
+            nat.check(lib.vlsa_prepare_queries_and_text(pQ, nq, D, int(plan.gated), plan.scale, _p(keep[0]), pT, K, _p(keep[1]),
                                                         _p(keep[2]), s), "vlsa_prepare_queries_and_text")
             qprep, That, tnorm = (t.data_ptr() for t in keep)
         gb = torch.empty(plan.grad_floats, dtype=torch.float32, device=dev)
@@ -408,13 +450,12 @@ class _SlideTrainFn(torch.autograd.Function):
         gv = None if g_vhat is None else _f32c(g_vhat)
         gt = None if g_That is None else _f32c(g_That)
         G = int(lib.vlsa_num_partials(N))
+        has_w = pW is not None
         nat.check(lib.vlsa_vlfan_backward_bag(_p(X2), _dt(X2), N, X2.stride(0), D, qprep, nq, int(plan.gated), plan.scale, _p(dl), _p(gv), _p(gt),
-                                              at("pooled"), vhat.data_ptr(), at("vnorm"), That, tnorm, logits.data_ptr(), _p(W), _p(ls), at("out"),
+                                              at("pooled"), vhat.data_ptr(), at("vnorm"), That, tnorm, logits.data_ptr(), pW, pls, at("out"),
                                               at("m2"), at("l"), K, c["hws"], gat("drows"), gat("dW") if has_w else None,
                                               gat("db") if has_w else None, gat("dT"), gat("dls"), c["bwd_prep"], c["pm"], c["pl"], c["pacc"], G,
                                               gat("dE"), gat("dQ"), s), "vlsa_vlfan_backward_bag")
-        def v(name, n, *sh):
-            return gb[goff[name]:goff[name] + n].view(*sh)
         dX = None
         if ctx.needs_input_grad[0]:      # the bag is the output of a trainable Feat_Projecter (fp32 [N, 512]): dL/dX of the aggregation
             dX = torch.empty(N, D, dtype=torch.float32, device=dev)
@@ -422,8 +463,7 @@ class _SlideTrainFn(torch.autograd.Function):
             delta = torch.empty(1, nat.P_STRIDE, dtype=torch.float32, device=dev)
             nat.check(lib.vlsa_vlfan_backward_dx(p_desc, p_dx, 1, D, qprep, P, plan.scale, p_ts, n_tiles, gat("drows"), at("out"), at("m2"),
                                                  at("l"), _p(delta), s), "vlsa_vlfan_backward_dx")
-        return (dX, v("dQ", nq * D, nq, D), v("dW", D * D, D, D) if has_w else None, v("db", D, D) if (has_w and has_b) else None,
-                v("dT", K * D, K, D), v("dls", 1, ls_shape), None)
+        return dX, gb[:plan.flat_floats], None
 
 
 def slide_train(X2: torch.Tensor, Q: torch.Tensor, W, b, T: torch.Tensor, logit_scale: torch.Tensor, plan: SlideTrainPlan):
@@ -433,7 +473,7 @@ def slide_train(X2: torch.Tensor, Q: torch.Tensor, W, b, T: torch.Tensor, logit_
     grad (the output of a trainable Feat_Projecter: vlsa_vlfan_backward_dx).  All tensors fp32 contiguous on
     the bag's device (Q [nq, 512], T [K, 512], logit_scale 0-dim); see ``SlideTrainPlan``."""
     _need_gpu(X2, Q, T, logit_scale)
-    return _SlideTrainFn.apply(X2, Q, W, b, T, logit_scale, plan)
+    return _SlideTrainFn.apply(X2, plan.step_params(Q, W, b, T, logit_scale), plan)
 
 
 class VlfanInferencePlan:
