@@ -1051,7 +1051,6 @@ class _PinnedRing:
 
 
 _TABLE_RING = {}     # per host thread (autograd runs backward functions on its own thread)
-_ONE_BAG_TABLES = {} # (thread, device, stream) -> 64-byte device buffer of the single-bag tables
 
 
 def _row_tables(bags, tile_rows: int, extra=None):
@@ -1066,12 +1065,7 @@ def _row_tables(bags, tile_rows: int, extra=None):
         # instead of numpy bookkeeping + a pinned staging copy + an event per call
         x, lib = bags[0], nat.load()
         s = _stream()
-        key = (threading.get_ident(), x.device, s.value or 0)
-        buf = _ONE_BAG_TABLES.get(key)
-        if buf is None:
-            if len(_ONE_BAG_TABLES) > 64:
-                _ONE_BAG_TABLES.clear()
-            buf = _ONE_BAG_TABLES[key] = torch.zeros(8, dtype=torch.int64, device=x.device)   # stream-ordered reuse
+        buf = torch.empty(8, dtype=torch.int64, device=x.device)      # 64 bytes per call: no state shared between calls
         ex = extra[0] if extra is not None else None
         n_tiles = lib.vlsa_fill_one_bag_tables(_p(buf), _p(x), x.shape[0], x.stride(0), _p(ex), 0 if ex is None else ex.stride(0), int(tile_rows), s)
         if n_tiles < 0:
