@@ -6,7 +6,6 @@ autograd only scales the saved gradient by the incoming one.
 """
 from __future__ import annotations
 
-import ctypes
 
 import torch
 import torch.nn as nn

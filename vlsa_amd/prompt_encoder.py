@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import ctypes
 from collections import OrderedDict
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -13,7 +13,7 @@ is enqueued after that.  ``finish()`` drains the pipeline.
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 

@@ -24,7 +24,6 @@ import torch.nn.functional as F
 from . import deepmil as mil_encoders
 from . import functional as VF
 from .deepmil import FeatMIL, VLFAN, logit_pooling
-from .prompt_adapter import PromptAdapter
 
 
 _GET_TRAINING, _GET_VERSION = operator.attrgetter("training"), operator.attrgetter("_version")    # C-level loops in _provider_key
