@@ -336,9 +336,14 @@ int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const 
  * bags (vlsa_gated_scores_batch; weights packed by vlsa_prepare_gated_weights) and ONE for the softmax-weighted row sums
  * (vlsa_scored_pool_partial_batch -> G partials per bag in the P = 1 partial layout, folded by vlsa_vlfan_merge_batch_strided).
  * bag_desc: device table of vlsa_bag_desc; B <= 64; D == 512; bf16 or fp32 bags (one dtype per batch).
- *   tile_start [B + 1] int32 (device): first row tile of every bag for tiles of rows_per_tile rows (multiple of 16, <= 256, <= 128
- *   for gated fp32 bags); n_tiles = tile_start[B].   a: all bags' scores, bag b at a + a_off[b] (int64, device), a_floats long.
+ *   tile_start [B + 1] int32 (device): first row tile of every bag for tiles of rows_per_tile rows (multiple of 16, at most the
+ *   max_rows of vlsa_gated_scores_tiling); n_tiles = tile_start[B].   a: all bags' scores, bag b at a + a_off[b] (int64, device),
+ *   a_floats long.
+ * vlsa_gated_scores_tiling: the tile geometry of the score kernel for a (bag dtype, module) pair -- max_rows = rows of its largest
+ *   tile, round_tiles = row tiles that fill the 256 CUs once; a batch smaller than one round is best served by the smallest
+ *   rows_per_tile that still fits round_tiles.
  */
+int vlsa_gated_scores_tiling(int x_dtype, int gated, int* max_rows, int* round_tiles);
 int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
                             int n_tiles, int rows_per_tile, float* a, const int64_t* a_off, int64_t a_floats, void* stream);
 int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const float* scores, const int64_t* a_off,

@@ -19,6 +19,10 @@
 //     (16x16x32 bf16) per step and wave, hi and lo terms interleaved so that back-to-back MFMAs never share an accumulator.
 //   * epilogue: accumulators start at the bias; tanh * sigmoid as (1 - u) / ((1 + u)(1 + v)) with two v_exp_f32 and one
 //     v_rcp_f32 per value; dot with w2 over the wave's 16 hidden units by four DPP row rotations; cross-wave sum through LDS.
+//   * the ungated module (half the accumulators) runs as FOUR-wave workgroups of 128 rows x 128 hidden units, wave w owning two
+//     groups of 16 hidden units (template HG = 2): an A fragment feeds four MFMAs instead of two, 152 registers let three such
+//     workgroups share a CU out of step with each other (gs_tiling() below has the measurements and what the gated module did
+//     with the same shapes).
 //   * bags that fit one round of the 256 CUs use smaller tiles (rows per tile = smallest multiple of 16 that still fits one
 //     round: a 2 798-patch bag runs on 176 CUs instead of 22); larger bags use the static 256-row variant.
 // Roofline: MFMA-bound: 2 terms x 2 branches x 2 x 512 x 256 = 1.05 MFLOP per patch -> 52 GFLOP per 50k bag = 21 us at
@@ -130,7 +134,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 // X_lo W_hi (the lo x lo term is 2^-16 relative and dropped): 1.5x the MFMA work of a bf16 bag, no [N, 256] activations in
 // memory, no library GEMM.  (XF32 always takes the two-deep weight ring: 256-register budget.)
 // RT = row tiles of 16 patches per workgroup (16; 8 for gated fp32 bags: 64 instead of 128 accumulator registers leave room for
-// the fp32 staging registers -- with 16 the kernel spilled).
+// the fp32 staging registers -- with 16 the kernel spilled).  HG = groups of 16 hidden units per wave: the workgroup has 8 / HG
+// waves (HG = 2, RT = 8: the four-wave shape of the ungated module).
 // Several bags per launch (the DeepMIL encoder over a batch of slides, runner/vlsa_handler.py:315-345): bags != null, row tile
 // t of the launch belongs to the bag b with tile_start[b] <= t < tile_start[b + 1]; its scores go to a_out + a_off[b].
 struct GsBag {
@@ -149,12 +154,14 @@ struct GsBatch {
     unsigned int row_base;      // first row of this launch inside the bag's score array (a bag may be covered by two launches)
 };
 
-template <bool GATED, bool FULL, bool XF32, int RT = 16>
-__global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
+template <bool GATED, bool FULL, bool XF32, int RT = 16, int HG = 1>
+__global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
                                                        const unsigned char* __restrict__ prep, float* __restrict__ a_out,
                                                        int rows_per_tile, const GsBatch bt) {
     using namespace gs;
-    constexpr bool DEEP = FULL && !XF32;   // four-deep weight ring
+    constexpr bool DEEP = FULL && !XF32 && HG == 1;   // four-deep weight ring
+    constexpr int AQ = 4 / HG;            // row tiles per group of A fragments (MFMAs on one accumulator stay 4 NB apart)
+    constexpr int NW = 8 / HG;            // waves per workgroup; a wave owns HG groups of 16 hidden units (of both branches)
     constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
     constexpr int NB = GATED ? 2 : 1;     // branches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -185,8 +192,10 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     // plain (compiler-tracked) loads only: weight fragments one step ahead (double-buffered registers; a 4-deep ring measured
     // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
     // into the shared LDS tile of its step
-    const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + w) * kSteps * NF * 1024 + lane * 16;
-    const int xr = tid >> 1, xc = (tid & 1) * 2;                  // this thread's row and first 16-B chunk of the X chunk
+    const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + HG * w) * kSteps * NF * 1024 + lane * 16;
+    constexpr int XCH = (RT / NW) > 2 ? (RT / NW) : 2;            // 16-B chunks of a step's X chunk per thread (a row has 4)
+    static_assert(!XF32 || XCH == 2, "fp32 bags: two chunks per thread");
+    const int xr = tid / (4 / XCH), xc = (tid % (4 / XCH)) * XCH;  // this thread's row and first 16-B chunk of the X chunk
     const bool xok = xr < nrows;
     const __bf16* xsrc = XF32 ? nullptr : static_cast<const __bf16*>(Xv) + (row0 + xr) * ldx + xc * 8;          // + 32 ks
     const float* xsrc32 = XF32 ? static_cast<const float*>(Xv) + (row0 + xr) * ldx + xc * 8 : nullptr;
@@ -194,10 +203,10 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), and with this f the 16 lanes of every
     // group hit 16 different 4-bank sets
     const int fx = (0 - (xr >> 2)) & 3;
-    const int x_dst0 = xr * 64 + ((xc ^ fx) << 4), x_dst1 = xr * 64 + (((xc + 1) ^ fx) << 4);
+    const int x_dst0 = xr * 64 + ((xc ^ fx) << 4), x_dst1 = xr * 64 + (((xc + 1) ^ fx) << 4);   // chunk j: xr * 64 + (((xc + j) ^ fx) << 4)
     const int a_off = i16 * 64 + ((g ^ ((0 - (i16 >> 2)) & 3)) << 4);    // A fragment of row tile rt: + rt * 1024
     // the thread's 16 values of a step: two 16-byte bf16 chunks c0, c1 (bf16 bags), or four float4 (fp32 bags)
-    struct XPair { bf16x8 lo, hi; f32x4 f[XF32 ? 4 : 1]; };
+    struct XPair { bf16x8 c[XF32 ? 1 : XCH]; f32x4 f[XF32 ? 4 : 1]; };
     auto load_x = [&](int ks) -> XPair {
         XPair r = {};
         if (xok) {
@@ -205,43 +214,50 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r.f[q] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4 * q);
             } else {
-                r.lo = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks);
-                r.hi = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8);
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8 * j);
             }
         }
         return r;
     };
-    auto load_b = [&](int ks, bf16x8 (&dst)[NF]) {
+    auto load_b = [&](int ks, bf16x8 (&dst)[HG * NF]) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)(ks * NF + f) * 1024);
+        for (int hg = 0; hg < HG; ++hg)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                dst[hg * NF + f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((hg * kSteps + ks) * NF + f) * 1024);
     };
 
     // accumulators start at the (pre-scaled) bias of the lane's hidden unit
-    const int h = 128 * half + 16 * w + i16;
-    const float bav = reinterpret_cast<const float*>(prep + L.ba)[h];
-    const float bgv = GATED ? reinterpret_cast<const float*>(prep + L.bg)[h] : 0.f;
-    const float w2v = reinterpret_cast<const float*>(prep + L.w2)[h];
-    f32x4 acc[RT][NB];
+    const int h0 = 128 * half + 16 * HG * w + i16;   // hidden unit of group hg: h0 + 16 hg
+    float w2v[HG];
+    f32x4 acc[RT][HG][NB];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int hg = 0; hg < HG; ++hg) {
+        const float bav = reinterpret_cast<const float*>(prep + L.ba)[h0 + 16 * hg];
+        const float bgv = GATED ? reinterpret_cast<const float*>(prep + L.bg)[h0 + 16 * hg] : 0.f;
+        w2v[hg] = reinterpret_cast<const float*>(prep + L.w2)[h0 + 16 * hg];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float bb = b == 0 ? bav : bgv;
-            acc[rt][b] = f32x4{bb, bb, bb, bb};
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float bb = b == 0 ? bav : bgv;
+                acc[rt][hg][b] = f32x4{bb, bb, bb, bb};
+            }
+    }
 
-    bf16x8 B0[NF], B1[NF], B2[NF], B3[NF];   // FULL: 4-deep ring, weights three steps ahead; else B0 / B1, one step ahead
+    bf16x8 B0[HG * NF], B1[HG * NF], B2[DEEP ? NF : 1], B3[DEEP ? NF : 1];   // FULL: 4-deep ring, weights three steps ahead; else B0 / B1, one step ahead
     XPair X0, X1;
     X0 = load_x(0);
     load_b(0, B0);
     X1 = load_x(1);
-    if (DEEP) {
+    if constexpr (DEEP) {
         load_b(1, B1);
         load_b(2, B2);
     }
 
     // one K step: publish this step's X share, barrier, start the loads of later steps, 16 A reads, 64 (32) MFMAs
-    auto step = [&](int s, bf16x8 (&cur)[NF], bf16x8 (&nxt)[NF], XPair& xcur) {
+    auto step = [&](int s, bf16x8 (&cur)[HG * NF], bf16x8 (&nxt)[HG * NF], XPair& xcur) {
         unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * kXBuf;     // fp32 bags: hi image, lo image behind it
         if constexpr (XF32) {
             bf16x8 h0, h1, l0, l1;
@@ -257,47 +273,53 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
             *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst0) = l0;
             *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst1) = l1;
         } else {
-            *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = xcur.lo;
-            *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = xcur.hi;
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8_mag*>(xb + xr * 64 + (((xc + j) ^ fx) << 4)) = xcur.c[j];
         }
         __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
         if (s + (DEEP ? 3 : 1) < kSteps) load_b(s + (DEEP ? 3 : 1), nxt);
         if (s + 2 < kSteps) xcur = load_x(s + 2);
 #pragma unroll
-        for (int q = 0; q < RT / 4; ++q) {
-            if (4 * q >= nrt) break;         // uniform
-            bf16x8 A[4], AL[XF32 ? 4 : 1];
+        for (int q = 0; q < RT / AQ; ++q) {
+            if (AQ * q >= nrt) break;         // uniform
+            bf16x8 A[AQ], AL[XF32 ? AQ : 1];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (4 * q + r4) * 1024 + a_off);
-                if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + kXBuf + (4 * q + r4) * 1024 + a_off);
+            for (int r4 = 0; r4 < AQ; ++r4) {
+                A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (AQ * q + r4) * 1024 + a_off);
+                if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + kXBuf + (AQ * q + r4) * 1024 + a_off);
             }
-            if (4 * q + 4 <= nrt) {
+            if (AQ * q + AQ <= nrt) {
                 // hi terms of the 4 NB accumulators of this group, then the lo terms: MFMAs on one accumulator are 4 NB apart
 #pragma unroll
                 for (int term = 0; term < 2; ++term)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
+                    for (int hg = 0; hg < HG; ++hg)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + term], acc[4 * q + r4][b], 0, 0, 0);
+                        for (int r4 = 0; r4 < AQ; ++r4)
+#pragma unroll
+                            for (int b = 0; b < NB; ++b)
+                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b + term], acc[AQ * q + r4][hg][b], 0, 0, 0);
                 if constexpr (XF32) {
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4)
+                    for (int hg = 0; hg < HG; ++hg)
 #pragma unroll
-                        for (int b = 0; b < NB; ++b)
-                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
+                        for (int r4 = 0; r4 < AQ; ++r4)
+#pragma unroll
+                            for (int b = 0; b < NB; ++b)
+                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
                 }
             } else {                          // the last, partly filled group of row tiles
 #pragma unroll
-                for (int r4 = 0; r4 < 3; ++r4)
-                    if (4 * q + r4 < nrt) {
+                for (int r4 = 0; r4 < AQ - 1; ++r4)
+                    if (AQ * q + r4 < nrt) {
+#pragma unroll
+                        for (int hg = 0; hg < HG; ++hg)
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
-                            acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[2 * b + 1], acc[4 * q + r4][b], 0, 0, 0);
+                            acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                            acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b + 1], acc[AQ * q + r4][hg][b], 0, 0, 0);
                             if constexpr (XF32)
-                                acc[4 * q + r4][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[2 * b], acc[4 * q + r4][b], 0, 0, 0);
+                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
                         }
                     }
             }
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
     };
 #pragma unroll 1
     for (int s = 0; s < kSteps; s += 4) {
-        if (DEEP) {
+        if constexpr (DEEP) {
             step(s, B0, B3, X0);
             step(s + 1, B1, B0, X1);
             step(s + 2, B2, B1, X0);
@@ -326,21 +348,26 @@ __global__ __launch_bounds__(512) void k_gated_scores(const void* __restrict__ X
         if (rt < nrt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float e = GATED ? gate_act(acc[rt][0][r], acc[rt][NB - 1][r]) : tanh_act(acc[rt][0][r]);
-            if (GATED && bt.drop_thr != 0u) {      // uniform: training-mode dropout on both branches
-                const unsigned int row = rid0 + 16 * rt + 4 * g + r;
-                const bool ka = dropout_bits(bt.drop_seed, row, (unsigned int)h) >= bt.drop_thr;
-                const bool kg = dropout_bits(bt.drop_seed, row, (unsigned int)h + 256u) >= bt.drop_thr;
-                e = (ka && kg) ? e * bt.drop_scale * bt.drop_scale : 0.f;
+            float ew = 0.f;
+#pragma unroll
+            for (int hg = 0; hg < HG; ++hg) {
+                float e = GATED ? gate_act(acc[rt][hg][0][r], acc[rt][hg][NB - 1][r]) : tanh_act(acc[rt][hg][0][r]);
+                if (GATED && bt.drop_thr != 0u) {      // uniform: training-mode dropout on both branches
+                    const unsigned int row = rid0 + 16 * rt + 4 * g + r, h = (unsigned int)(h0 + 16 * hg);
+                    const bool ka = dropout_bits(bt.drop_seed, row, h) >= bt.drop_thr;
+                    const bool kg = dropout_bits(bt.drop_seed, row, h + 256u) >= bt.drop_thr;
+                    e = (ka && kg) ? e * bt.drop_scale * bt.drop_scale : 0.f;
+                }
+                ew += e * w2v[hg];
             }
-            const float v = row16_sum(e * w2v);
+            const float v = row16_sum(ew);
             if (i16 == 0) scr[w * kRows + 16 * rt + 4 * g + r] = v;
         }
     __syncthreads();
     if (tid < kRows && tid < nrows) {
         float sum = half == 0 ? reinterpret_cast<const float*>(prep + L.c)[0] : 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) sum += scr[ww * kRows + tid];
+        for (int ww = 0; ww < NW; ++ww) sum += scr[ww * kRows + tid];
         atomicAdd(a_out + row0 + tid, sum);     // two addends per element on a zeroed array: order-independent
     }
 }
@@ -364,6 +391,31 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
 static bool gs_round64() {
     static const bool on = [] { const char* e = getenv("VLSA_GS_R64"); return e && atoi(e) == 1; }();   // (A/B hook; off: +-2 us either way, tools/gs_rows.py)
     return on;
+}
+
+// Workgroup shape per (bag dtype, module): rows of the largest tile, row tiles in one round of the 256 CUs (x 2 hidden halves =
+// workgroups), and whether the four-wave kernel serves it.
+//   * gated, bf16:   256 rows x 128 hidden units of both branches, 8 waves, one workgroup per CU;
+//   * gated, fp32:   128 rows (64 instead of 128 accumulator registers leave room for the fp32 staging);
+//   * ungated, bf16: 128 rows x 128 hidden units, FOUR waves of 32 hidden units each: every A fragment read from LDS feeds four
+//     MFMAs instead of two, 152 registers -> three independent workgroups per CU whose prologues / epilogues overlap the others'
+//     K loops: 400k patches 251 -> 211 us, 65 536: 44.9 -> 41.2, 50k: 43.2 -> 37.8 (same box, tools/kbench_gated_ab.py).  The same
+//     shape for the gated module needs 256 registers (473 vs 430 us at 400k), 64-row tiles 182 (447 vs 418), a 256 x 128 tile at one
+//     wave per SIMD and 512 registers 584: the gated module keeps its 8-wave shape.
+struct GsTiling { int max_rows, round_tiles; bool four_waves; };
+static GsTiling gs_tiling(bool f32, bool gated) {
+    static const bool four_off = [] { const char* e = getenv("VLSA_GS_HG2"); return e && atoi(e) == 0; }();   // (A/B hook)
+    if (!f32 && !gated && !four_off) return {128, 256, true};
+    return {(f32 && gated) ? 128 : gs::kRows, 128, false};
+}
+
+// vlsa_gated_scores_batch's caller sizes its tile table with this: rows of the largest tile and row tiles per round.
+extern "C" int vlsa_gated_scores_tiling(int x_dtype, int gated, int* max_rows, int* round_tiles) {
+    if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !max_rows || !round_tiles) return VLSA_EINVAL;
+    const GsTiling tl = gs_tiling(x_dtype == VLSA_DT_F32, gated != 0);
+    *max_rows = tl.max_rows;
+    *round_tiles = tl.round_tiles;
+    return VLSA_OK;
 }
 
 static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
@@ -390,7 +442,8 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     // (every CU busy, every tile full), then the remainder as one more single-round launch with its own, smaller tile height --
     // instead of a last round in which 256-row tiles occupy a fraction of the CUs for a full tile time (50k patches: 1.53
     // rounds were paid as 2).
-    const int max_rows = (f32 && gated) ? 128 : gs::kRows;     // gated fp32: 8 row tiles per workgroup (register budget)
+    const GsTiling tl = gs_tiling(f32, gated != 0);
+    const int max_rows = tl.max_rows, round_tiles = tl.round_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
@@ -402,10 +455,12 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         dropb.drop_seed = seed;
         dropb.drop_scale = 1.f / (1.f - drop_p);
     }
-    const int64_t round_rows = 128 * (int64_t)max_rows;
+    const int64_t round_rows = round_tiles * (int64_t)max_rows;
     static const bool split = [] { const char* e = getenv("VLSA_GS_SPLIT"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     int64_t seg_rows[2] = {N, 0};
-    if (split && N > round_rows && N % round_rows != 0) {
+    // (four-wave workgroups: three fit a CU and run out of step with each other, a partly filled last round costs little and a
+    // second launch more -- 50k patches: 37.8 us as one launch of 128-row tiles, 41.5 split; tools/gs_rows_sweep.py)
+    if (split && !tl.four_waves && N > round_rows && N % round_rows != 0) {
         seg_rows[0] = N / round_rows * round_rows;
         seg_rows[1] = N - seg_rows[0];
     }
@@ -414,7 +469,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         const int64_t n = seg_rows[sgi];
         int rows_per_tile = max_rows;
         if (n <= round_rows) {
-            rows_per_tile = (int)(((n + 127) / 128 + 15) / 16 * 16);
+            rows_per_tile = (int)(((n + round_tiles - 1) / round_tiles + 15) / 16 * 16);
             // (optional: whole groups of four 16-row tiles above 64 rows -- helps 30k / 60k patches, hurts 10k / 20k / 50k)
             if (rows_per_tile > 64 && gs_round64()) rows_per_tile = (rows_per_tile + 63) / 64 * 64;
             if (rows_per_tile > max_rows) rows_per_tile = max_rows;
@@ -429,7 +484,10 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         float* as = a + off;
         dropb.row_base = (unsigned int)off;
 #define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
-        if (f32) {
+#define VLSA_GS2(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
+        if (tl.four_waves) {
+            if (full) VLSA_GS2(true); else VLSA_GS2(false);
+        } else if (f32) {
             if (gated) {
                 if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
                 else hipLaunchKernelGGL((k_gated_scores<true, false, true, 8>), dim3(tiles), dim3(512), gs::kLds32, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
@@ -439,6 +497,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
             else       { if (full) VLSA_GS(false, true, false); else VLSA_GS(false, false, false); }
         }
 #undef VLSA_GS
+#undef VLSA_GS2
         off += n;
     }
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
@@ -466,7 +525,8 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     if (!bag_desc || !prep || !a || !tile_start || !a_off || B < 1 || B > 64 || n_tiles < 1 || a_floats < 1) return VLSA_EINVAL;
     if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
     const bool f32 = x_dtype == VLSA_DT_F32;
-    const int max_rows = (f32 && gated) ? 128 : gs::kRows;
+    const GsTiling tl = gs_tiling(f32, gated != 0);
+    const int max_rows = tl.max_rows;
     if (rows_per_tile < 16 || rows_per_tile > max_rows || (rows_per_tile % 16)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
@@ -486,7 +546,10 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
-    if (f32) {
+    if (tl.four_waves) {
+        if (full) hipLaunchKernelGGL((k_gated_scores<false, true, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+        else hipLaunchKernelGGL((k_gated_scores<false, false, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+    } else if (f32) {
         if (gated) { if (full) VLSA_GSB(true, true, true, 8); else VLSA_GSB(true, false, true, 8); }
         else       { if (full) VLSA_GSB(false, true, true, 16); else VLSA_GSB(false, false, true, 16); }
     } else {

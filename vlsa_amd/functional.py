@@ -908,6 +908,21 @@ def attn_scores(H: torch.Tensor, Hg: Optional[torch.Tensor], b1, bg, w2, b2) -> 
     return a
 
 
+_SCORE_TILING = {}
+
+
+def _score_tiling(f32: bool, gated: bool):
+    """(rows of the score kernel's largest tile, row tiles per round of the CUs) -- vlsa_gated_scores_tiling, asked once."""
+    key = (f32, gated)
+    t = _SCORE_TILING.get(key)
+    if t is None:
+        mr, rt = ctypes.c_int(0), ctypes.c_int(0)
+        nat.check(nat.load().vlsa_gated_scores_tiling(nat.DT_F32 if f32 else nat.DT_BF16, int(gated), ctypes.addressof(mr),
+                                                     ctypes.addressof(rt)), "vlsa_gated_scores_tiling")
+        t = _SCORE_TILING[key] = (mr.value, rt.value)
+    return t
+
+
 class FusedAttnScores:
     """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 or fp32 bag in ONE MFMA kernel
     (vlsa_gated_scores; model/layers.py:85-153): the [N, 256] hidden activations never reach memory.  Holds the weights
@@ -960,11 +975,11 @@ class FusedAttnScores:
         prep = self._packed(dev, Wa, ba, Wg, bg, w2, c)
         rows = [x.shape[0] for x in bags]
         f32 = bags[0].dtype == torch.float32
-        max_rows = 128 if (f32 and gated) else 256
+        max_rows, round_tiles = _score_tiling(f32, bool(gated))
         rpt = max_rows
-        if sum((n + max_rows - 1) // max_rows for n in rows) < 128:      # less than one round of the 256 CUs: smaller tiles
+        if sum((n + max_rows - 1) // max_rows for n in rows) < round_tiles:      # less than one round of the 256 CUs: smaller tiles
             rpt = 16
-            while rpt < max_rows and sum((n + rpt - 1) // rpt for n in rows) > 128:
+            while rpt < max_rows and sum((n + rpt - 1) // rpt for n in rows) > round_tiles:
                 rpt += 16
         import numpy as np
         stage = getattr(self, "_stage", None)
