@@ -28,13 +28,20 @@
 // Roofline: MFMA-bound: 2 terms x 2 branches x 2 x 512 x 256 = 1.05 MFLOP per patch -> 52 GFLOP per 50k bag = 21 us at
 // 2.5 PFLOP/s dense bf16.  Measured 62 us per 50k bag (2 rounds of tiles for 1.53 rounds of work) and 389 us at N = 400k =
 // 1.08 PFLOP/s executed = 43 % of the dense peak (a register-only probe with this accumulator / operand pattern reaches
-// 2.0 PFLOP/s at 2 waves per SIMD, tools/probes/mfma_rate.hip).  What was measured on the way (tools/kbench_gated.py):
-// the loop is NOT load- or barrier-bound (dropping all loads: -12 %, dropping publish + barrier: 0 %, LDS-DMA ring vs
-// register ring vs deeper prefetch: equal); the activations were (~25 % of a tile with IEEE divisions and ds_bpermute
-// shuffles, now ~15 %): N x 512 transcendental pairs at quarter rate are ~12 us per 50k bag on their own.
+// 2.0 PFLOP/s at 2 waves per SIMD, tools/probes/mfma_rate.hip).  What was measured on the way (tools/kbench_gated.py, and the
+// timing-only ablations listed at gs_tiling() below): of the 435 us at 400k patches the X loads cost 92 (343 without them), the
+// weight loads 36, the activations 34 (they were ~25 % of a tile with IEEE divisions and ds_bpermute shuffles), the barrier 25,
+// the A-fragment reads 7; LDS-DMA ring vs register ring vs deeper prefetch: equal.
 #include <cstdlib>
 
 #include "vlsa_common.h"
+
+// Timing-only ablations of k_gated_scores (results are WRONG with any bit set; tools/gs_ablate.sh builds one library per bit):
+// 1 = no A-fragment reads from LDS, 2 = no weight loads, 4 = no X loads / publication, 8 = no per-step barrier,
+// 16 = no activations in the epilogue, 32 = no MFMAs, 64 = no X loads (stale registers are published), 128 = X loaded, not published, 256 = X rows from the first 4 MB of the bag only (cache hits).
+#ifndef VLSA_GS_ABL
+#define VLSA_GS_ABL 0
+#endif
 
 namespace vlsa {
 
@@ -120,6 +127,14 @@ __device__ __forceinline__ float tanh_act(float au) {
     const float u = fast_exp2(fminf(au, 43.f));
     return (1.f - u) * __builtin_amdgcn_rcpf(1.f + u);
 }
+__device__ __forceinline__ f32x4 gs_mfma(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {
+#if VLSA_GS_ABL & 32
+    asm volatile("" ::"v"(a), "v"(b));     // operands still have to arrive in registers
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 // sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane: four full-rate VALU adds
 __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
@@ -154,26 +169,33 @@ struct GsBatch {
     unsigned int row_base;      // first row of this launch inside the bag's score array (a bag may be covered by two launches)
 };
 
-template <bool GATED, bool FULL, bool XF32, int RT = 16, int HG = 1>
-__global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
+template <bool GATED, bool FULL, bool XF32, int RT = 16, int HG = 1, int NW = 8 / HG>
+__global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
                                                        const unsigned char* __restrict__ prep, float* __restrict__ a_out,
                                                        int rows_per_tile, const GsBatch bt) {
     using namespace gs;
     constexpr bool DEEP = FULL && !XF32 && HG == 1;   // four-deep weight ring
     constexpr int AQ = 4 / HG;            // row tiles per group of A fragments (MFMAs on one accumulator stay 4 NB apart)
-    constexpr int NW = 8 / HG;            // waves per workgroup; a wave owns HG groups of 16 hidden units (of both branches)
+    // NW waves per workgroup, a wave owns HG groups of 16 hidden units (of both branches): the workgroup covers 16 HG NW of the 256
+    // hidden units -- one half (two workgroups per row tile) or all of them (ONE: the X rows are then loaded by one CU only)
+    constexpr int HALVES = 16 / (HG * NW);
+    static_assert(HALVES == 1 || HALVES == 2, "workgroup covers half or all of the hidden units");
     constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
     constexpr int NB = GATED ? 2 : 1;     // branches
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int half = blockIdx.x & 1;
+    // The two hidden halves of a row tile read the same X rows: blocks b and b + 8 (same XCD under the round-robin dispatch, its L2
+    // then serves the second read -- with b, b + 1 they sat on two XCDs and X came out of HBM twice, which, not the MFMA pipe,
+    // was what bounded the kernel: without the X loads 400k patches took 115 instead of 208 us).  Speed only: any placement is correct.
+    const int bid = blockIdx.x, nfull = (int)(gridDim.x >> 4) << 4;
+    const int half = HALVES == 1 ? 0 : bid < nfull ? (bid >> 3) & 1 : bid & 1;
     // rows_per_tile (a multiple of 16, <= 256) is chosen by the host so that the launch is a whole number of full rounds of
     // the 256 CUs: a 50k-patch bag runs as 2 x 241 tiles of 208 rows instead of 2 x 196 tiles of 256 (1.5 rounds rounded up)
     // FULL: 256-row tiles, everything static (large bags); otherwise the row-tile count is a run-time, wave-uniform value
     const int nrt = FULL ? RT : (rows_per_tile >> 4);
-    int tile = blockIdx.x >> 1;
+    int tile = HALVES == 1 ? bid : bid < nfull ? ((bid >> 4) << 3) + (bid & 7) : bid >> 1;
     if (bt.bags != nullptr) {   // one vector load of the (<= 65-entry) tile table + a ballot instead of a dependent scalar search
         const int ts = lane < bt.B ? bt.tile_start[lane] : 0x7fffffff;
         const int b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ts <= tile)) - 1;
@@ -193,11 +215,17 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
     // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
     // into the shared LDS tile of its step
     const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + HG * w) * kSteps * NF * 1024 + lane * 16;
-    constexpr int XCH = (RT / NW) > 2 ? (RT / NW) : 2;            // 16-B chunks of a step's X chunk per thread (a row has 4)
+    constexpr int XCH = XF32 ? 2 : (RT / NW) > 1 ? (RT / NW) : 1;  // 16-B chunks of a step's X chunk per thread (a row has 4)
     static_assert(!XF32 || XCH == 2, "fp32 bags: two chunks per thread");
-    const int xr = tid / (4 / XCH), xc = (tid % (4 / XCH)) * XCH;  // this thread's row and first 16-B chunk of the X chunk
+    // QUADX (the ungated module's bf16 bags): four lanes share the 64 contiguous bytes of a row (chunk tid & 3), the thread's chunk j
+    // sits XRS rows further down -- 16 rows x 64 B per load instruction instead of 32 rows x 2 x 16 B (199 vs 207 us at 400k
+    // patches).  Otherwise (fp32 bags; the gated module, whose 256-register budget the second row pointer broke: 64 spilled
+    // registers, 671 vs 409 us): 4 / XCH lanes per row, XCH contiguous chunks each.
+    constexpr bool QUADX = !XF32 && !GATED;
+    constexpr int XRS = QUADX ? 16 * NW : 0, XCS = QUADX ? 0 : 1;      // row / chunk step between the thread's chunks
+    const int xr = QUADX ? tid >> 2 : tid / (4 / XCH), xc = QUADX ? tid & 3 : (tid % (4 / XCH)) * XCH;
     const bool xok = xr < nrows;
-    const __bf16* xsrc = XF32 ? nullptr : static_cast<const __bf16*>(Xv) + (row0 + xr) * ldx + xc * 8;          // + 32 ks
+    const __bf16* xsrc = XF32 ? nullptr : static_cast<const __bf16*>(Xv) + (((VLSA_GS_ABL & 256) ? (row0 & 4095) : row0) + xr) * ldx + xc * 8;          // + 32 ks
     const float* xsrc32 = XF32 ? static_cast<const float*>(Xv) + (row0 + xr) * ldx + xc * 8 : nullptr;
     // 16-B chunk c of row r is stored at position c ^ f(r), f(r) = (-(r >> 2)) & 3: ds_read_b128 is serviced in the lane groups
     // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS), and with this f the 16 lanes of every
@@ -209,11 +237,17 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
     struct XPair { bf16x8 c[XF32 ? 1 : XCH]; f32x4 f[XF32 ? 4 : 1]; };
     auto load_x = [&](int ks) -> XPair {
         XPair r = {};
-        if (xok) {
-            if constexpr (XF32) {
+        if constexpr (XF32) {
+            if (xok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r.f[q] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4 * q);
-            } else {
+            }
+        } else if (!(VLSA_GS_ABL & (4 | 64))) {
+            if constexpr (QUADX) {
+#pragma unroll
+                for (int j = 0; j < XCH; ++j)
+                    if (xr + j * XRS < nrows) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + (long long)j * XRS * ldx + 32 * ks);
+            } else if (xok) {
 #pragma unroll
                 for (int j = 0; j < XCH; ++j) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8 * j);
             }
@@ -221,6 +255,7 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
         return r;
     };
     auto load_b = [&](int ks, bf16x8 (&dst)[HG * NF]) {
+        if ((VLSA_GS_ABL & 2) && ks > 1) return;
 #pragma unroll
         for (int hg = 0; hg < HG; ++hg)
 #pragma unroll
@@ -256,6 +291,7 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
         load_b(2, B2);
     }
 
+    bf16x8 abl_a[AQ] = {};
     // one K step: publish this step's X share, barrier, start the loads of later steps, 16 A reads, 64 (32) MFMAs
     auto step = [&](int s, bf16x8 (&cur)[HG * NF], bf16x8 (&nxt)[HG * NF], XPair& xcur) {
         unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * kXBuf;     // fp32 bags: hi image, lo image behind it
@@ -272,11 +308,14 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
             *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = h1;
             *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst0) = l0;
             *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst1) = l1;
-        } else {
+        } else if (!(VLSA_GS_ABL & (4 | 128)) || s < 2) {
 #pragma unroll
-            for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8_mag*>(xb + xr * 64 + (((xc + j) ^ fx) << 4)) = xcur.c[j];
+            for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8_mag*>(xb + (xr + j * XRS) * 64 + (((xc + j * XCS) ^ fx) << 4)) = xcur.c[j];
+        } else if (VLSA_GS_ABL & 128) {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) asm volatile("" ::"v"(xcur.c[j]));
         }
-        __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
+        if (!(VLSA_GS_ABL & 8) || s < 2) __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
         if (s + (DEEP ? 3 : 1) < kSteps) load_b(s + (DEEP ? 3 : 1), nxt);
         if (s + 2 < kSteps) xcur = load_x(s + 2);
 #pragma unroll
@@ -285,7 +324,9 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
             bf16x8 A[AQ], AL[XF32 ? AQ : 1];
 #pragma unroll
             for (int r4 = 0; r4 < AQ; ++r4) {
+                if ((VLSA_GS_ABL & 1) && (s > 0 || q > 0)) { A[r4] = abl_a[r4]; continue; }
                 A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (AQ * q + r4) * 1024 + a_off);
+                if (VLSA_GS_ABL & 1) abl_a[r4] = A[r4];
                 if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + kXBuf + (AQ * q + r4) * 1024 + a_off);
             }
             if (AQ * q + AQ <= nrt) {
@@ -298,7 +339,7 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
                         for (int r4 = 0; r4 < AQ; ++r4)
 #pragma unroll
                             for (int b = 0; b < NB; ++b)
-                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b + term], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                                acc[AQ * q + r4][hg][b] = gs_mfma(A[r4], cur[hg * NF + 2 * b + term], acc[AQ * q + r4][hg][b], 0, 0, 0);
                 if constexpr (XF32) {
 #pragma unroll
                     for (int hg = 0; hg < HG; ++hg)
@@ -306,7 +347,7 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
                         for (int r4 = 0; r4 < AQ; ++r4)
 #pragma unroll
                             for (int b = 0; b < NB; ++b)
-                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                                acc[AQ * q + r4][hg][b] = gs_mfma(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
                 }
             } else {                          // the last, partly filled group of row tiles
 #pragma unroll
@@ -316,10 +357,10 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
                         for (int hg = 0; hg < HG; ++hg)
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
-                            acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
-                            acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r4], cur[hg * NF + 2 * b + 1], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                            acc[AQ * q + r4][hg][b] = gs_mfma(A[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                            acc[AQ * q + r4][hg][b] = gs_mfma(A[r4], cur[hg * NF + 2 * b + 1], acc[AQ * q + r4][hg][b], 0, 0, 0);
                             if constexpr (XF32)
-                                acc[AQ * q + r4][hg][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
+                                acc[AQ * q + r4][hg][b] = gs_mfma(AL[r4], cur[hg * NF + 2 * b], acc[AQ * q + r4][hg][b], 0, 0, 0);
                         }
                     }
             }
@@ -351,7 +392,8 @@ __global__ __launch_bounds__(512 / HG, 2) void k_gated_scores(const void* __rest
             float ew = 0.f;
 #pragma unroll
             for (int hg = 0; hg < HG; ++hg) {
-                float e = GATED ? gate_act(acc[rt][hg][0][r], acc[rt][hg][NB - 1][r]) : tanh_act(acc[rt][hg][0][r]);
+                float e = (VLSA_GS_ABL & 16) ? acc[rt][hg][0][r] + acc[rt][hg][NB - 1][r]
+                          : GATED ? gate_act(acc[rt][hg][0][r], acc[rt][hg][NB - 1][r]) : tanh_act(acc[rt][hg][0][r]);
                 if (GATED && bt.drop_thr != 0u) {      // uniform: training-mode dropout on both branches
                     const unsigned int row = rid0 + 16 * rt + 4 * g + r, h = (unsigned int)(h0 + 16 * hg);
                     const bool ka = dropout_bits(bt.drop_seed, row, h) >= bt.drop_thr;
@@ -393,26 +435,36 @@ static bool gs_round64() {
     return on;
 }
 
-// Workgroup shape per (bag dtype, module): rows of the largest tile, row tiles in one round of the 256 CUs (x 2 hidden halves =
-// workgroups), and whether the four-wave kernel serves it.
+// Workgroup shape per (bag dtype, module): rows of the largest tile, row tiles in one round of the 256 CUs, workgroups per row
+// tile (hidden halves) and whether a four-wave kernel serves it.
 //   * gated, bf16:   256 rows x 128 hidden units of both branches, 8 waves, one workgroup per CU;
 //   * gated, fp32:   128 rows (64 instead of 128 accumulator registers leave room for the fp32 staging);
-//   * ungated, bf16: 128 rows x 128 hidden units, FOUR waves of 32 hidden units each: every A fragment read from LDS feeds four
-//     MFMAs instead of two, 152 registers -> three independent workgroups per CU whose prologues / epilogues overlap the others'
-//     K loops: 400k patches 251 -> 211 us, 65 536: 44.9 -> 41.2, 50k: 43.2 -> 37.8 (same box, tools/kbench_gated_ab.py).  The same
-//     shape for the gated module needs 256 registers (473 vs 430 us at 400k), 64-row tiles 182 (447 vs 418), a 256 x 128 tile at one
-//     wave per SIMD and 512 registers 584: the gated module keeps its 8-wave shape.
-struct GsTiling { int max_rows, round_tiles; bool four_waves; };
-static GsTiling gs_tiling(bool f32, bool gated) {
-    static const bool four_off = [] { const char* e = getenv("VLSA_GS_HG2"); return e && atoi(e) == 0; }();   // (A/B hook)
-    if (!f32 && !gated && !four_off) return {128, 256, true};
-    return {(f32 && gated) ? 128 : gs::kRows, 128, false};
+//   * ungated, bf16: FOUR waves, 128 rows.  Shape 1: 128 hidden units per workgroup, 32 per wave (HG = 2): every A fragment read
+//     from LDS feeds four MFMAs instead of two, 150 registers -> three independent workgroups per CU whose prologues / epilogues
+//     overlap the others' K loops: 400k patches 251 -> 199 us, 20k: 21.4 -> 19.5 (same box, tools/kbench_gated_ab.py).  Shape 2: all
+//     256 hidden units, 64 per wave (HG = 4), two workgroups per CU, X loaded by ONE workgroup: one round holds 65 536 rows instead
+//     of 49 152 -- faster only for bags of 32k..64k rows (50k: 32.3 vs 36.6 us, 65 536: 38.4 vs 41.0; 70k: 50 vs 43), which is
+//     where it is used.  The gated module keeps its 8-wave shape: 128 x 128 four-wave tiles need 256 registers (473 vs 430 us at
+//     400k), 64-row tiles 182 (447 vs 418), a 256 x 128 tile at one wave per SIMD and 512 registers 584.
+// What bounds the loop (timing-only ablations, VLSA_GS_ABL / tools/gs_ablate.sh, ungated shape 1 at 400k patches, 202-208 us):
+// without the X loads 124 us (= 92 % of what the MFMA pipe sustains at this clock), X rows served from a 4 MB window (cache hits)
+// 173, X loaded but not published 200, no weight loads 187, no A-fragment reads 201, no barrier 212, no activations 202, no MFMAs
+// 163.  Not latency (X four steps ahead instead of two: 207 vs 207), not A-fragment latency (double-buffered reads: 211 vs 213).
+struct GsTiling { int max_rows, round_tiles; bool four_waves; int halves; };
+static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
+    static const int shape = [] { const char* e = getenv("VLSA_GS_HG2"); return e ? atoi(e) : -1; }();   // (A/B hook: 0 / 1 / 2)
+    if (!f32 && !gated && shape != 0) {
+        const bool all_hidden = shape == 2 || (shape < 0 && n_hint > 32768 && n_hint <= 65536);
+        if (all_hidden) return {128, 512, true, 1};
+        return {128, 256, true, 2};
+    }
+    return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
 }
 
 // vlsa_gated_scores_batch's caller sizes its tile table with this: rows of the largest tile and row tiles per round.
 extern "C" int vlsa_gated_scores_tiling(int x_dtype, int gated, int* max_rows, int* round_tiles) {
     if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !max_rows || !round_tiles) return VLSA_EINVAL;
-    const GsTiling tl = gs_tiling(x_dtype == VLSA_DT_F32, gated != 0);
+    const GsTiling tl = gs_tiling(x_dtype == VLSA_DT_F32, gated != 0, 0);
     *max_rows = tl.max_rows;
     *round_tiles = tl.round_tiles;
     return VLSA_OK;
@@ -442,7 +494,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     // (every CU busy, every tile full), then the remainder as one more single-round launch with its own, smaller tile height --
     // instead of a last round in which 256-row tiles occupy a fraction of the CUs for a full tile time (50k patches: 1.53
     // rounds were paid as 2).
-    const GsTiling tl = gs_tiling(f32, gated != 0);
+    const GsTiling tl = gs_tiling(f32, gated != 0, N);
     const int max_rows = tl.max_rows, round_tiles = tl.round_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
@@ -479,13 +531,16 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
             if (v >= 16 && v <= max_rows && v % 16 == 0) rows_per_tile = v;
         }
         const bool full = rows_per_tile == max_rows;
-        const unsigned int tiles = (unsigned int)((n + rows_per_tile - 1) / rows_per_tile) * gs::kHalves;  // (row tile, hidden half)
+        const unsigned int tiles = (unsigned int)((n + rows_per_tile - 1) / rows_per_tile) * tl.halves;  // (row tile, hidden half)
         const void* Xs = static_cast<const unsigned char*>(X) + off * ldx * esz;
         float* as = a + off;
         dropb.row_base = (unsigned int)off;
 #define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS2(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
-        if (tl.four_waves) {
+#define VLSA_GS3(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
+        if (tl.four_waves && tl.halves == 1) {
+            VLSA_GS3(false);
+        } else if (tl.four_waves) {
             if (full) VLSA_GS2(true); else VLSA_GS2(false);
         } else if (f32) {
             if (gated) {
@@ -498,6 +553,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         }
 #undef VLSA_GS
 #undef VLSA_GS2
+#undef VLSA_GS3
         off += n;
     }
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
@@ -525,7 +581,7 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     if (!bag_desc || !prep || !a || !tile_start || !a_off || B < 1 || B > 64 || n_tiles < 1 || a_floats < 1) return VLSA_EINVAL;
     if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
     const bool f32 = x_dtype == VLSA_DT_F32;
-    const GsTiling tl = gs_tiling(f32, gated != 0);
+    const GsTiling tl = gs_tiling(f32, gated != 0, 0);
     const int max_rows = tl.max_rows;
     if (rows_per_tile < 16 || rows_per_tile > max_rows || (rows_per_tile % 16)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
@@ -542,11 +598,13 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(a, 0, (size_t)a_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const bool full = rows_per_tile == max_rows;
-    const unsigned int tiles = (unsigned int)n_tiles * gs::kHalves;
+    const unsigned int tiles = (unsigned int)n_tiles * tl.halves;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
-    if (tl.four_waves) {
+    if (tl.four_waves && tl.halves == 1) {
+        hipLaunchKernelGGL((k_gated_scores<false, false, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+    } else if (tl.four_waves) {
         if (full) hipLaunchKernelGGL((k_gated_scores<false, true, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
         else hipLaunchKernelGGL((k_gated_scores<false, false, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
     } else if (f32) {
