@@ -1,0 +1,31 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): PMC passes of the attention-score kernel alone (gated and ungated module, N patches per bag):
+# gpurun_out/r03/pmc_scores_<gated|ungated>_<N>.json
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03; mkdir -p $O
+N=${1:-400000}
+pmc() { tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2>&1; }
+for m in gated ungated; do
+  pmc gs_${m}_sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -- python tools/run_gated.py $N $m
+  pmc gs_${m}_lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_WAVES GRBM_GUI_ACTIVE -- python tools/run_gated.py $N $m
+  pmc gs_${m}_mem FETCH_SIZE -- python tools/run_gated.py $N $m
+  pmc gs_${m}_wait SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU -- python tools/run_gated.py $N $m
+  python - <<PY
+import csv, glob, collections, json
+out = {}
+for tag in ("gs_${m}_sq", "gs_${m}_lds", "gs_${m}_mem", "gs_${m}_wait"):
+    fs = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)
+    if not fs: continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "k_gated_scores" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        v = v[8:] or v
+        out[k] = sum(v) / len(v)
+json.dump(out, open("$O/pmc_scores_${m}_$N.json", "w"), indent=1)
+print("$m", json.dumps(out))
+PY
+done

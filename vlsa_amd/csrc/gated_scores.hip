@@ -38,7 +38,8 @@
 
 // Timing-only ablations of k_gated_scores (results are WRONG with any bit set; tools/gs_ablate.sh builds one library per bit):
 // 1 = no A-fragment reads from LDS, 2 = no weight loads, 4 = no X loads / publication, 8 = no per-step barrier,
-// 16 = no activations in the epilogue, 32 = no MFMAs, 64 = no X loads (stale registers are published), 128 = X loaded, not published, 256 = X rows from the first 4 MB of the bag only (cache hits).
+// 16 = no activations in the epilogue, 32 = no MFMAs, 64 = no X loads (stale registers are published), 128 = X loaded, not published, 256 = X rows from the first 4 MB of the bag only (cache hits),
+// 512 = a step's X chunk read as one contiguous block of the tile (DRAM-page-friendly addresses, same bytes and instructions).
 #ifndef VLSA_GS_ABL
 #define VLSA_GS_ABL 0
 #endif
@@ -246,7 +247,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
             if constexpr (QUADX) {
 #pragma unroll
                 for (int j = 0; j < XCH; ++j)
-                    if (xr + j * XRS < nrows) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + (long long)j * XRS * ldx + 32 * ks);
+                    if (xr + j * XRS < nrows) {
+                        if (VLSA_GS_ABL & 512)   // a step's chunk of the tile as ONE contiguous block (same bytes, same instructions)
+                            r.c[j] = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(Xv) + row0 * 512 + (xr + j * XRS) * 32 + xc * 8 + 32 * 16 * RT * ks);
+                        else
+                            r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + (long long)j * XRS * ldx + 32 * ks);
+                    }
             } else if (xok) {
 #pragma unroll
                 for (int j = 0; j < XCH; ++j) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8 * j);
@@ -446,10 +452,17 @@ static bool gs_round64() {
 //     of 49 152 -- faster only for bags of 32k..64k rows (50k: 32.3 vs 36.6 us, 65 536: 38.4 vs 41.0; 70k: 50 vs 43), which is
 //     where it is used.  The gated module keeps its 8-wave shape: 128 x 128 four-wave tiles need 256 registers (473 vs 430 us at
 //     400k), 64-row tiles 182 (447 vs 418), a 256 x 128 tile at one wave per SIMD and 512 registers 584.
-// What bounds the loop (timing-only ablations, VLSA_GS_ABL / tools/gs_ablate.sh, ungated shape 1 at 400k patches, 202-208 us):
-// without the X loads 124 us (= 92 % of what the MFMA pipe sustains at this clock), X rows served from a 4 MB window (cache hits)
-// 173, X loaded but not published 200, no weight loads 187, no A-fragment reads 201, no barrier 212, no activations 202, no MFMAs
-// 163.  Not latency (X four steps ahead instead of two: 207 vs 207), not A-fragment latency (double-buffered reads: 211 vs 213).
+// What bounds the loop -- timing-only ablations (VLSA_GS_ABL, tools/gs_ablate.sh), compared in SHADER CYCLES (GRBM_GUI_ACTIVE,
+// tools/pmc_gs_variants.sh): wall time misleads here, the clock follows the data (zeroed X operands: 2.33 instead of 1.96 GHz).
+// Ungated shape 1, 400k patches: 375k cycles per XCD, of which the MFMAs need 200k (53 % busy).  Without the MFMAs the rest of the
+// loop still takes 347k: the kernel is bound by its vector-memory path, not by the matrix pipe.  On that MFMA-less loop: no X loads
+// 156k, no weight loads 265k, no A-fragment reads 346k, no activations 344k, no barrier 392k -- per round of three workgroups' steps
+// (1 536 MFMA cycles per SIMD) the 24 KB of X cost ~1 470 cycles (16 B/clk/CU: the per-CU miss path) and the 48 KB of weights ~630
+// (L2 hits at the L1's 64 B/clk).  What did NOT change it: X four steps ahead (207 vs 207 us), weights AND X four steps ahead at two
+// workgroups per CU (228 vs 227), double-buffered A fragments (211 vs 213), the publication pinned behind the MFMAs (198 vs 198),
+// full 128-byte lines per row and step pair with half the barriers (399k vs 377k cycles), DRAM-page-friendly addresses (403k vs
+// 394k); non-temporal X loads cost 17 % (the second half of every line comes from the L2).  What is left is the byte budget: a
+// 128-row x 128-unit workgroup tile needs 8 KB of X and 16 KB of weights per 512 MFMA cycles and wave.
 struct GsTiling { int max_rows, round_tiles; bool four_waves; int halves; };
 static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
     static const int shape = [] { const char* e = getenv("VLSA_GS_HG2"); return e ? atoi(e) : -1; }();   // (A/B hook: 0 / 1 / 2)
