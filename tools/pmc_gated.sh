@@ -4,7 +4,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03; mkdir -p $O
-N=${1:-400000}
+N=${1:-393216}     # 12 whole rounds of the gated kernel: one launch per call
 pmc() { tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2>&1; }
 for m in gated ungated; do
