@@ -105,7 +105,7 @@ python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1
 python tools/bench_module.py > $O/bench_module.txt 2>&1
 python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
-VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2>/dev/null
+VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2> $O/bench_sh1.err
 # ---- round 3: backward kernels of the N-sized layers, attention-weights traffic, text tower with the shared prefix
 python tools/kbench_mlp_bwd.py > $O/kbench_mlp_bwd.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mb -- python tools/run_mlp_bwd.py 50000 > /dev/null 2>&1
