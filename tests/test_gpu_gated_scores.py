@@ -31,7 +31,7 @@ def _ref(X, Wa, ba, Wg, bg, w2, c):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 16384, 16385, 20000, 32768, 32769, 50001])
+@pytest.mark.parametrize("N", [1, 16, 127, 128, 129, 1000, 5001, 16384, 16385, 20000, 32768, 32769, 50001, 65536, 65537, 100003])
 def test_fused_scores_vs_torch(N, gated, dtype):
     from vlsa_amd import functional as F
     dev = torch.device("cuda", 0)

@@ -16,7 +16,7 @@ for gated in ((False,) if os.environ.get('ONLY_UNGATED') else (True, False)):
     fs = F.FusedAttnScores()
     out = []
     for n in [int(v) for v in os.environ.get('NS', '32768,65536,50000,20000,2798,400000').split(',')]:
-        bags = [torch.randn(n, 512, device=dev).bfloat16() for _ in range(4 if n > 100000 else 16)]
+        bags = [torch.randn(n, 512, device=dev).to(torch.float32 if os.environ.get('DTYPE') == 'f32' else torch.bfloat16) for _ in range(4 if n > 100000 else 16)]
         for i in range(40): fs(bags[i %% len(bags)], Wa, ba, Wg, bg, w2, c)
         torch.cuda.synchronize()
         us = 1e30
