@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     // Where it pays is where PEEL (below) does; the gated static and fp32 kernels measured 2-5 % slower with buffer loads, the
     // ungated module's small bags (run-time tile heights of 16-48 rows) 0.7-1.5 us per bag: those keep flat loads under the row
     // predicate.
-    constexpr bool XBUF = GATED ? (!FULL && !XF32) : FULL;
+    constexpr bool XBUF = GATED ? ((!FULL || NW == 4) && !XF32) : FULL;
     const bool xok = xr < nrows;
     const __bf16* xsrc = (XBUF || XF32) ? nullptr : static_cast<const __bf16*>(Xv) + (row0 + xr) * ldx + xc * 8;          // + 32 ks; QUADX: + j XRS ldx
     const float* xsrc32 = (!XBUF && XF32) ? static_cast<const float*>(Xv) + (row0 + xr) * ldx + xc * 8 : nullptr;
@@ -485,15 +485,16 @@ static bool gs_round64() {
 
 // Workgroup shape per (bag dtype, module): rows of the largest tile, row tiles in one round of the 256 CUs, workgroups per row
 // tile (hidden halves) and whether a four-wave kernel serves it.
-//   * gated, bf16:   256 rows x 128 hidden units of both branches, 8 waves, one workgroup per CU;
+//   * gated, bf16:   four waves x 64 rows (below; VLSA_GS_G4=0: 256 rows x 128 hidden units of both branches, 8 waves, one
+//     workgroup per CU -- the shape of rounds 1-2);
 //   * gated, fp32:   128 rows (64 instead of 128 accumulator registers leave room for the fp32 staging);
 //   * ungated, bf16: FOUR waves, 128 rows.  Shape 1: 128 hidden units per workgroup, 32 per wave (HG = 2): every A fragment read
 //     from LDS feeds four MFMAs instead of two, 150 registers -> three independent workgroups per CU whose prologues / epilogues
 //     overlap the others' K loops: 400k patches 251 -> 199 us, 20k: 21.4 -> 19.5 (same box, tools/kbench_gated_ab.py).  Shape 2: all
 //     256 hidden units, 64 per wave (HG = 4), two workgroups per CU, X loaded by ONE workgroup: one round holds 65 536 rows instead
 //     of 49 152 -- faster only for bags of 32k..64k rows (50k: 32.3 vs 36.6 us, 65 536: 38.4 vs 41.0; 70k: 50 vs 43), which is
-//     where it is used.  The gated module keeps its 8-wave shape: 128 x 128 four-wave tiles need 256 registers (473 vs 430 us at
-//     400k), 64-row tiles 182 (447 vs 418), a 256 x 128 tile at one wave per SIMD and 512 registers 584.
+//     where it is used.  For the gated module 128 x 128 four-wave tiles need 256 registers (473 vs 430 us at 400k), a 256 x 128 tile at
+//     one wave per SIMD and 512 registers 584; 64-row tiles lost at 182 registers (447 vs 418) and won once they fit three per CU.
 // What bounds the loop -- timing-only ablations (VLSA_GS_ABL, tools/gs_ablate.sh), compared in SHADER CYCLES (GRBM_GUI_ACTIVE,
 // tools/pmc_gs_variants.sh): wall time misleads here, the clock follows the data (zeroed X operands: 2.33 instead of 1.96 GHz).
 // Ungated shape 1, 400k patches: 375k cycles per XCD, of which the MFMAs need 200k (53 % busy).  Without the MFMAs the rest of the
@@ -513,6 +514,13 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
         if (all_hidden) return {128, 512, true, 1};
         return {128, 256, true, 2};
     }
+    static const bool g4 = [] { const char* e = getenv("VLSA_GS_G4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    // gated, bf16: four waves x 64 rows x 128 hidden units of both branches (HG = 2): 154 registers -> three workgroups per CU, as
+    // for the ungated module (it took the leaner buffer loads to get under 168 registers; with 182 the shape lost, 447 vs 418 us).
+    // 400k patches 429 -> 379 us, 50k 63.8 -> 56.8, 24 576 33.4 -> 30.0 (same box).  A workgroup streams its 512 KB of weights
+    // whatever its tile height, so small bags keep 64-row tiles too (10k patches: 17.1 us with 64 rows, 21.4 with 32); the
+    // "round" reported to the batch caller is 64 tiles for that reason.
+    if (!f32 && gated && g4) return {64, 64, true, 2};
     return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
 }
 
@@ -575,7 +583,9 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     for (int sgi = 0; sgi < 2 && seg_rows[sgi] > 0; ++sgi) {
         const int64_t n = seg_rows[sgi];
         int rows_per_tile = max_rows;
-        if (n <= round_rows) {
+        if (gated && tl.four_waves) {
+            rows_per_tile = n > 4096 ? 64 : n > 1024 ? 32 : 16;
+        } else if (n <= round_rows) {
             rows_per_tile = (int)(((n + round_tiles - 1) / round_tiles + 15) / 16 * 16);
             // (optional: whole groups of four 16-row tiles above 64 rows -- helps 30k / 60k patches, hurts 10k / 20k / 50k)
             if (rows_per_tile > 64 && gs_round64()) rows_per_tile = (rows_per_tile + 63) / 64 * 64;
@@ -593,7 +603,10 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
 #define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS2(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS3(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
-        if (tl.four_waves && tl.halves == 1) {
+        if (gated && tl.four_waves) {
+            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+            else hipLaunchKernelGGL((k_gated_scores<true, false, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+        } else if (tl.four_waves && tl.halves == 1) {
             VLSA_GS3(false);
         } else if (tl.four_waves) {
             if (full) VLSA_GS2(true); else VLSA_GS2(false);
@@ -657,7 +670,10 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
-    if (tl.four_waves && tl.halves == 1) {
+    if (gated && tl.four_waves) {
+        if (full) hipLaunchKernelGGL((k_gated_scores<true, true, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+        else hipLaunchKernelGGL((k_gated_scores<true, false, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+    } else if (tl.four_waves && tl.halves == 1) {
         hipLaunchKernelGGL((k_gated_scores<false, false, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
     } else if (tl.four_waves) {
         if (full) hipLaunchKernelGGL((k_gated_scores<false, true, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
