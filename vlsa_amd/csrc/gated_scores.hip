@@ -26,7 +26,8 @@
 //   * bags that fit one round of the 256 CUs use smaller tiles (rows per tile = smallest multiple of 16 that still fits one
 //     round: a 2 798-patch bag runs on 176 CUs instead of 22); larger bags use the static 256-row variant.
 // Roofline: MFMA-bound: 2 terms x 2 branches x 2 x 512 x 256 = 1.05 MFLOP per patch -> 52 GFLOP per 50k bag = 21 us at
-// 2.5 PFLOP/s dense bf16.  Measured 62 us per 50k bag (2 rounds of tiles for 1.53 rounds of work) and 389 us at N = 400k =
+// 2.5 PFLOP/s dense bf16.  Round 3 (four-wave shapes, gs_tiling() below): gated 57 us per 50k bag, 383 us at 400k = 21.9 %
+// algorithmic; ungated 32 / 188 us = 22.1 %.  Rounds 1-2 (8 waves x 256 rows): 62 us per 50k bag and 389 us at N = 400k =
 // 1.08 PFLOP/s executed = 43 % of the dense peak (a register-only probe with this accumulator / operand pattern reaches
 // 2.0 PFLOP/s at 2 waves per SIMD, tools/probes/mfma_rate.hip).  What was measured on the way (tools/kbench_gated.py, and the
 // timing-only ablations listed at gs_tiling() below): of the 435 us at 400k patches the X loads cost 92 (343 without them), the
