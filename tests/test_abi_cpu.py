@@ -36,6 +36,14 @@ def test_host_side_queries_need_no_gpu():
     assert lib.vlsa_num_partials(50_000) == 256
     assert lib.vlsa_qprep_bytes(512) == 16 * 512 * 4 + 3 * 16 * 512 * 2 + 17 * 512 * 4 + 128
     assert lib.vlsa_error_string(-1) == b"invalid argument"
+    # tile geometry of the attention-score kernel (what the batched caller sizes its tile table with)
+    import ctypes
+    for dt in (_native.DT_BF16, _native.DT_F32):
+        for gated in (0, 1):
+            mr, rt = ctypes.c_int(0), ctypes.c_int(0)
+            assert lib.vlsa_gated_scores_tiling(dt, gated, ctypes.addressof(mr), ctypes.addressof(rt)) == 0
+            assert mr.value in (64, 128, 256) and rt.value >= 64
+    assert lib.vlsa_gated_scores_tiling(99, 0, ctypes.addressof(mr), ctypes.addressof(rt)) != 0
 
 
 def test_cpu_tensor_is_refused_loudly():
