@@ -181,6 +181,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     constexpr int AQ = 4 / HG;            // row tiles per group of A fragments (MFMAs on one accumulator stay 4 NB apart)
     // NW waves per workgroup, a wave owns HG groups of 16 hidden units (of both branches): the workgroup covers 16 HG NW of the 256
     // hidden units -- one half (two workgroups per row tile) or all of them (ONE: the X rows are then loaded by one CU only)
+    // fp32 bags on a four-wave shape: 128-row images of 8 KB, four of them + the scratch in the 40 KB of the bf16 layout
+    constexpr bool XSMALL = XF32 && NW == 4 && RT <= 8;
+    constexpr int XIS = XSMALL ? RT * 1024 : kXBuf;       // bytes between the LDS images of a step
     constexpr int HALVES = 16 / (HG * NW);
     static_assert(HALVES == 1 || HALVES == 2, "workgroup covers half or all of the hidden units");
     constexpr int NF = GATED ? 4 : 2;     // weight fragments per step and wave: (branch) x (hi, lo)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     // `body` (a literal): this is a step of the loop body, where every later step exists -- its loads are unconditional.  The last
     // four steps are a second copy with literal step numbers, so that no load of the loop sits behind a branch (see xrc above).
     auto step = [&](int s, const bool body, bf16x8 (&cur)[HG * NF], bf16x8 (&nxt)[HG * NF], XPair& xcur) {
-        unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * kXBuf;     // fp32 bags: hi image, lo image behind it
+        unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * XIS;     // fp32 bags: hi image, lo image behind it
         if constexpr (XF32) {
             bf16x8 h0, h1, l0, l1;
 #pragma unroll
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
             }
             *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = h0;
             *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = h1;
-            *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst0) = l0;
-            *reinterpret_cast<bf16x8_mag*>(xb + kXBuf + x_dst1) = l1;
+            *reinterpret_cast<bf16x8_mag*>(xb + XIS + x_dst0) = l0;
+            *reinterpret_cast<bf16x8_mag*>(xb + XIS + x_dst1) = l1;
         } else if (!(VLSA_GS_ABL & (4 | 128)) || s < 2) {
 #pragma unroll
             for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8_mag*>(xb + (xr + j * XRS) * 64 + (((xc + j * XCS) ^ fx) << 4)) = xcur.c[j];
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
                 if ((VLSA_GS_ABL & 1) && (s > 0 || q > 0)) { A[r4] = abl_a[r4]; continue; }
                 A[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + (AQ * q + r4) * 1024 + a_off);
                 if (VLSA_GS_ABL & 1) abl_a[r4] = A[r4];
-                if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + kXBuf + (AQ * q + r4) * 1024 + a_off);
+                if constexpr (XF32) AL[r4] = *reinterpret_cast<const bf16x8_mag*>(xb + XIS + (AQ * q + r4) * 1024 + a_off);
             }
             if (AQ * q + AQ <= nrt) {
                 // hi terms of the 4 NB accumulators of this group, then the lo terms: MFMAs on one accumulator are 4 NB apart
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
 
     // ---- epilogue: activations, gate, w2, sum over this wave's 16 hidden units, then over the 8 waves, then (atomically) over
     // the two workgroups that share the row tile
-    float_mag* scr = reinterpret_cast<float_mag*>(smem + (XF32 ? kScrOff32 : kScrOff));
+    float_mag* scr = reinterpret_cast<float_mag*>(smem + ((XF32 && !XSMALL) ? kScrOff32 : kScrOff));
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
         if (rt < nrt)
@@ -522,6 +525,8 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
     // whatever its tile height, so small bags keep 64-row tiles too (10k patches: 17.1 us with 64 rows, 21.4 with 32); the
     // "round" reported to the batch caller is 64 tiles for that reason.
     if (!f32 && gated && g4) return {64, 64, true, 2};
+    static const bool f4 = [] { const char* e = getenv("VLSA_GS_F4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    if (f32 && !gated && f4) return {128, 256, true, 2};
     return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
 }
 
@@ -604,7 +609,10 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
 #define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS2(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS3(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
-        if (gated && tl.four_waves) {
+        if (f32 && tl.four_waves) {
+            if (full) hipLaunchKernelGGL((k_gated_scores<false, true, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+            else hipLaunchKernelGGL((k_gated_scores<false, false, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+        } else if (gated && tl.four_waves) {
             if (full) hipLaunchKernelGGL((k_gated_scores<true, true, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
             else hipLaunchKernelGGL((k_gated_scores<true, false, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
         } else if (tl.four_waves && tl.halves == 1) {
@@ -671,7 +679,10 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
-    if (gated && tl.four_waves) {
+    if (f32 && tl.four_waves) {
+        if (full) hipLaunchKernelGGL((k_gated_scores<false, true, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+        else hipLaunchKernelGGL((k_gated_scores<false, false, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+    } else if (gated && tl.four_waves) {
         if (full) hipLaunchKernelGGL((k_gated_scores<true, true, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
         else hipLaunchKernelGGL((k_gated_scores<true, false, false, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
     } else if (tl.four_waves && tl.halves == 1) {
