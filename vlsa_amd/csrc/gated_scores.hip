@@ -221,8 +221,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     // no faster: the loop is not load-bound), the thread's 32 B of the X chunk two steps ahead in registers and from there
     // into the shared LDS tile of its step
     const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + HG * w) * kSteps * NF * 1024 + lane * 16;
-    constexpr int XCH = XF32 ? 2 : (RT / NW) > 1 ? (RT / NW) : 1;  // 16-B chunks of a step's X chunk per thread (a row has 4)
-    static_assert(!XF32 || XCH == 2, "fp32 bags: two chunks per thread");
+    // 16-B chunks (8 values) of a step's X chunk per thread (a row has 4); fp32 bags: two, one on the 64-row four-wave shape
+    constexpr int XCH = XF32 ? ((NW == 4 && RT == 4) ? 1 : 2) : (RT / NW) > 1 ? (RT / NW) : 1;
     // QUADX (the ungated module's bf16 bags): four lanes share the 64 contiguous bytes of a row (chunk tid & 3), the thread's chunk j
     // sits XRS rows further down -- 16 rows x 64 B per load instruction instead of 32 rows x 2 x 16 B (199 vs 207 us at 400k
     // patches).  Otherwise (fp32 bags; the gated module, whose 256-register budget the second row pointer broke: 64 spilled
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     // Where it pays is where PEEL (below) does; the gated static and fp32 kernels measured 2-5 % slower with buffer loads, the
     // ungated module's small bags (run-time tile heights of 16-48 rows) 0.7-1.5 us per bag: those keep flat loads under the row
     // predicate.
-    constexpr bool XBUF = GATED ? ((!FULL || NW == 4) && !XF32) : FULL;
+    constexpr bool XBUF = GATED ? (XF32 ? (NW == 4 && FULL) : (!FULL || NW == 4)) : FULL;
     const bool xok = xr < nrows;
     const __bf16* xsrc = (XBUF || XF32) ? nullptr : static_cast<const __bf16*>(Xv) + (row0 + xr) * ldx + xc * 8;          // + 32 ks; QUADX: + j XRS ldx
     const float* xsrc32 = (!XBUF && XF32) ? static_cast<const float*>(Xv) + (row0 + xr) * ldx + xc * 8 : nullptr;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     const int x_dst0 = xr * 64 + ((xc ^ fx) << 4), x_dst1 = xr * 64 + (((xc + 1) ^ fx) << 4);   // chunk j: xr * 64 + (((xc + j) ^ fx) << 4)
     const int a_off = i16 * 64 + ((g ^ ((0 - (i16 >> 2)) & 3)) << 4);    // A fragment of row tile rt: + rt * 1024
     // the thread's 16 values of a step: two 16-byte bf16 chunks c0, c1 (bf16 bags), or four float4 (fp32 bags)
-    struct XPair { bf16x8 c[XF32 ? 1 : XCH]; f32x4 f[XF32 ? 4 : 1]; };
+    struct XPair { bf16x8 c[XF32 ? 1 : XCH]; f32x4 f[XF32 ? 2 * XCH : 1]; };
     auto load_x = [&](int ks) -> XPair {
         XPair r = {};
         if constexpr (!XBUF) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
             } else if (xok) {
                 if constexpr (XF32) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) r.f[q] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4 * q);
+                    for (int q = 0; q < 2 * XCH; ++q) r.f[q] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4 * q);
                 } else {
 #pragma unroll
                     for (int j = 0; j < XCH; ++j) r.c[j] = *reinterpret_cast<const bf16x8*>(xsrc + 32 * ks + 8 * j);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
             }
         } else if constexpr (XF32) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 2 * XCH; ++q)
                 r.f[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, 128 * ks + 16 * q, 0));
         } else if (!(VLSA_GS_ABL & (4 | 64))) {
 #pragma unroll
@@ -329,18 +329,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
     auto step = [&](int s, const bool body, bf16x8 (&cur)[HG * NF], bf16x8 (&nxt)[HG * NF], XPair& xcur) {
         unsigned char* xb = smem + kXOff + (s & 1) * (XF32 ? 2 : 1) * XIS;     // fp32 bags: hi image, lo image behind it
         if constexpr (XF32) {
-            bf16x8 h0, h1, l0, l1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v0 = xcur.f[e >> 2][e & 3], v1 = xcur.f[2 + (e >> 2)][e & 3];
-                const __bf16 a0 = (__bf16)v0, a1 = (__bf16)v1;
-                h0[e] = a0; l0[e] = (__bf16)(v0 - (float)a0);
-                h1[e] = a1; l1[e] = (__bf16)(v1 - (float)a1);
+            for (int j = 0; j < XCH; ++j) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = xcur.f[2 * j + (e >> 2)][e & 3];
+                    const __bf16 a = (__bf16)v;
+                    h[e] = a;
+                    l[e] = (__bf16)(v - (float)a);
+                }
+                *reinterpret_cast<bf16x8_mag*>(xb + (j ? x_dst1 : x_dst0)) = h;
+                *reinterpret_cast<bf16x8_mag*>(xb + XIS + (j ? x_dst1 : x_dst0)) = l;
             }
-            *reinterpret_cast<bf16x8_mag*>(xb + x_dst0) = h0;
-            *reinterpret_cast<bf16x8_mag*>(xb + x_dst1) = h1;
-            *reinterpret_cast<bf16x8_mag*>(xb + XIS + x_dst0) = l0;
-            *reinterpret_cast<bf16x8_mag*>(xb + XIS + x_dst1) = l1;
         } else if (!(VLSA_GS_ABL & (4 | 128)) || s < 2) {
 #pragma unroll
             for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8_mag*>(xb + (xr + j * XRS) * 64 + (((xc + j * XCS) ^ fx) << 4)) = xcur.c[j];
@@ -491,7 +492,7 @@ static bool gs_round64() {
 // tile (hidden halves) and whether a four-wave kernel serves it.
 //   * gated, bf16:   four waves x 64 rows (below; VLSA_GS_G4=0: 256 rows x 128 hidden units of both branches, 8 waves, one
 //     workgroup per CU -- the shape of rounds 1-2);
-//   * gated, fp32:   128 rows (64 instead of 128 accumulator registers leave room for the fp32 staging);
+//   * gated, fp32:   four waves x 64 rows as for bf16 (VLSA_GS_F4=0: 8 waves x 128 rows);
 //   * ungated, bf16: FOUR waves, 128 rows.  Shape 1: 128 hidden units per workgroup, 32 per wave (HG = 2): every A fragment read
 //     from LDS feeds four MFMAs instead of two, 150 registers -> three independent workgroups per CU whose prologues / epilogues
 //     overlap the others' K loops: 400k patches 251 -> 199 us, 20k: 21.4 -> 19.5 (same box, tools/kbench_gated_ab.py).  Shape 2: all
@@ -525,8 +526,10 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
     // whatever its tile height, so small bags keep 64-row tiles too (10k patches: 17.1 us with 64 rows, 21.4 with 32); the
     // "round" reported to the batch caller is 64 tiles for that reason.
     if (!f32 && gated && g4) return {64, 64, true, 2};
+    // fp32 bags: the same two shapes (LDS images of RT KB; 164 registers): ungated 50k patches 62.4 -> 52.0 us, gated 105.7 -> 81.5
     static const bool f4 = [] { const char* e = getenv("VLSA_GS_F4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     if (f32 && !gated && f4) return {128, 256, true, 2};
+    if (f32 && gated && f4) return {64, 64, true, 2};
     return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
 }
 
@@ -609,7 +612,10 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
 #define VLSA_GS(G, F, X32) hipLaunchKernelGGL((k_gated_scores<G, F, X32>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS2(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
 #define VLSA_GS3(F) hipLaunchKernelGGL((k_gated_scores<false, F, false, 8, 4, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb)
-        if (f32 && tl.four_waves) {
+        if (f32 && gated && tl.four_waves) {
+            if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+            else hipLaunchKernelGGL((k_gated_scores<true, false, true, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
+        } else if (f32 && tl.four_waves) {
             if (full) hipLaunchKernelGGL((k_gated_scores<false, true, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
             else hipLaunchKernelGGL((k_gated_scores<false, false, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, Xs, (long long)n, (long long)ldx, pp, as, rows_per_tile, dropb);
         } else if (gated && tl.four_waves) {
@@ -679,7 +685,10 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
 #define VLSA_GSB(G, F, X32, RTV) hipLaunchKernelGGL((k_gated_scores<G, F, X32, RTV>), dim3(tiles), dim3(512), X32 ? gs::kLds32 : gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt)
-    if (f32 && tl.four_waves) {
+    if (f32 && gated && tl.four_waves) {
+        if (full) hipLaunchKernelGGL((k_gated_scores<true, true, true, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+        else hipLaunchKernelGGL((k_gated_scores<true, false, true, 4, 2, 4>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
+    } else if (f32 && tl.four_waves) {
         if (full) hipLaunchKernelGGL((k_gated_scores<false, true, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
         else hipLaunchKernelGGL((k_gated_scores<false, false, true, 8, 2>), dim3(tiles), dim3(256), gs::kLds, st, (const void*)nullptr, 0ll, 0ll, pp, a, rows_per_tile, bt);
     } else if (gated && tl.four_waves) {
