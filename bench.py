@@ -163,7 +163,13 @@ def main():
 
     dist = None
     force_sharded = os.environ.get("VLSA_BENCH_FORCE_SHARDED") == "1"  # exercise the N > 1 code path on one GPU
+    real_stdout = None
     if world > 1 or force_sharded:
+        # RCCL prints its version banner on fd 1 when the communicator comes up: everything this process writes to stdout goes to
+        # stderr from here on, the ONE JSON line is written to the saved descriptor
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         if force_sharded and "RANK" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1")
@@ -413,7 +419,10 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
         if not out.get("verified", {}).get("ok", False):
             sys.stderr.write("bench.py: the timed launches' logits do not match the CPU oracle -- the number above is void\n")
             if dist is not None:
