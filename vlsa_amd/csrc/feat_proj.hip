@@ -19,6 +19,10 @@
 // per patch written.
 #include "vlsa_common.h"
 
+#ifndef FP_XBUF
+#define FP_XBUF 1
+#endif
+
 namespace vlsa {
 
 typedef bf16x8 __attribute__((may_alias)) bf16x8_maf;
@@ -109,10 +113,27 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
     // 16-B chunk c of row r is stored at position c ^ f(r), f(r) = (-(r >> 2)) & 3 (see k_gated_scores)
     const int x_dst = xr * 64 + ((xc ^ ((0 - (xr >> 2)) & 3)) << 4);
     const int a_off = i16 * 64 + ((g ^ ((0 - (i16 >> 2)) & 3)) << 4);    // A fragment of row tile rt: + rt * 1024
+    // X through range-checked buffer loads: rows past the end of the bag (and threads past the tile) read zeros without a branch, so
+    // that the compiler's s_waitcnt counts stay exact (see k_gated_scores)
+    constexpr int XESZ = XF32 ? 4 : 2;
+    const unsigned long long xbase = reinterpret_cast<unsigned long long>(Xv) + (unsigned long long)row0 * ldx * XESZ;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>((static_cast<unsigned long long>((unsigned)__builtin_amdgcn_readfirstlane((int)(xbase >> 32))) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)xbase)),
+        0, __builtin_amdgcn_readfirstlane((int)(((long long)(nrows - 1) * ldx + kD) * XESZ)), 0x00020000);
+    const int xvoff = (int)((long long)xr * ldx + xc * 8) * XESZ;
+    typedef int i32x4fp __attribute__((ext_vector_type(4)));
     struct XReg { bf16x8 h; f32x4 f[XF32 ? 2 : 1]; };
     auto load_x = [&](int ks) -> XReg {
         XReg r = {};
-        if (xok) {
+        if constexpr (FP_XBUF) {
+            if constexpr (XF32) {
+                r.f[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, 128 * ks, 0));
+                r.f[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, 128 * ks + 16, 0));
+            } else {
+                r.h = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff, 64 * ks, 0));
+            }
+        } else if (xok) {
             if constexpr (XF32) {
                 r.f[0] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks);
                 r.f[1] = *reinterpret_cast<const f32x4*>(xsrc32 + 32 * ks + 4);
@@ -142,7 +163,7 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
     load_b(0, B0);
     X1 = load_x(1);
 
-    auto step = [&](int s, bf16x8 (&cur)[kNF], bf16x8 (&nxt)[kNF], XReg& xcur) {
+    auto step = [&](int s, const bool body, bf16x8 (&cur)[kNF], bf16x8 (&nxt)[kNF], XReg& xcur) {
         unsigned char* xb = smem + (s & 1) * 2 * kXBuf;     // hi image; fp32 bags: lo image behind it
         if (xr < ROWS) {
             if constexpr (XF32) {
@@ -161,8 +182,8 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
             }
         }
         __syncthreads();                     // X(s) published by every wave; everyone is done reading buffer (s + 1) & 1
-        if (s + 1 < kSteps) load_b(s + 1, nxt);
-        if (s + 2 < kSteps) xcur = load_x(s + 2);
+        if (body || s + 1 < kSteps) load_b(s + 1, nxt);
+        if (body || s + 2 < kSteps) xcur = load_x(s + 2);
 #pragma unroll
         for (int q = 0; q < RT / 2; ++q) {   // two row tiles at a time (8 A-fragment registers; groups of four spilled)
             bf16x8 A[2], AL[XF32 ? 2 : 1];
@@ -188,10 +209,15 @@ __global__ __launch_bounds__(512) void k_feat_proj(const void* __restrict__ Xv, 
             }
         }
     };
+    constexpr bool PEEL = FP_XBUF;
 #pragma unroll 1
-    for (int s = 0; s < kSteps; s += 2) {
-        step(s, B0, B1, X0);
-        step(s + 1, B1, B0, X1);
+    for (int s = 0; s < (PEEL ? kSteps - 2 : kSteps); s += 2) {
+        step(s, PEEL, B0, B1, X0);
+        step(s + 1, PEEL, B1, B0, X1);
+    }
+    if constexpr (PEEL) {
+        step(kSteps - 2, false, B0, B1, X0);
+        step(kSteps - 1, false, B1, B0, X1);
     }
 
     // ---- epilogue: LayerNorm over the 512 columns of every row (8 waves x 64 columns), two passes
