@@ -74,7 +74,7 @@ def test_module_forward_bags_ret_with_attn_vs_reference_fixture(name):
     if grads:
         (logits2[0:1] * H.t(fx["G"]).cuda()).sum().backward()
         g = model.mil_encoder.Q.grad if gated else model.mil_encoder.Q.residual_features.grad
-        cases.check_big(fx, "grad.Q" if gated else "grad.resid", g, atol=2e-5, rtol=2e-3)
+        cases.check_big(fx, "grad.Q" if gated else "grad.resid", g, atol=1e-5, rtol=1e-4)
     v, attn3 = model.mil_encoder.forward_bags(bags[:2], ret_with_attn=True)
     assert v.shape[0] == 2 and len(attn3) == 2
 

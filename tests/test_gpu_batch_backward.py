@@ -9,7 +9,7 @@ from oracle import vlsa_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-GRAD_RTOL = 2e-3  # relative to the largest gradient entry (fp32 accumulation order differs), as in test_gpu_modules.py
+GRAD_RTOL = 1e-4  # relative to the largest gradient entry, as in test_gpu_modules.py (observed <= 2.6e-5: profiles/r04_grad_errors.txt)
 
 
 def _oracle_grads(bags, Q, Gs, gated):
@@ -43,6 +43,7 @@ def test_batched_backward_vs_oracle_autograd(sizes, dtype, P, gated):
     torch.cuda.synchronize()
     assert (out.detach().cpu() - ref_out).abs().max().item() < 1e-4 * max(1.0, ref_out.abs().max().item())
     scale = ref_grad.abs().max().item()
+    cases.record_grad_error("dQ", (Qd.grad.cpu() - ref_grad).abs().max().item(), scale, GRAD_RTOL * scale)
     assert (Qd.grad.cpu() - ref_grad).abs().max().item() < GRAD_RTOL * scale
 
 
@@ -107,6 +108,7 @@ def test_forward_bags_training_matches_per_bag_loop(pooling):
             continue
         scale = max(pb.grad.abs().max().item(), 1e-6)
         # + 2e-6: the attention-pooling output bias is softmax-invariant, its gradient is rounding noise around 0
+        cases.record_grad_error("batched vs per-bag: " + na, (pa.grad - pb.grad).abs().max().item(), scale, GRAD_RTOL * scale + 2e-6)
         assert (pa.grad - pb.grad).abs().max().item() < GRAD_RTOL * scale + 2e-6, na
 
 

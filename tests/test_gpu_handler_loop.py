@@ -145,3 +145,146 @@ def test_single_slide_path_follows_retrained_prompts_when_the_mil_encoder_is_fro
     # the evaluation-time text features did change between rounds (the step is large) -- and the hazard is real only if
     # an address repeats; either way every round matched the oracle above
     assert len(seen_ptrs) >= 1
+
+
+# ---- look-ahead: the handler's bag-by-bag evaluation loop served from batched launches -------------------
+class _PatchItems(torch.utils.data.Dataset):
+    """items shaped like WSIPatchSurv's 'patch' mode (dataset/PatchWSI.py:197-215)"""
+
+    def __init__(self, sizes, seed=77):
+        self.feats = [cases.make_bag(n, seed + i, "clustered" if i % 2 else "iid") for i, n in enumerate(sizes)]
+        self.uid = [f"p{i}" for i in range(len(sizes))]
+
+    def __len__(self):
+        return len(self.feats)
+
+    def __getitem__(self, i):
+        return torch.Tensor([i]).to(torch.int), (self.feats[i].to(torch.float), torch.Tensor([0])), torch.Tensor([float(i), 1.0])
+
+
+def _eval_loop(model, loader):
+    """runner/vlsa_handler.py:315-345 (tests/handler_loop.py::test_model) + the launches the model issued"""
+    return HL.test_model(model, loader)["raw_y_hat"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lookahead_serves_the_handlers_eval_loop_from_batched_launches(hooks_installed, dtype):
+    from vlsa_amd.ingest import ResidentBags, ResidentBagView
+    model, cfg = _build()
+    sizes = [700, 64, 1, 2798, 333, 4100, 65, 900, 17, 1200] * 8          # 80 items: a full 64-bag window + a 16-bag one
+    ds = _PatchItems(sizes)
+    rb = ResidentBags(ds, dtype=dtype)
+    loader = torch.utils.data.DataLoader(rb, batch_size=1, shuffle=False, num_workers=0)
+    model.lookahead_bags = 0
+    first = _eval_loop(model, loader)                  # epoch 1 uploads; bag-by-bag route (look-ahead off)
+    model.lookahead_bags = 64
+    calls = []
+    orig = model._forward_bags_fused
+    model._forward_bags_fused = lambda bags, tf, **kw: (calls.append(len(bags)), orig(bags, tf, **kw))[1]
+    ahead = _eval_loop(model, loader)                  # everything resident: windows of 64 + 16
+    assert calls == [64, 16], calls
+    # the loader really delivered the resident rows themselves (no collate copy), tagged with their item
+    _, data_x, _ = next(iter(loader))
+    assert isinstance(data_x[0], ResidentBagView) and data_x[0]._vlsa_src[1] == 0 and data_x[0].data_ptr() == rb.resident_view(0).data_ptr()
+    # values: the batched kernels vs the per-bag kernels (different partial sums) and vs the oracle
+    assert (ahead - first).abs().max().item() < 2e-5
+    enc = model.mil_encoder
+    with torch.no_grad():
+        T, Q = model.forward_text_only().cpu(), enc.get_query().cpu()
+    for i in (0, 2, 3, 63, 64, 79):
+        x = ds.feats[i].to(dtype).float()
+        ref = O.vlsa_vlfan_forward(x, Q, T, model.logit_scale.detach().cpu(), head_weight=enc.visual_adapter.weight.detach().cpu(),
+                                   head_bias=enc.visual_adapter.bias.detach().cpu())["logits"]
+        assert (ahead[i:i + 1] - ref).abs().max().item() < 1e-4, i
+    # bit-equal to what forward_bags hands out for the same window
+    with torch.no_grad():
+        direct = model.forward_bags([rb.resident_view(j) for j in range(64)])[0].cpu()
+    assert torch.equal(direct, ahead[:64])
+    # a second pass under unchanged parameters: new windows (only the last one is kept), same numbers, bit for bit
+    again = _eval_loop(model, loader)
+    assert torch.equal(again, ahead)
+
+
+def test_lookahead_cannot_serve_stale_rows(hooks_installed):
+    """An optimizer step, a load_state_dict, an in-place edit of any tensor the result depends on, or train mode between two
+    calls of ONE window: the rows computed before are not handed out again."""
+    from vlsa_amd.ingest import ResidentBags
+    model, cfg = _build()
+    opt = HL.make_optimizer(model, cfg)
+    for g in opt.param_groups:
+        g["lr"] = 0.05          # a large step: stale rows would be far outside the tolerance
+    sizes = [500, 300, 700, 64, 900, 129, 2000, 31]
+    ds = _PatchItems(sizes, seed=177)
+    rb = ResidentBags(ds, dtype=torch.float32)
+    for i in range(len(sizes)):
+        rb[i]                                           # upload
+    xs, ys = HC.train_batch()
+    xs, ys = [x.cuda() for x in xs], [y.cuda() for y in ys]
+    enc = model.mil_encoder
+
+    def item(i):
+        return torch.utils.data.default_collate([rb[i]])[1][0].cuda()
+
+    def oracle(i):
+        with torch.no_grad():
+            T, Q = model.forward_text_only().cpu(), enc.get_query().cpu()
+        return O.vlsa_vlfan_forward(ds.feats[i], Q, T, model.logit_scale.detach().cpu(), head_weight=enc.visual_adapter.weight.detach().cpu(),
+                                    head_bias=enc.visual_adapter.bias.detach().cpu())["logits"]
+
+    def check(i, what):
+        model.eval()
+        with torch.no_grad():
+            got = model(item(i))[0].cpu()
+        assert (got - oracle(i)).abs().max().item() < 1e-4, what
+
+    check(0, "first window")
+    assert model._la is not None and len(model._la["rows"]) == len(sizes)
+    check(1, "served from the window")
+    model.train()
+    HL.update_network(model, opt, O.vlsa_objective, xs, ys)                  # prompts, queries, adapter, logit scale all move
+    check(2, "after an optimizer step")
+    with torch.no_grad():
+        enc.visual_adapter.bias.add_(0.3)                                     # in-place edit, no forward in between
+    check(3, "after an in-place parameter edit")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["mil_encoder.visual_adapter.weight"] = sd["mil_encoder.visual_adapter.weight"] * 1.5
+    model.load_state_dict(sd, strict=False)
+    check(4, "after load_state_dict")
+    with torch.no_grad():
+        model.logit_scale.mul_(0.5)
+    check(5, "after a logit-scale edit")
+    with torch.no_grad():
+        model.prompt_learner.rank_embeds.mul_(1.1)                            # text side: a new text-feature tensor
+    check(6, "after a prompt edit")
+    # train mode under no_grad (dropout-bearing encoders would be stochastic): never served from a window
+    model.train()
+    with torch.no_grad():
+        model._la = None
+        model(item(7))
+    assert model._la is None
+
+
+def test_lookahead_shrinks_under_random_access(hooks_installed):
+    from vlsa_amd.ingest import ResidentBags
+    model, cfg = _build()
+    sizes = [300] * 200
+    ds = _PatchItems(sizes, seed=277)
+    rb = ResidentBags(ds, dtype=torch.bfloat16)
+    for i in range(len(sizes)):
+        rb[i]
+    model.eval()
+    calls = []
+    orig = model._forward_bags_fused
+    model._forward_bags_fused = lambda bags, tf, **kw: (calls.append(len(bags)), orig(bags, tf, **kw))[1]
+    order = [0, 120, 3, 77, 160, 30, 141, 15, 99, 6, 180, 50]
+    with torch.no_grad():
+        outs = [model(torch.utils.data.default_collate([rb[i]])[1][0])[0] for i in order]
+    assert calls == [64, 16, 4], calls                 # 64 -> 16 -> 4 -> 1 = the per-bag route from the fourth access on
+    with torch.no_grad():
+        for i, o in zip(order, outs):
+            ref = model.forward_bags([rb.resident_view(i)])[0]
+            assert (o - ref).abs().max().item() < 2e-5
+        calls.clear()
+        for i in range(100, 140):                      # sequential again: after three in a row the windows come back (8, 16, ...)
+            model(torch.utils.data.default_collate([rb[i]])[1][0])
+    assert calls == [8, 16, 32], calls

@@ -5,7 +5,7 @@ vlfan_dx.hip) against torch autograd through the CPU oracle's restatements of th
   * Feat_Projecter (model/layers.py:65-82): dW, db, dgamma, dbeta from the upstream dL/dY
   * cross attention (model/deepmil.py:187-200): dL/dX for fp32 bags (+ dQ from the existing kernels)
 
-Gradient bar as everywhere else in the suite: 2e-3 of the tensor's largest entry.  The module-level paths through these
+Gradient bar as everywhere else in the suite: 1e-4 of the tensor's largest entry.  The module-level paths through these
 kernels are pinned by the reference-generated fixtures in test_gpu_modules.py / test_gpu_modules_r2.py."""
 import numpy as np
 import pytest
@@ -15,12 +15,14 @@ import cases
 from oracle import vlsa_oracle as O
 
 pytestmark = pytest.mark.gpu
-RTOL = 2e-3
+RTOL = 1e-4       # BASELINE.md 3; observed <= 1.7e-5 for fp32 gradients (profiles/r04_grad_errors.txt)
 
 
 def _close(got, ref, what, rtol=RTOL, atol=1e-6):
     got, ref = got.detach().float().cpu().numpy(), ref.detach().float().cpu().numpy()
     err = np.abs(got - ref).max()
+    if rtol > 0:
+        cases.record_grad_error(what, err, np.abs(ref).max(), rtol * np.abs(ref).max() + atol)
     assert err <= rtol * np.abs(ref).max() + atol, f"{what}: max abs err {err:.3e} vs max |ref| {np.abs(ref).max():.3e}"
 
 
@@ -243,5 +245,5 @@ def test_attention_pooling_dx_matches_autograd(gated, dtype, N):
     for k in pp:
         if k != "b2":                       # softmax-invariant shift: gradient 0 up to rounding
             _close(gp[k].grad, pp[k].grad, f"d{k}", atol=2e-6)
-    tol = RTOL if dtype == torch.float32 else 8e-3      # a bf16 bag receives a bf16 gradient
+    tol = RTOL if dtype == torch.float32 else 4.5e-3    # a bf16 bag receives a bf16 gradient: half an ulp = 2^-8 = 3.9e-3 (observed 3.4e-3)
     _close(Xd.grad, X.grad, "dX", rtol=tol, atol=1e-6)

@@ -10,7 +10,9 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-GRAD_RTOL = 2e-3   # relative to the largest entry of each gradient tensor (fp32 accumulation order differs)
+GRAD_RTOL = 1e-4   # "backward grads within 1e-4 relative" (of the largest entry of each gradient tensor); the worst
+# error observed over the 621 gradient comparisons of the GPU suite is 2.6e-5 (profiles/r04_grad_errors.txt)
+GRAD_ATOL = 1e-5   # gradients that are exactly 0 in the reference (softmax-invariant biases, N = 1 bags): rounding noise <= 3.5e-6
 
 
 class TextParam(nn.Module):
@@ -90,7 +92,7 @@ def test_vlsa_vlfan_forward_backward(case):
     assert np.abs(logits2.detach().cpu().numpy() - fx["logits"]).max() < TOL
     (logits2 * H.t(fx["G"]).cuda()).sum().backward()
     enc = model.mil_encoder
-    chk = lambda key, g: cases.check_big(fx, key, g, atol=2e-5, rtol=GRAD_RTOL)  # noqa: E731
+    chk = lambda key, g: cases.check_big(fx, key, g, atol=GRAD_ATOL, rtol=GRAD_RTOL)  # noqa: E731
     chk("grad.logit_scale", model.logit_scale.grad)
     chk("grad.T", tp.T.grad)
     if head != "Identity":
@@ -160,7 +162,7 @@ def test_vlsa_deepmil_forward_backward(case):
     logits2, _, _ = model(Xd)
     assert np.abs(logits2.detach().cpu().numpy() - fx["logits"]).max() < TOL
     (logits2 * H.t(fx["G"]).cuda()).sum().backward()
-    chk = lambda key, g: cases.check_big(fx, key, g, atol=2e-5, rtol=GRAD_RTOL)  # noqa: E731
+    chk = lambda key, g: cases.check_big(fx, key, g, atol=GRAD_ATOL, rtol=GRAD_RTOL)  # noqa: E731
     chk("grad.logit_scale", model.logit_scale.grad)
     chk("grad.T", tp.T.grad)
     chk("grad.adapter.down", enc.visual_adapter.fc[0].weight.grad)
@@ -187,6 +189,7 @@ def test_backward_full_size_vs_oracle_autograd():
         (out * G.cuda()).sum().backward()
         scale = Q.grad.abs().max().item()
         assert (out.detach().cpu() - ref["out"].detach()).abs().max().item() < 1e-4 * max(1.0, ref["out"].abs().max().item())
+        cases.record_grad_error("dQ", (Qd.grad.cpu() - Q.grad).abs().max().item(), scale, GRAD_RTOL * scale)
         assert (Qd.grad.cpu() - Q.grad).abs().max().item() < GRAD_RTOL * scale
 
 

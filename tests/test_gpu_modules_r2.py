@@ -13,7 +13,7 @@ from test_oracle_golden_r2 import prompt_adapter_state
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-GRAD_RTOL = 2e-3
+GRAD_RTOL, GRAD_ATOL = 1e-4, 1e-5      # as in test_gpu_modules.py (observed <= 2.6e-5: profiles/r04_grad_errors.txt)
 
 
 class TextParam(nn.Module):
@@ -85,7 +85,7 @@ def test_feat_projecter_forward_and_gradients(case):
     logits2, _, _ = model(Xd)                  # training: the bag now carries a gradient (into the projecter)
     assert np.abs(logits2.detach().cpu().numpy() - fx["logits"]).max() < TOL
     (logits2 * H.t(fx["G"]).cuda()).sum().backward()
-    chk = lambda key, g: cases.check_big(fx, key, g, atol=2e-5, rtol=GRAD_RTOL)  # noqa: E731
+    chk = lambda key, g: cases.check_big(fx, key, g, atol=GRAD_ATOL, rtol=GRAD_RTOL)  # noqa: E731
     fp = enc.feat_proj.projecter
     chk("grad.fp.w", fp[0].weight.grad); chk("grad.fp.b", fp[0].bias.grad)
     chk("grad.fp.gamma", fp[1].weight.grad); chk("grad.fp.beta", fp[1].bias.grad)
@@ -137,7 +137,7 @@ def test_deepmil_linear_head(case):
     assert np.abs(img.cpu().numpy() - fx["image_features"]).max() < 1e-5
     logits2, _, _ = model(Xd)
     (logits2 * H.t(fx["G"]).cuda()).sum().backward()
-    chk = lambda key, g: cases.check_big(fx, key, g, atol=2e-5, rtol=GRAD_RTOL)  # noqa: E731
+    chk = lambda key, g: cases.check_big(fx, key, g, atol=GRAD_ATOL, rtol=GRAD_RTOL)  # noqa: E731
     chk("grad.g.w", enc.g.weight.grad); chk("grad.g.b", enc.g.bias.grad)
     for k, g in _pool_grads(enc.sigma).items():
         chk("grad.pool." + k, g)
@@ -173,7 +173,7 @@ def test_prompt_adapter_methods(case):
     if "G" in fx:
         (Q * H.t(fx["G"]).cuda()).sum().backward()
         for n, p in pa.named_parameters():
-            cases.check_big(fx, "grad." + n, p.grad, atol=2e-5, rtol=GRAD_RTOL)
+            cases.check_big(fx, "grad." + n, p.grad, atol=GRAD_ATOL, rtol=GRAD_RTOL)
 
 
 def test_negative_prompt_adapter_feeds_gated_query_vlfan():

@@ -44,8 +44,9 @@ def _grads(model, tp):
     return g
 
 
-def _close(a, b, what, rtol=2e-3):
+def _close(a, b, what, rtol=1e-4):
     a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+    cases.record_grad_error(str(what), np.abs(a - b).max(), np.abs(b).max(), rtol * np.abs(b).max() + 2e-6)
     assert np.abs(a - b).max() <= rtol * np.abs(b).max() + 2e-6, (what, np.abs(a - b).max(), np.abs(b).max())
 
 

@@ -150,6 +150,7 @@ def test_trainable_tower_features_and_weight_gradients(case, prefix):
 
     def close(got, want, what):
         got, want = got.detach().cpu().numpy(), want.detach().numpy()
+        cases.record_grad_error("trainable tower: " + what, np.abs(got - want).max(), np.abs(want).max(), 2e-3 * np.abs(want).max() + 1e-7)
         assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-7, (what, np.abs(got - want).max(), np.abs(want).max())
     close(pl.context_embeds.grad, ctx.grad, "context")
     close(pl.rank_embeds.grad, rk.grad, "rank")
@@ -210,6 +211,7 @@ def test_vlsa_end_to_end_with_gpu_text_side():
     (ref_logits * G).sum().backward()
     for p, leaf in ((pl.context_embeds, leaves["context"]), (pl.rank_embeds, leaves["rank"])):
         ref = leaf.grad
+        cases.record_grad_error("end to end: prompt embeds", (p.grad.cpu() - ref).abs().max().item(), ref.abs().max().item())
         assert (p.grad.cpu() - ref).abs().max().item() < 2e-3 * max(1e-3, ref.abs().max().item()) + 1e-5
     # after an optimizer-like update the cached text features are recomputed
     with torch.no_grad():

@@ -138,3 +138,36 @@ def test_prototype_shap_matches_reference_fixture_cpu():
     fx = dict(np.load(os.path.join(GOLDEN, "interpretation.npz")))
     s = evaluate_prototype_shap_imp(fx["shap_in"], 56.31)
     assert np.abs(s.numpy() - fx["shap_out"]).max() < 1e-5
+
+
+def test_step_query_is_not_shared_across_bags_when_the_query_network_has_active_dropout():
+    """the 'FC' PromptAdapter carries Dropout(0.25) (model/prompt_learners/prompt_adapter.py:95-104); the reference
+    evaluates it once per bag (runner/vlsa_handler.py:267-269), so in training mode every bag sees its own mask.  A
+    deterministic query network is still evaluated once per parameter version."""
+    from vlsa_amd.deepmil import VLFAN
+
+    class QNet(nn.Module):
+        def __init__(self, p):
+            super().__init__()
+            self.base = nn.Parameter(torch.randn(5, 512))
+            self.drop = nn.Dropout(p)
+            self.calls = 0
+
+        def forward(self):
+            self.calls += 1
+            return self.drop(self.base)
+
+    enc = VLFAN(dim_in=512, use_feat_proj=False, query="Text", num_query=5)
+    q = QNet(0.25)
+    enc.reset_query(q)
+    enc.train()
+    a, b = enc.step_query(), enc.step_query()
+    assert q.calls == 2 and not torch.equal(a, b)          # two masks
+    enc.eval()
+    a, b = enc.step_query(), enc.step_query()
+    assert q.calls == 3 and a is b                         # dropout inactive: shared again
+    q0 = QNet(0.0)
+    enc.reset_query(q0)
+    enc.train()
+    a, b = enc.step_query(), enc.step_query()
+    assert q0.calls == 1 and a is b

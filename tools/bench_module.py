@@ -28,3 +28,52 @@ for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfl
         for i in range(40): net.forward_bags(bags2)
         torch.cuda.synchronize(); t3 = (time.perf_counter() - t0) / 40 / 64 * 1e6
     print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag")
+
+
+# ---- the handler's evaluation loop (runner/vlsa_handler.py:315-345) over a ResidentBags dataset: net(X) once per bag, look-ahead
+# windows of <= 64 bags behind it (vlsa_amd/vlsa.py::_lookahead).  Row 1: the model calls alone (as the rows above); row 2: the
+# whole loop as the handler writes it (DataLoader(batch_size=1) + default_collate + .cuda() + softmax + two .cpu() per bag).
+from vlsa_amd.ingest import ResidentBags
+
+
+class _Items(torch.utils.data.Dataset):
+    def __init__(self, n_items, n, dt):
+        g = torch.Generator().manual_seed(5)
+        self.x = [torch.randn(n, 512, generator=g).to(dt) for _ in range(8)]
+        self.n_items = n_items
+
+    def __len__(self):
+        return self.n_items
+
+    def __getitem__(self, i):
+        return torch.Tensor([i]).to(torch.int), (self.x[i % 8].float(), torch.Tensor([0])), torch.Tensor([1.0, 1.0])
+
+
+for n, dt, n_items in ((50000, torch.bfloat16, 256), (2798, torch.bfloat16, 512), (10000, torch.float32, 256)):
+    torch.cuda.empty_cache()
+    rb = ResidentBags(_Items(n_items, n, dt), dtype=dt)
+    loader = torch.utils.data.DataLoader(rb, batch_size=1, shuffle=False, num_workers=0)
+    items = [torch.utils.data.default_collate([rb[i]])[1][0] for i in range(n_items)]       # uploads; tagged [1, N, 512] views
+    res = {}
+    for la in (64, 0):
+        net.lookahead_bags = la
+        with torch.no_grad():
+            for _ in range(2):
+                for X in items: net(X)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                for X in items: net(X)
+            torch.cuda.synchronize(); t_calls = (time.perf_counter() - t0) / 3 / n_items * 1e6
+            t0 = time.perf_counter()
+            for _ in range(2):
+                out = []
+                for data_idx, data_x, data_y in loader:
+                    X = data_x[0].cuda()
+                    raw, *_ = net(X)
+                    pred = torch.softmax(raw, dim=-1)
+                    out.append(raw.detach().cpu()); out.append(pred.detach().cpu())
+            t_loop = (time.perf_counter() - t0) / 2 / n_items * 1e6
+        res[la] = (t_calls, t_loop)
+    print(f"N={n:6d} {str(dt)[6:]:9s}: handler eval loop over {n_items} resident items: net(X) {res[64][0]:6.2f} us/bag with look-ahead "
+          f"({n / res[64][0] / 1e3:.2f} G patches/s), {res[0][0]:6.2f} without;   whole loop incl. DataLoader + softmax + 2 x .cpu(): "
+          f"{res[64][1]:6.1f} us/bag with, {res[0][1]:6.1f} without")

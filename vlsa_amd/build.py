@@ -22,7 +22,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-OBJ_DIR = os.path.join(LIB_DIR, "obj")
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+STAMP = os.path.join(LIB_DIR, "flags.stamp")
+
+
+def _flags():
+    """compile flags; VLSA_EXTRA_HIPCC_FLAGS adds debug switches (e.g. -DVLSA_TT_DEBUG: cycle stamps in the text GEMM, whose
+    results are "wrong: timing only")"""
+    return BASE_FLAGS + os.environ.get("VLSA_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def _flag_tag() -> str:
+    import hashlib
+    return hashlib.sha1(" ".join(_flags()).encode()).hexdigest()[:10]
+
+
+def _obj_dir() -> str:
+    """objects of a non-default flag set live in their own directory: a debug build never leaves objects a later normal build
+    would link (and the other way round)"""
+    extra = os.environ.get("VLSA_EXTRA_HIPCC_FLAGS", "").split()
+    return os.path.join(LIB_DIR, "obj" if not extra else "obj-" + _flag_tag())
 
 
 def _newer(target: str, deps) -> bool:
@@ -34,7 +53,12 @@ def _newer(target: str, deps) -> bool:
 
 def _stale() -> bool:
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return _newer(LIB_PATH, deps)
+    if _newer(LIB_PATH, deps):
+        return True
+    try:        # the library on disk was linked from another flag set (debug build <-> normal build)
+        return open(STAMP).read().strip() != _flag_tag()
+    except OSError:
+        return True
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
@@ -42,11 +66,11 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     library.  Returns its path."""
     if not force and not _stale():
         return LIB_PATH
+    OBJ_DIR = _obj_dir()
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     common = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-    flags += os.environ.get("VLSA_EXTRA_HIPCC_FLAGS", "").split()     # debug builds (e.g. -DVLSA_TT_DEBUG: cycle stamps in the text GEMM)
+    flags = _flags()
     jobs = []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
@@ -72,6 +96,8 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed linking libvlsa_hip.so")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP, "w") as f:
+        f.write(_flag_tag() + "\n")
     return LIB_PATH
 
 

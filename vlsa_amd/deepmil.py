@@ -68,14 +68,14 @@ class FeatMIL(nn.Module):
 
 
 class VLFAN(VF.nat.TransientCaches, nn.Module):
-    _transient = {"_step_query": None, "_enc_plans": None, "_fused_scores": None, "_coattn_scale": None}
-
     """Language-guided visual feature aggregation network (model/deepmil.py:74-215).
 
     P query vectors (text prototypes through a query network, or an ``nn.Parameter``) cross-attend over the N
     patches with cosine scores x 100, softmax over the patches; the P aggregated rows are pooled over the queries
     and passed through the visual adapter.  The cross attention runs in the HIP streaming kernels.
     """
+
+    _transient = {"_step_query": None, "_enc_plans": None, "_fused_scores": None, "_coattn_scale": None}
 
     def __init__(self, dim_in=1024, dim_hid=256, use_feat_proj=True, drop_rate=0.25, query="Parameter", num_query=10,
                  gated_query=False, query_pooling="mean", pred_head="default", dim_reduction=4, keep_ratio=0.8, **kwargs):
@@ -129,7 +129,10 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
         """``get_query()`` for the per-bag training path: when the queries come from a module (the text PromptAdapter), its
         output -- WITH its autograd graph -- is shared by all bags that see the same parameter versions, train / eval flag and
         grad mode (the reference's step evaluates the adapter once per bag: runner/vlsa_handler.py:267-269; same values, 32 x
-        the launches and autograd nodes).  A backward pass through the cached tensor frees that graph: the next call rebuilds."""
+        the launches and autograd nodes).  A backward pass through the cached tensor frees that graph: the next call rebuilds.
+        NOT shared when the query network is stochastic: an active ``nn.Dropout`` (the 'FC' PromptAdapter has Dropout(0.25),
+        model/prompt_learners/prompt_adapter.py:95-104) draws a fresh mask per bag in the reference, so every call evaluates
+        the network again -- a cached output would give all bags of a step (a frozen adapter: of the whole run) one mask."""
         Qs = self.Q
         if not isinstance(Qs, nn.Module):
             return self.get_query()
@@ -137,6 +140,9 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
         stack = [Qs]
         while stack:
             m = stack.pop()
+            if m.training and isinstance(m, nn.modules.dropout._DropoutNd) and m.p > 0:
+                self._step_query = None
+                return self.get_query()
             key.append((id(m), m.training))
             for t in m._parameters.values():
                 if t is not None:
@@ -314,10 +320,10 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
 
 
 class DeepMIL(VF.nat.TransientCaches, nn.Module):
-    _transient = {"_fused_scores": None}
-
     """ABMIL-style encoder (model/deepmil.py:222-292): optional Feat_Projecter, mean / max / (gated-)attention pooling
     over the N patches, Adapter head mixed with ``keep_ratio`` or a Linear head."""
+
+    _transient = {"_fused_scores": None}
 
     def __init__(self, dim_in=1024, dim_hid=256, num_cls=2, use_feat_proj=True, drop_rate=0.25, pooling="attention",
                  pred_head="default", dim_reduction=4, keep_ratio=0.8, **kwargs):

@@ -241,6 +241,7 @@ class _HeadTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, W, b, T, logit_scale, tickets):
+        ctx.set_materialize_grads(False)      # the handler uses the logits only: no zero-filled g_vhat / g_That per backward
         lib, s = nat.load(), _stream()
         rows = _f32c(rows)
         B, P, D = rows.shape
@@ -346,6 +347,22 @@ class SlideTrainPlan:
         self.grad_floats = o
         self.flat_floats = self.goff["dls"] + 1
         self._flat, self._flat_src, self._zero_b = None, None, None
+        self._conv = {}
+
+    def f32c(self, slot: str, t: torch.Tensor) -> torch.Tensor:
+        """fp32-contiguous view of a step parameter, converted ONCE per (tensor object, in-place version, grad mode): a fresh
+        ``.float().contiguous()`` per bag would defeat the identity check of ``step_params`` (one cat + one preparation per bag
+        instead of per step).  The conversion is differentiable; a backward pass through it frees its graph, so the memo goes
+        with it (as for the flat tensor)."""
+        if t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        c = self._conv.get(slot)
+        if c is None or c[0] is not t or c[1] != t._version or c[3] != torch.is_grad_enabled():
+            conv = t.float().contiguous()
+            if conv.requires_grad and conv.grad_fn is not None:
+                conv.register_hook(lambda *_: self._conv.pop(slot, None))
+            c = self._conv[slot] = (t, t._version, conv, torch.is_grad_enabled())
+        return c[2]
 
     def step_params(self, Q, W, b, T, logit_scale) -> torch.Tensor:
         """Q | W | b | T | logit_scale as ONE fp32 tensor (a ``torch.cat``: differentiable), shared -- with its graph -- by every bag
@@ -403,6 +420,7 @@ class _SlideTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X2, flat, plan):
+        ctx.set_materialize_grads(False)      # unused outputs (v^, T^) reach backward as None, not as zero-filled tensors
         lib, s, c, off = plan.lib, _stream(), plan._c, plan.off
         N = X2.shape[0]
         dev = X2.device

@@ -205,6 +205,53 @@ class DeviceBagArena:
         return len(self.layout)
 
 
+class ResidentBagView(torch.Tensor):
+    """A resident bag's rows as the handler's loader sees them: an ordinary device tensor that additionally KNOWS which item of
+    which ``ResidentBags`` it is (``_vlsa_src = (resident_bags, index)``).
+
+    Why a subclass: the reference's loaders collate with ``default_collate`` (runner/base_handler.py:233), i.e. ``torch.stack([feats])``
+    -- for a bag that already sits in HBM that is a 51 MB device copy per 50k-patch bag, after which nothing links the tensor to
+    the dataset item any more.  Here ``torch.stack`` of ONE such tensor along dim 0 returns the view ``feats[None]`` (still tagged),
+    and ``.cuda()`` / ``.to(its own device)`` return it unchanged (runner/vlsa_handler.py:205,324), so ``net(X)`` receives the resident
+    rows themselves plus their identity -- which is what lets an evaluation loop that calls the model once per bag be served from
+    ONE batched launch over the next bags of the dataset (``VLSA`` look-ahead).  Every other operation yields a
+    plain, untagged ``torch.Tensor``: the tag can never end up on data that is not bit for bit the resident bag."""
+
+    _vlsa_src = None
+
+    @staticmethod
+    def wrap(t: torch.Tensor, src) -> "ResidentBagView":
+        v = t.as_subclass(ResidentBagView)
+        v._vlsa_src = src
+        return v
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        with torch._C.DisableTorchFunctionSubclass():
+            if func is torch.stack and not kwargs.get("out"):
+                seq = args[0] if args else kwargs.get("tensors")
+                dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+                if isinstance(seq, (list, tuple)) and len(seq) == 1 and dim == 0 and isinstance(seq[0], ResidentBagView) and seq[0].dim() == 2:
+                    return ResidentBagView.wrap(seq[0].as_subclass(torch.Tensor)[None], seq[0]._vlsa_src)
+            elif func in (torch.Tensor.cuda, torch.Tensor.to) and isinstance(args[0], ResidentBagView):
+                out = func(*args, **kwargs)
+                me = args[0]
+                if out.data_ptr() == me.data_ptr() and out.dtype == me.dtype and out.shape == me.shape and out.stride() == me.stride():
+                    return me                        # a no-op move: the very same rows
+                return out.as_subclass(torch.Tensor)
+            out = func(*args, **kwargs)
+        return _untag(out)
+
+
+def _untag(out):
+    if isinstance(out, ResidentBagView):
+        return out.as_subclass(torch.Tensor)
+    if isinstance(out, (list, tuple)):
+        return type(out)(_untag(o) for o in out)
+    return out
+
+
 class ResidentBags(torch.utils.data.Dataset):
     """Drop-in wrapper for the reference's bag datasets (``WSIPatchSurv`` in 'patch' mode, ``FewShot_WSIPatchSurv``:
     dataset/PatchWSI.py:143-215): items are ``(index, (feats [N, 512], extra...), label)``.  The first time an item is asked for it is
@@ -215,12 +262,19 @@ class ResidentBags(torch.utils.data.Dataset):
     (``vlsa_amd.model_utils.patch_reference(resident_bags=True)`` does) and run the loaders with ``num_workers: 0`` -- inside a
     DataLoader worker process (no device there) items pass through unchanged.
 
-    ``dtype=torch.float32`` keeps the features bit for bit (2 KB per patch).  Segments of ``segment_rows`` rows are allocated as
-    the data arrives (a bag larger than a segment gets its own)."""
+    ``dtype=torch.float32`` keeps the features bit for bit (2 KB per patch).  Segments are allocated as the data arrives and grow
+    geometrically -- the first holds ``first_segment_rows`` rows (128 MiB as bf16), each further one twice the last up to
+    ``segment_rows`` -- so that a small validation split does not pin gigabytes (a bag larger than a segment gets its own)."""
 
-    def __init__(self, dataset, device="cuda", dtype: torch.dtype = torch.bfloat16, segment_rows: int = 1 << 21, D: int = 512):
+    def __init__(self, dataset, device="cuda", dtype: torch.dtype = torch.bfloat16, segment_rows: int = 1 << 21, D: int = 512,
+                 first_segment_rows: int = 1 << 17, tag_views: bool = True):
+        """tag_views: resident features come back as ``ResidentBagView`` (see there): no collate copy, and the model can serve a
+        bag-by-bag evaluation loop from batched launches."""
         self.dataset = dataset
+        self._tag_views = bool(tag_views)
         self._device, self._dtype, self._segment_rows, self._D = torch.device(device), dtype, int(segment_rows), int(D)
+        self._next_rows = min(int(first_segment_rows), int(segment_rows))
+        self._warned_worker = False
         self._segments: List[DeviceBagArena] = []
         self._where: Dict[int, DeviceBagArena] = {}
         self._rest: Dict[int, tuple] = {}
@@ -230,7 +284,7 @@ class ResidentBags(torch.utils.data.Dataset):
         return len(self.dataset)
 
     def __getattr__(self, name):          # uid, get_meta_data, summary, ...: whatever the handler asks the dataset for
-        if name in ("dataset", "_segments", "_where", "_rest"):
+        if name in ("dataset", "_segments", "_where", "_rest", "_next_rows", "_warned_worker", "_tag_views"):
             raise AttributeError(name)
         return getattr(self.dataset, name)
 
@@ -238,7 +292,8 @@ class ResidentBags(torch.utils.data.Dataset):
         need = -(-n_rows // ROW_ALIGN) * ROW_ALIGN
         if self._segments and self._segments[-1].layout.rows_free() >= need:
             return self._segments[-1]
-        seg = DeviceBagArena(max(self._segment_rows, need), self._device, D=self._D, dtype=self._dtype)
+        seg = DeviceBagArena(max(self._next_rows, need), self._device, D=self._D, dtype=self._dtype)
+        self._next_rows = min(2 * max(self._next_rows, need), self._segment_rows)
         self._segments.append(seg)
         return seg
 
@@ -248,7 +303,12 @@ class ResidentBags(torch.utils.data.Dataset):
     def __getitem__(self, i):
         i = int(i)
         if torch.utils.data.get_worker_info() is not None:
-            return self.dataset[i]        # a loader worker process: no device here
+            if not self._warned_worker:   # a loader worker process: no device here
+                self._warned_worker = True
+                import warnings
+                warnings.warn("vlsa_amd.ResidentBags is being read from a DataLoader worker process: bags pass through unchanged "
+                              "(disk + PCIe every epoch).  Set `num_workers: 0` to keep them resident in HBM.", RuntimeWarning)
+            return self.dataset[i]
         if i not in self._rest:
             item = self.dataset[i]
             self.reads += 1
@@ -265,4 +325,13 @@ class ResidentBags(torch.utils.data.Dataset):
             seg.add(i, feats)
             self._where[i], self._rest[i] = seg, (idx, tuple(data_x[1:]), label)
         idx, rest, label = self._rest[i]
-        return idx, (self._where[i].bag(i), *rest), label
+        feats = self._where[i].bag(i)
+        if self._tag_views:
+            feats = ResidentBagView.wrap(feats, (self, i))
+        return idx, (feats, *rest), label
+
+    # -- what the model's look-ahead asks (vlsa_amd/vlsa.py) ----------------------------------------------------------------
+    def resident_view(self, i: int):
+        """plain [N, 512] view of item i if it is resident, else None (never reads the wrapped dataset)"""
+        seg = self._where.get(int(i))
+        return None if seg is None else seg.bag(int(i))

@@ -73,7 +73,10 @@ def patch_reference(resident_bags: bool = False, **resident_kw):
       model/utils_vl.py:129-138 and ``utils/model_inference.py`` see the same classes.
     * ``resident_bags=True``: ``dataset.utils.prepare_surv_dataset`` (and the name ``runner.sa_handler`` imported from it, if already
       loaded) wraps what it returns in ``vlsa_amd.ingest.ResidentBags`` -- every bag is read and uploaded ONCE, later epochs find it in
-      HBM (bf16; ``dtype=torch.float32`` in ``resident_kw`` keeps fp32).  Needs ``num_workers: 0`` in the run's config.
+      HBM.  Stored as **fp32** here, bit for bit what dataset/PatchWSI.py:214 hands the handler (an "unmodified" reference run must
+      not be fed rounded features silently); ``dtype=torch.bfloat16`` in ``resident_kw`` halves the footprint and the streaming
+      time at ~1e-2 on the logits.  Needs ``num_workers: 0`` in the run's config (a worker process has no device: items pass
+      through unchanged there, with a one-time warning).
     Returns the patched reference modules (for un-patching in tests)."""
     import model.deepmil as ref_mil
     import model.utils as ref_utils
@@ -92,6 +95,9 @@ def patch_reference(resident_bags: bool = False, **resident_kw):
         from .ingest import ResidentBags
         original = ref_ds.prepare_surv_dataset
         if not getattr(original, "_vlsa_resident", False):
+            import torch
+            resident_kw.setdefault("dtype", torch.float32)
+
             def prepare_surv_dataset(*args, **kwargs):
                 return ResidentBags(original(*args, **kwargs), **resident_kw)
             prepare_surv_dataset._vlsa_resident = True

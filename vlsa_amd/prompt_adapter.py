@@ -41,6 +41,18 @@ def _runs_on_host(prompt_encoder) -> bool:
     return tensors is not None and not tensors()[0].is_cuda
 
 
+class _DeferredTowerPass:
+    """A tower pass over tokenised sentences that has to wait for the device (the HIP tower has no CPU route).  A plain
+    object instead of a closure: a model with pending passes can be pickled, and ``copy.deepcopy`` of the model binds the
+    copy's pass to the copy's encoder (shared through the deepcopy memo)."""
+
+    def __init__(self, prompt_encoder, token_ids, mean_row):
+        self.prompt_encoder, self.token_ids, self.mean_row = prompt_encoder, token_ids, mean_row
+
+    def __call__(self):
+        return PromptAdapter._tower_pass(self.prompt_encoder, self.token_ids, self.mean_row)
+
+
 class PromptAdapter(nn.Module):
     def __init__(self, prompt_encoder=None, tokenizer=None, method: str = "default", load_path: Optional[str] = None,
                  load_idx: Union[int, str] = 0, load_negative_prompts: bool = False, load_negative_idx: str = "prompt_normal_tissue",
@@ -53,6 +65,7 @@ class PromptAdapter(nn.Module):
         super().__init__()
         assert method in ["default", "FC", "Adapter", "TaskRes"]
         self.method = method
+        self.num_prompts = num_prompts
         self.__dict__["_pending"] = {}          # buffer name -> zero-argument callable producing it (deferred tower pass)
         dim = None
         if pretrained_prompt_features is None:
@@ -122,7 +135,7 @@ class PromptAdapter(nn.Module):
     def _encode_or_defer(self, name, prompt_encoder, tokenizer, texts, mean_row):
         token_ids = tokenizer(texts, return_raw_tokens=False, return_num_tokens=False)      # [n, ctx_length]
         if _runs_on_host(prompt_encoder):
-            self._pending[name] = lambda: self._tower_pass(prompt_encoder, token_ids, mean_row)
+            self._pending[name] = _DeferredTowerPass(prompt_encoder, token_ids, mean_row)
             return None
         return self._tower_pass(prompt_encoder, token_ids, mean_row)
 
@@ -130,9 +143,18 @@ class PromptAdapter(nn.Module):
         """Run the deferred tower passes (the encoder has been moved to the device by now)."""
         for name in list(self._pending):
             feats = self._pending[name]().detach().clone()
+            if name == "prompt_features":      # the constructor's check for ready-made features (prompt_adapter.py:66), deferred too
+                assert len(feats) == self.num_prompts, f"Expected {self.num_prompts} initial texts, but got {len(feats)}."
             like = next((p for p in self.parameters()), None)
             self._buffers[name] = feats if like is None else feats.to(like.device)
             del self._pending[name]
+
+    def pending_on_device(self) -> bool:
+        """True when deferred tower passes exist and could run now (their encoder has reached the GPU)."""
+        if not self._pending:
+            return False
+        return not any(_runs_on_host(getattr(f, "prompt_encoder", None)) for f in self._pending.values()
+                       if getattr(f, "prompt_encoder", None) is not None)
 
     def _feature(self, name):
         if self._pending:

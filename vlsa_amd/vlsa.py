@@ -38,6 +38,19 @@ def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
     return cls(**image_encoder_cfg)
 
 
+class _DeferredCoopFeatures:
+    """Text features of a CoOp-pretrained, frozen prompt learner (model/vlsa.py:129-137) -- a tower pass that waits for the device.
+    A plain object (picklable; deep copies of the model stay bound to their own encoder), see prompt_adapter._DeferredTowerPass."""
+
+    def __init__(self, prompt_encoder, learner):
+        self.prompt_encoder, self.learner = prompt_encoder, learner
+
+    def __call__(self):
+        dev = self.prompt_encoder.token_embedding.weight.device
+        with torch.no_grad():
+            return self.prompt_encoder(prompts_embedding=self.learner.to(dev)(), prompts_pseudo_tokens=self.learner.pseudo_sentence_tokens)
+
+
 class VLSA(VF.nat.TransientCaches, nn.Module):
     """``VLSA(text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None, vlsa_api=...,
     path_clip_model=...)`` -- the reference's constructor (model/vlsa.py:22-105), i.e. what ``load_model('VLSA', **arch_cfg)``
@@ -46,7 +59,11 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
 
     _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
                   "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
-                  "_head_tickets": lambda: VF.HeadTickets()}
+                  "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None}
+
+    #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
+    #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
+    lookahead_bags = 64
 
     def __init__(self, text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None,
                  info_prefix="VLSA-UNI", **kwargs):
@@ -177,12 +194,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             coop_cfg["pretrained"] = True
             learner, fixed = self._build_prompt_learner(coop_cfg, {"ckpt": coop_cfg["ckpt"]})
             assert fixed, "Found empty `pretrained_text_features`."
-            encoder = self.prompt_encoder
-
-            def features():      # evaluated by the adapter at first use (the tower has to be on the device)
-                dev = encoder.token_embedding.weight.device
-                with torch.no_grad():
-                    return encoder(prompts_embedding=learner.to(dev)(), prompts_pseudo_tokens=learner.pseudo_sentence_tokens)
+            features = _DeferredCoopFeatures(self.prompt_encoder, learner)     # evaluated once the tower is on the device
         cfg.update(tokenizer=self.text_tokenizer, num_prompts=cfg["num_ranks"], pretrained_prompt_features=features)
         return load_prompt_adapter(self.prompt_encoder, cfg)
 
@@ -241,13 +253,36 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             self._plans.clear()
             self._train_plans.clear()
             self._prepared_text = self._prepared_query = None
-        return super()._apply(fn, *args, **kwargs)
+            self._la = self._la_lists = None
+        out = super()._apply(fn, *args, **kwargs)
+        self._materialise_frozen_prototypes()
+        return out
+
+    def _materialise_frozen_prototypes(self):
+        """The reference computes its frozen text prototypes in the constructors, from the PRETRAINED tower (model/vlsa.py:57-60,
+        prompt_adapter.py:60-79).  Here those tower passes wait for the device -- and run as soon as the model arrives there
+        (this is called at the end of ``_apply``, i.e. of ``.cuda()`` / ``.to(device)``), before a later ``load_state_dict`` could
+        put trained tower weights under them."""
+        if "_plans" not in self.__dict__:
+            return
+        tower = getattr(self, "prompt_encoder", None)
+        tensors = getattr(tower, "_tower_tensors", None)
+        if tensors is None or not tensors()[0].is_cuda:
+            return
+        from .prompt_adapter import PromptAdapter
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, PromptAdapter) and m.pending_on_device():
+                    m._materialise()
+            if self._buffers.get("pretrained_text_features", 0) is None and getattr(self, "prompt_learner", None) is not None:
+                self._fixed_text_features()
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         if "_plans" in self.__dict__:
             self._drop_text_cache()
             self._tower_lists = None
+            self._la = self._la_lists = None
         return out
 
     def compute_text_features_with_coop(self, prompt_learner):
@@ -410,10 +445,6 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if W is not None and (W.dtype != torch.float32 or not W.is_contiguous() or tuple(W.shape) != (D, D) or not W.is_cuda
                               or (b is not None and (b.dtype != torch.float32 or not b.is_contiguous()))):
             return None
-        if Q.dtype != torch.float32 or not Q.is_contiguous():
-            Q = Q.float().contiguous()
-        if T.dtype != torch.float32 or not T.is_contiguous():
-            T = T.float().contiguous()
         K = T.shape[0]
         scale = enc.coattn_scale()
         key = (D, P, K, X2.device, enc.gated_query, W is None, scale)
@@ -422,7 +453,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             if len(self._train_plans) > 8:
                 self._train_plans.clear()
             plan = self._train_plans[key] = VF.SlideTrainPlan(D, P, K, X2.device, enc.gated_query, W is None, scale)
-        return VF.slide_train(X2, Q, W, b, T, ls, plan)
+        # fp32-contiguous Q / T: converted once per step, not per bag (the flat parameter tensor is keyed on tensor identity)
+        return VF.slide_train(X2, plan.f32c("Q", Q), W, b, plan.f32c("T", T), ls, plan)
 
     def forward(self, X):
         """X: [1, N, D] bag -> (logits [1, K], image_features (unit-norm), text_features (unit-norm)).
@@ -430,12 +462,20 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         ``DistributedDataParallel`` with bags as the data-parallel unit -- see the batched path too)."""
         if isinstance(X, (list, tuple)):
             return self.forward_bags(list(X))
+        src = getattr(X, "_vlsa_src", None)          # a ResidentBags item as the handler's loader delivers it (vlsa_amd/ingest.py)
+        if src is not None:
+            X = X.as_subclass(torch.Tensor)
         text_features = self._text_features()
         if not self._needs_grad(text_features):
+            if src is not None and not self.training and self.lookahead_bags > 1:
+                ahead = self._lookahead(src, X, text_features)
+                if ahead is not None:
+                    return ahead
             fused = self._fused_vlfan(X, text_features)
             if fused is not None:
                 return fused
         else:
+            self._la = None                      # a differentiable forward: parameters are about to move
             trained = self._slide_train(X, text_features)
             if trained is not None:
                 return trained
@@ -464,6 +504,85 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if logits.shape[0] > 1:
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
         return logits, image_features, text_features
+
+    # -- look-ahead: the reference handler's bag-by-bag evaluation loop at batched speed ---------------------------------------
+    def _eval_state(self, text_features):
+        """Everything an inference result depends on besides the bag: the text-feature tensor (object + in-place version: the text
+        side's own cache hands out the same object as long as ITS key -- every provider tensor's version and flags -- holds) and
+        every parameter / buffer (object + version) and train / eval flag of the MIL encoder (query network included), the logit
+        scale, the co-attention scale.  The module / tensor lists are kept between calls and rebuilt by an exact walk whenever a
+        window is computed, on ``_apply`` and on ``load_state_dict``."""
+        enc = self.mil_encoder
+        ll = self._la_lists
+        if ll is None or ll[0] is not enc:
+            sub, tensors = self._walk_module(enc)
+            ll = self._la_lists = (enc, sub, tensors)
+        cs = getattr(enc, "coattn_logit_scale", None)
+        return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version,
+                self.logit_scale, self.logit_scale._version, cs, -1 if cs is None else cs._version)
+
+    @staticmethod
+    def _same_state(a, b):
+        return (a[1] == b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4] and a[5] is b[5] and a[6] == b[6] and a[7] is b[7]
+                and a[8] == b[8] and len(a[0]) == len(b[0]) and all(x is y for x, y in zip(a[0], b[0])))
+
+    def _lookahead(self, src, X, text_features):
+        """``net(X)`` in eval mode under ``no_grad`` for item i of a ``ResidentBags`` dataset (the handler's ``test_model`` loop,
+        runner/vlsa_handler.py:322-330, calls the model once per bag): the first call of a window runs ``forward_bags`` over items
+        i, i+1, ... (as many as are resident, <= ``lookahead_bags``: the loaders of base_handler.py:246-259 do not shuffle) -- ONE
+        persistent launch instead of one latency-bound launch chain per bag -- and the following calls return their rows of that
+        result.  A row is only ever handed out for the exact item it was computed from (the tag travels on the tensor object:
+        ``ResidentBagView``) and while the model state it was computed under (``_eval_state``) still holds; any differentiable
+        forward, ``_apply`` or ``load_state_dict`` drops the window.  An access pattern that does not use the window shrinks it
+        (random access degenerates to the per-bag route)."""
+        rb, i = src
+        state = self._eval_state(text_features)
+        la = self._la
+        same_rb = la is not None and la["rb"] is rb
+        if same_rb and la["rows"] and self._same_state(la["state"], state):
+            row = la["rows"].get(i)
+            if row is not None:
+                la["used"] += 1
+                la["last"] = i
+                return self._lookahead_row(row, X)
+        width, seq = int(self.lookahead_bags), 0
+        if same_rb:
+            width, seq = la["width"], la["seq"]
+            if la["rows"]:                            # a miss behind a window: was that window used?
+                if la["used"] >= len(la["rows"]):
+                    width = min(int(self.lookahead_bags), 2 * width)
+                elif la["used"] <= 1:
+                    width = max(1, width // 4)
+            seq = seq + 1 if i == la["last"] + 1 else 0
+            if width <= 1 and seq >= 3:               # the per-bag route, but the accesses have become sequential again
+                width = min(int(self.lookahead_bags), 8)
+        views, idx = [], []
+        if width > 1:
+            for j in range(i, min(len(rb), i + width)):
+                v = rb.resident_view(j)
+                if v is None:
+                    break
+                views.append(v)
+                idx.append(j)
+        self._la = la = {"rb": rb, "state": None, "rows": {}, "used": 0, "width": width, "seq": seq, "last": i}
+        if len(views) < 2 or views[0].data_ptr() != X.data_ptr() or tuple(views[0].shape) != tuple(X.shape[-2:]):
+            return None                               # nothing to batch (yet): the per-bag route
+        self._la_lists = None                         # the kept lists are re-walked exactly before a window is computed
+        state = self._eval_state(text_features)
+        with torch.no_grad():
+            out = self._forward_bags_fused(views, text_features)
+        logits, feats, That = out[0], out[1], out[2]
+        per_bag = isinstance(feats, torch.Tensor) and feats.dim() == 2 and feats.shape[0] == len(idx)
+        for b, j in enumerate(idx):
+            la["rows"][j] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag)
+        la["state"], la["used"] = state, 1
+        return self._lookahead_row(la["rows"][i], X)
+
+    def _lookahead_row(self, row, X):
+        logits, f, That, has_feats = row
+        if not has_feats:       # identity FeatMIL: the per-patch unit features of THIS bag, as the per-bag route returns them
+            f = VF.normalize_many(VF._bag2d(X)) if getattr(self, "return_patch_features", True) else None
+        return logits, f, That
 
     def forward_bags(self, bags, ret_with_attn=False):
         """A list of independent bags in one call (the reference loops bag by bag: eval runner/vlsa_handler.py:315-345,
