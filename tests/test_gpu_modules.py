@@ -159,6 +159,15 @@ def test_vlsa_deepmil_forward_backward(case):
             assert np.abs(v.cpu().numpy().ravel() - fx["v"].ravel()).max() < 1e-4
     assert np.abs(logits.cpu().numpy() - fx["logits"]).max() < TOL
     assert np.abs(img.cpu().numpy() - fx["image_features"]).max() < 1e-5
+    if "attn" in fx:
+        # utils/model_inference.py:146-178 through the drop-in DeepMIL(ret_with_attn=True): RAW scores out of the encoder, the
+        # caller's softmax over the patches, predicted incidence = softmax of the bag logits
+        from vlsa_amd.inference import calc_abmil_text_img_similarity
+        attn_w, probs = calc_abmil_text_img_similarity(model, X[None])
+        raw = torch.from_numpy(np.asarray(fx["attn"])).reshape(1, -1)
+        assert not attn_w.is_cuda and tuple(attn_w.shape) == (1, N) and abs(float(attn_w.sum()) - 1.0) < 1e-5
+        assert (attn_w - torch.softmax(raw, dim=-1)).abs().max().item() < 1e-5
+        assert (probs - torch.softmax(torch.from_numpy(np.asarray(fx["logits"])), dim=-1)).abs().max().item() < 1e-5
     logits2, _, _ = model(Xd)
     assert np.abs(logits2.detach().cpu().numpy() - fx["logits"]).max() < TOL
     (logits2 * H.t(fx["G"]).cuda()).sum().backward()

@@ -195,6 +195,25 @@ def check(code: int, what: str):
         raise VlsaNativeError(f"{what} failed: {msg} ({code})")
 
 
+# ---- library-GEMM detours: an N-sized tensor (a bag's rows) that takes a torch route instead of a HIP kernel of this package ----
+TORCH_ROUTE_ROWS = 1024          # P-sized inputs (<= 16 query rows) take torch ops by design; a bag is thousands of rows
+torch_route_counts: dict = {}    # site -> number of calls with >= TORCH_ROUTE_ROWS rows (tests and benches read this)
+
+
+def note_torch_route(site: str, rows: int, why: str) -> None:
+    """Count -- and warn ONCE per site about -- a call that sends ``rows`` patch rows through torch library ops (rocBLAS GEMMs,
+    [N, hidden] activations in HBM) because no fused kernel covers the configuration.  Correct, but several times slower than
+    the HIP route and invisible otherwise."""
+    if rows < TORCH_ROUTE_ROWS:
+        return
+    n = torch_route_counts.get(site, 0)
+    torch_route_counts[site] = n + 1
+    if n == 0:
+        import warnings
+        warnings.warn(f"vlsa_amd: {site}: {rows} patch rows go through torch library ops, not a fused HIP kernel ({why}); "
+                      "further calls are counted in vlsa_amd._native.torch_route_counts", RuntimeWarning, stacklevel=3)
+
+
 class TransientCaches:
     """nn.Module mixin.  The attributes named in ``_transient`` hold native handles (ctypes structures with device pointers), device
     scratch or cached results tied to them; none of it is state.  ``copy.deepcopy`` / ``pickle`` / ``torch.save(module)`` go

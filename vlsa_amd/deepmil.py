@@ -387,6 +387,9 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
             if need_grad or drop_p > 0:
                 return VF.attn_scores_autograd(X2, self._fused_scores, *w, drop_p=drop_p)
             return self._fused_scores(X2, *w)
+        VF.nat.note_torch_route("DeepMIL attention scores", X2.shape[0],
+                                f"widths {lin_a.in_features} -> {lin_a.out_features}, bag gradient {bag_grad}: the fused score kernel covers 512 -> 256 "
+                                "hidden units, bags without a gradient of their own and equal dropout rates in both branches")
         Xf = X2 if X2.dtype == torch.float32 else X2.float()
         if isinstance(sg, Attention_Pooling):
             lin1, lin2 = sg.attention[0], sg.attention[2]

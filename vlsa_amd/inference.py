@@ -1,4 +1,4 @@
-"""Interpretation utilities over a trained VLSA model -- counterparts of utils/model_inference.py:23-144.
+"""Interpretation utilities over a trained VLSA model -- counterparts of utils/model_inference.py:11-178.
 
 ``calc_text_img_similarity`` decouples the prediction over the P text prototypes.  The reference re-encodes all N
 patches through the visual adapter (an [N,512]x[512,512] GEMM) and contracts with the attention weights
@@ -97,3 +97,60 @@ def calc_text_img_similarity(model, X_feats, axis_softmax="V", verbose=False):
     cottn_h = cottn.cpu()
     A_h = cottn_h.clone() if A is cottn else A.cpu()              # axis 'V': the same matrix -- one device-to-host copy, two tensors
     return None, A_h, cottn_h, probs.cpu(), probs_2.cpu(), decoupled_imp.cpu(), shap
+
+
+@torch.no_grad()
+def calc_abmil_text_img_similarity(model, X_feats, verbose=False, **kws):
+    """utils/model_inference.py:146-178 for a VLSA model whose MIL encoder is the ABMIL-style ``DeepMIL``: ->
+    (attention weights over the patches [1, N] (softmax of the encoder's RAW scores: ``ret_with_attn`` hands those out,
+    model/layers.py:118-122,149-153), predicted incidence [1, K]), both on the host.  Scores, pooling and head run in the HIP
+    kernels of ``DeepMIL.forward``."""
+    model.eval()
+    X = X_feats if X_feats.dim() == 3 else X_feats[None]
+    assert X.shape[0] == 1
+    X = X.to(next(model.parameters()).device)
+    scale = float(model.get_logit_scale())
+    That = F.normalize(model.forward_text_only(), dim=-1)
+    if verbose:
+        print("pred_logit_scale:", scale)
+    feature, raw_scores = model.mil_encoder(X, ret_with_attn=True)
+    attn = F.softmax(raw_scores, dim=-1)
+    unit = feature / feature.norm(dim=-1)
+    probs = F.softmax(scale * unit @ That.t(), dim=-1)
+    return attn.cpu(), probs.cpu()
+
+
+def _read_run_cfg(run_path: str) -> dict:
+    """config.yaml of a run directory, else its print_config.txt ('key --> value' lines); utils/func.py:219-241"""
+    import ast
+    import os
+    import yaml
+    path = os.path.join(run_path, "config.yaml")
+    if os.path.exists(path):
+        with open(path) as f:
+            return yaml.load(f, Loader=yaml.FullLoader)
+    path = os.path.join(run_path, "print_config.txt")
+    if os.path.exists(path):
+        cfg = {}
+        for line in open(path):
+            if "-->" in line:
+                k, v = (t.strip() for t in line.split("-->", 1))
+                try:
+                    cfg[k] = ast.literal_eval(v)
+                except (ValueError, SyntaxError):
+                    cfg[k] = v
+        return cfg
+    raise RuntimeError(f"[Model CFG] Model configuration is not found in {run_path}.")
+
+
+def load_vlsa_model(run_path, cuda_id=0, return_cfg=False):
+    """utils/model_inference.py:11-21: a run directory (config + ``train_model-last.pth``) -> the model on ``cuda:<cuda_id>`` with the
+    trained tensors loaded (``strict=False``: keys of the frozen text tower are not in the reference's checkpoints)."""
+    import os
+    from .model_utils import func_load_model
+    cfg = _read_run_cfg(run_path)
+    cfg["cuda_id"] = cuda_id
+    model = func_load_model(cfg).cuda(cuda_id)
+    ckpt = torch.load(os.path.join(run_path, "train_model-last.pth"), map_location=f"cuda:{cuda_id}", weights_only=False)
+    model.load_state_dict(ckpt["model"], strict=False)
+    return (model, cfg) if return_cfg else model

@@ -179,8 +179,19 @@ class DeviceBagArena:
         """[N, D] bf16 view of a bag; the current stream is ordered after the bag's upload."""
         ev = self._ready.get(key)
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            if ev.query():        # the upload has completed (seen by the host): every later launch on any stream is behind it
+                del self._ready[key]
+            else:
+                torch.cuda.current_stream(self.device).wait_event(ev)
         return self._view(key)
+
+    def uploaded(self, key) -> bool:
+        """True once the bag's upload has completed (``bag`` then needs no event wait any more)"""
+        ev = self._ready.get(key)
+        if ev is not None and ev.query():
+            del self._ready[key]
+            ev = None
+        return ev is None
 
     def batches(self, keys: Sequence, batch_size: int = 32) -> Iterable[List[torch.Tensor]]:
         for i in range(0, len(keys), batch_size):
@@ -278,13 +289,14 @@ class ResidentBags(torch.utils.data.Dataset):
         self._segments: List[DeviceBagArena] = []
         self._where: Dict[int, DeviceBagArena] = {}
         self._rest: Dict[int, tuple] = {}
+        self._views: Dict[int, torch.Tensor] = {}
         self.reads = 0                    # items fetched from the wrapped dataset so far
 
     def __len__(self):
         return len(self.dataset)
 
     def __getattr__(self, name):          # uid, get_meta_data, summary, ...: whatever the handler asks the dataset for
-        if name in ("dataset", "_segments", "_where", "_rest", "_next_rows", "_warned_worker", "_tag_views"):
+        if name in ("dataset", "_segments", "_where", "_rest", "_views", "_next_rows", "_warned_worker", "_tag_views"):
             raise AttributeError(name)
         return getattr(self.dataset, name)
 
@@ -333,5 +345,13 @@ class ResidentBags(torch.utils.data.Dataset):
     # -- what the model's look-ahead asks (vlsa_amd/vlsa.py) ----------------------------------------------------------------
     def resident_view(self, i: int):
         """plain [N, 512] view of item i if it is resident, else None (never reads the wrapped dataset)"""
-        seg = self._where.get(int(i))
-        return None if seg is None else seg.bag(int(i))
+        i = int(i)
+        v = self._views.get(i)
+        if v is None:
+            seg = self._where.get(i)
+            if seg is None:
+                return None
+            v = seg.bag(i)
+            if seg.uploaded(i):
+                self._views[i] = v       # the same view object from now on (no event, no slicing per call)
+        return v

@@ -61,6 +61,15 @@ class Feat_Projecter(_TransientCaches, nn.Module):
         return self.projecter(x)
 
 
+def _note(module, x):
+    """the pooling modules' own ``forward`` is plain torch: meant for the P query rows inside VLFAN; ``DeepMIL`` drives the fused
+    kernels with the modules' parameters instead of calling it on a bag"""
+    if x.is_cuda:
+        from ._native import note_torch_route
+        note_torch_route(type(module).__name__ + ".forward", x.shape[-2], "called directly on the rows of a bag; DeepMIL.forward / "
+                         "VF.attn_pool_autograd run the same parameters through the fused score + pooling kernels")
+
+
 class Gated_Attention_Pooling(nn.Module):
     """ABMIL gated attention (model/layers.py:85-122). Keys: fc1.0.*, score.0.*, fc2.*.
     Returns (pooled[B, d], attn) where attn is the softmax weights, or the raw scores if ret_raw_attn."""
@@ -74,6 +83,7 @@ class Gated_Attention_Pooling(nn.Module):
     def forward(self, x, ret_raw_attn: bool = False):
         if x.dim() == 2:
             x = x.unsqueeze(0)
+        _note(self, x)
         raw = self.fc2(self.fc1(x) * self.score(x)).transpose(2, 1)  # [B, 1, n]
         attn = F.softmax(raw, dim=2)
         out = torch.matmul(attn, x).squeeze(1)
@@ -92,6 +102,7 @@ class Attention_Pooling(nn.Module):
     def forward(self, x, ret_raw_attn: bool = True):
         if x.dim() == 2:
             x = x.unsqueeze(0)
+        _note(self, x)
         raw = self.attention(x).transpose(2, 1)  # [B, 1, n]
         attn = F.softmax(raw, dim=2)
         out = torch.matmul(attn, x).squeeze(1)

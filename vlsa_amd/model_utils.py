@@ -13,7 +13,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
-__all__ = ["load_model", "Deep_VLSA", "get_prompt_encoder", "load_prompt_learner", "load_prompt_adapter", "patch_reference"]
+__all__ = ["load_model", "Deep_VLSA", "get_prompt_encoder", "load_prompt_learner", "load_prompt_adapter", "patch_reference",
+           "arch_cfg_from_run_cfg", "func_load_model"]
 
 
 def load_model(arch: str, dims: Optional[List] = None, **kws):
@@ -60,6 +61,57 @@ def load_prompt_adapter(prompt_encoder, cfg: dict):
     """model/prompt_learners/__init__.py:20-24"""
     from .prompt_adapter import PromptAdapter
     return PromptAdapter(prompt_encoder, **cfg)
+
+
+def _sub_cfg(cfg: dict, prefix: str) -> dict:
+    """the keys ``<prefix>_<name>`` of a flat run config as ``{name: value}`` (what utils/func.py:136-147 ``fetch_kws`` hands the
+    handler; names shorter than two characters are not picked up there either)"""
+    cut = len(prefix) + 1
+    return {k[cut:]: v for k, v in cfg.items() if k.startswith(prefix) and len(k) > cut and k[len(prefix)] == "_"}
+
+
+def arch_cfg_from_run_cfg(cfg: dict) -> dict:
+    """A run's flat config (cfg_vlsa_conch.yaml / a run directory's config.yaml) -> the keyword arguments of
+    ``load_model('VLSA', **arch_cfg)``, as ``VLSAHandler.func_load_model`` assembles them (runner/vlsa_handler.py:88-120)."""
+    arch = cfg["arch"].lower()
+    assert f"{arch}_api" in cfg, "Please specify the API for VLSA models."
+    learner = cfg["vlsa_pmt_learner_name"]
+    learner_cfg = _sub_cfg(cfg, f"{arch}_pmt_learner_{learner.lower()}")
+    pretrained = bool(cfg.get("vlsa_pmt_learner_pretrained", False))
+    learner_cfg.update(name=learner, pretrained=pretrained)
+    coop_cfg = None
+    if pretrained:          # text prompts pre-trained by CoOp: the checkpoint path is a template over (split seed, method)
+        coop_cfg = _sub_cfg(cfg, "vlsa_pmt_learner_coop")
+        assert coop_cfg.get("ckpt") is not None, "Found null ckpt path."
+        coop_cfg["ckpt"] = coop_cfg["ckpt"].format(cfg["data_split_seed"], coop_cfg["method"])
+    return dict(vlsa_api=cfg[f"{arch}_api"], text_encoder_cfg=_sub_cfg(cfg, f"{arch}_txt_encoder"),
+                image_encoder_cfg=_sub_cfg(cfg, f"{arch}_img_encoder"), prompt_learner_cfg=learner_cfg,
+                pretrained_prompt_learner_cfg=coop_cfg, path_clip_model=cfg["path_clip_model"])
+
+
+def func_load_model(cfg: dict):
+    """``VLSAHandler.func_load_model`` (runner/vlsa_handler.py:88-151) without the handler: build the model from a run config and
+    freeze what the config freezes (prompt embeddings, MIL encoder, text tower, logit scale).  ``init_wt`` (a generic re-init of
+    every Linear, off in every shipped config) is refused rather than silently ignored."""
+    if cfg.get("init_wt"):
+        raise NotImplementedError("init_wt: True re-initialises the model with utils/func.py:general_init_weight; run it on the result if wanted")
+    arch_cfg = arch_cfg_from_run_cfg(cfg)
+    model = load_model(cfg["arch"], **arch_cfg)
+    arch = cfg["arch"].lower()
+    learner = cfg["vlsa_pmt_learner_name"]
+    freeze = []
+    if learner == "CoOp":
+        freeze += [(model.prompt_learner.context_embeds, arch_cfg["prompt_learner_cfg"]["frozen_context_embeds"]),
+                   (model.prompt_learner.rank_embeds, arch_cfg["prompt_learner_cfg"]["frozen_rank_embeds"])]
+    if learner in ("CoOp", "Adapter"):
+        tower = model.prompt_encoder if hasattr(model, "prompt_encoder") else getattr(model, "text_encoder", None)
+        freeze += [(model.mil_encoder, arch_cfg["image_encoder_cfg"]["frozen"]), (tower, arch_cfg["text_encoder_cfg"]["frozen"]),
+                   (model.logit_scale, cfg[f"{arch}_frozen_logit_scale"])]
+    for obj, frozen in freeze:
+        if frozen and obj is not None:
+            for p in (obj.parameters() if hasattr(obj, "parameters") else [obj]):
+                p.requires_grad = False
+    return model
 
 
 def patch_reference(resident_bags: bool = False, **resident_kw):

@@ -162,6 +162,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         self._plans = {}
         self._train_plans = {}
         self._tower_lists = None
+        self._la = self._la_lists = None                      # look-ahead window + kept module / tensor lists (see _lookahead)
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ / queries were computed from
         self._prepared_query, self._prepared_qver = None, -1
@@ -463,14 +464,15 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if isinstance(X, (list, tuple)):
             return self.forward_bags(list(X))
         src = getattr(X, "_vlsa_src", None)          # a ResidentBags item as the handler's loader delivers it (vlsa_amd/ingest.py)
-        if src is not None:
-            X = X.as_subclass(torch.Tensor)
         text_features = self._text_features()
-        if not self._needs_grad(text_features):
-            if src is not None and not self.training and self.lookahead_bags > 1:
+        needs_grad = self._needs_grad(text_features)
+        if src is not None:
+            if not needs_grad and not self.training and self.lookahead_bags > 1:
                 ahead = self._lookahead(src, X, text_features)
                 if ahead is not None:
                     return ahead
+            X = X.as_subclass(torch.Tensor)
+        if not needs_grad:
             fused = self._fused_vlfan(X, text_features)
             if fused is not None:
                 return fused
@@ -512,29 +514,32 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         every parameter / buffer (object + version) and train / eval flag of the MIL encoder (query network included), the logit
         scale, the co-attention scale.  The module / tensor lists are kept between calls and rebuilt by an exact walk whenever a
         window is computed, on ``_apply`` and on ``load_state_dict``."""
-        enc = self.mil_encoder
         ll = self._la_lists
-        if ll is None or ll[0] is not enc:
+        if ll is None or ll[0] is not self._modules["mil_encoder"]:
+            enc = self._modules["mil_encoder"]
             sub, tensors = self._walk_module(enc)
+            tensors = tensors + [self._parameters["logit_scale"]]
+            cs = getattr(enc, "coattn_logit_scale", None)
+            if isinstance(cs, torch.Tensor):
+                tensors.append(cs)
             ll = self._la_lists = (enc, sub, tensors)
-        cs = getattr(enc, "coattn_logit_scale", None)
-        return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version,
-                self.logit_scale, self.logit_scale._version, cs, -1 if cs is None else cs._version)
+        return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version)
 
     @staticmethod
     def _same_state(a, b):
-        return (a[1] == b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4] and a[5] is b[5] and a[6] == b[6] and a[7] is b[7]
-                and a[8] == b[8] and len(a[0]) == len(b[0]) and all(x is y for x, y in zip(a[0], b[0])))
+        return (a[1] == b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4]
+                and (a[0] is b[0] or (len(a[0]) == len(b[0]) and all(x is y for x, y in zip(a[0], b[0])))))
 
     def _lookahead(self, src, X, text_features):
         """``net(X)`` in eval mode under ``no_grad`` for item i of a ``ResidentBags`` dataset (the handler's ``test_model`` loop,
         runner/vlsa_handler.py:322-330, calls the model once per bag): the first call of a window runs ``forward_bags`` over items
         i, i+1, ... (as many as are resident, <= ``lookahead_bags``: the loaders of base_handler.py:246-259 do not shuffle) -- ONE
         persistent launch instead of one latency-bound launch chain per bag -- and the following calls return their rows of that
-        result.  A row is only ever handed out for the exact item it was computed from (the tag travels on the tensor object:
+        result; half way through a window the next one is launched, so that the GPU does not idle while the host walks through the
+        rows.  A row is only ever handed out for the exact item it was computed from (the tag travels on the tensor object:
         ``ResidentBagView``) and while the model state it was computed under (``_eval_state``) still holds; any differentiable
-        forward, ``_apply`` or ``load_state_dict`` drops the window.  An access pattern that does not use the window shrinks it
-        (random access degenerates to the per-bag route)."""
+        forward, ``_apply`` or ``load_state_dict`` drops the windows.  An access pattern that does not use its windows shrinks
+        them (random access degenerates to the per-bag route)."""
         rb, i = src
         state = self._eval_state(text_features)
         la = self._la
@@ -544,44 +549,78 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             if row is not None:
                 la["used"] += 1
                 la["last"] = i
+                if i >= la["trigger"]:
+                    self._lookahead_extend(la, text_features)
                 return self._lookahead_row(row, X)
         width, seq = int(self.lookahead_bags), 0
         if same_rb:
             width, seq = la["width"], la["seq"]
             if la["rows"]:                            # a miss behind a window: was that window used?
-                if la["used"] >= len(la["rows"]):
+                if la["used"] >= la["computed"]:
                     width = min(int(self.lookahead_bags), 2 * width)
                 elif la["used"] <= 1:
                     width = max(1, width // 4)
             seq = seq + 1 if i == la["last"] + 1 else 0
             if width <= 1 and seq >= 3:               # the per-bag route, but the accesses have become sequential again
                 width = min(int(self.lookahead_bags), 8)
-        views, idx = [], []
-        if width > 1:
-            for j in range(i, min(len(rb), i + width)):
-                v = rb.resident_view(j)
-                if v is None:
-                    break
-                views.append(v)
-                idx.append(j)
-        self._la = la = {"rb": rb, "state": None, "rows": {}, "used": 0, "width": width, "seq": seq, "last": i}
-        if len(views) < 2 or views[0].data_ptr() != X.data_ptr() or tuple(views[0].shape) != tuple(X.shape[-2:]):
-            return None                               # nothing to batch (yet): the per-bag route
+        self._la = la = {"rb": rb, "state": None, "rows": {}, "used": 0, "computed": 0, "width": width, "seq": seq, "last": i,
+                         "hi": i - 1, "trigger": 1 << 62}
+        if width <= 1:
+            return None
+        first = rb.resident_view(i)
+        Xp = X.as_subclass(torch.Tensor)
+        if first is None or first.data_ptr() != Xp.data_ptr() or tuple(first.shape) != tuple(Xp.shape[-2:]):
+            return None                               # not (yet) the resident rows: the per-bag route
         self._la_lists = None                         # the kept lists are re-walked exactly before a window is computed
-        state = self._eval_state(text_features)
+        la["state"] = self._eval_state(text_features)
+        if self._lookahead_window(la, text_features, width) < 2 and not la["rows"]:
+            return None
+        la["used"] = 1
+        return self._lookahead_row(la["rows"][i], X) if i in la["rows"] else None
+
+    def _lookahead_window(self, la, text_features, width) -> int:
+        """run ``forward_bags`` over the resident items hi+1 .. hi+width of la's dataset and add their rows; -> number of bags"""
+        rb, lo = la["rb"], la["hi"] + 1
+        views = []
+        for j in range(lo, min(len(rb), lo + width)):
+            v = rb.resident_view(j)
+            if v is None:
+                break
+            views.append(v)
+        if not views or (len(views) < 2 and not la["rows"]):
+            return len(views)                         # nothing to batch
         with torch.no_grad():
-            out = self._forward_bags_fused(views, text_features)
+            out = self._forward_bags_fused(views, text_features, trusted=True)
         logits, feats, That = out[0], out[1], out[2]
-        per_bag = isinstance(feats, torch.Tensor) and feats.dim() == 2 and feats.shape[0] == len(idx)
-        for b, j in enumerate(idx):
-            la["rows"][j] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag)
-        la["state"], la["used"] = state, 1
-        return self._lookahead_row(la["rows"][i], X)
+        per_bag = isinstance(feats, torch.Tensor) and feats.dim() == 2 and feats.shape[0] == len(views)
+        rows = la["rows"]
+        for b in range(len(views)):
+            rows[lo + b] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag)
+        la["hi"] = lo + len(views) - 1
+        la["computed"] += len(views)
+        la["trigger"] = lo + len(views) // 2          # ... at which the window behind this one is launched
+        return len(views)
+
+    def _lookahead_extend(self, la, text_features):
+        """half of the newest window has been handed out in order: launch the next one now (and forget the rows behind us)"""
+        la["trigger"] = 1 << 62
+        if la["hi"] + 1 >= len(la["rb"]):
+            return
+        last = la["last"]
+        for j in [j for j in la["rows"] if j < last]:
+            del la["rows"][j]
+        self._la_lists = None
+        state = self._eval_state(text_features)
+        if not self._same_state(la["state"], state):
+            return
+        la["state"] = state
+        la["width"] = min(int(self.lookahead_bags), 2 * max(la["width"], 1))     # used in order: the next window may be wider
+        self._lookahead_window(la, text_features, la["width"])
 
     def _lookahead_row(self, row, X):
         logits, f, That, has_feats = row
         if not has_feats:       # identity FeatMIL: the per-patch unit features of THIS bag, as the per-bag route returns them
-            f = VF.normalize_many(VF._bag2d(X)) if getattr(self, "return_patch_features", True) else None
+            f = VF.normalize_many(VF._bag2d(X.as_subclass(torch.Tensor))) if getattr(self, "return_patch_features", True) else None
         return logits, f, That
 
     def forward_bags(self, bags, ret_with_attn=False):
@@ -597,6 +636,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if ret_with_attn:
             return self._forward_bags_attn(bags, text_features)
         if self._needs_grad(text_features):
+            self._la = None                      # a differentiable forward: parameters are about to move (see _lookahead)
             if (isinstance(enc, VLFAN) and len(bags) > 0 and all(x.is_cuda and x.shape[-1] == 512 and x.shape[-2] > 0 for x in bags)
                     and all(x.dtype == bags[0].dtype for x in bags)):
                 spec = enc.fused_head_spec()
@@ -633,17 +673,20 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         attn = [a.unsqueeze(0).clone() for pl in plans for a in pl.attn.views]   # the plan's buffers are reused by later calls
         return logits, feats, That, attn
 
-    def _forward_bags_fused(self, bags, text_features, want_attn=False):
+    def _forward_bags_fused(self, bags, text_features, want_attn=False, trusted=False):
+        """trusted: the bags are [N, 512] device views of ONE dtype with N > 0 (the resident arena's own views): per-bag checks are
+        skipped -- with 64 small bags per call they are most of the host time"""
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
-        flat = [VF._bag2d(x) for x in bags]
+        flat = list(bags) if trusted else [VF._bag2d(x) for x in bags]
         projected = False
         if (getattr(enc, "feat_proj", None) is not None and isinstance(enc, (VLFAN, mil_encoders.DeepMIL)) and len(flat) > 0
                 and all(x.is_cuda and x.shape[0] > 0 for x in flat)):
             flat = [enc.feat_proj(x) for x in flat]    # use_feat_proj=True: one fused HIP launch per bag, fp32 [N, 512] out
             projected = True
         ok = (spec is not None and spec[0] != "module" and len(flat) > 0
-              and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat))
+              and ((trusted and not projected)
+                   or all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)))
         if not ok:
             same = (len(flat) > 0 and all(x.is_cuda and x.dtype == flat[0].dtype and x.shape[1] == 512 and x.shape[0] > 0 for x in flat)
                     and flat[0].dtype in (torch.bfloat16, torch.float32))
