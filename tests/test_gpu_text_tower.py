@@ -252,3 +252,74 @@ def test_sentence_assembly_kernels_match_the_torch_ops(kind):
     assert out.shape == ref.shape and (out - ref).abs().max().item() < 1e-6
     assert (g_hip[0] - pl.context_embeds.grad).abs().max().item() < 1e-5 * max(1.0, pl.context_embeds.grad.abs().max().item())
     assert (g_hip[1] - pl.rank_embeds.grad).abs().max().item() < 1e-5 * max(1.0, pl.rank_embeds.grad.abs().max().item())
+
+
+# ---- the persistent forward (k_tt_forward_persistent): one launch for the 12 blocks, stages ordered by in-kernel counters --------
+def _tower_kernels(fn):
+    """names of the HIP kernels `fn` launches (torch profiler, device activity only)"""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return [e.key for e in prof.key_averages() for _ in range(e.count)]
+
+
+@pytest.mark.parametrize("name", ["rank_conch_k12", "rank_conch_k4", "text_conch"])
+def test_persistent_forward_equals_the_launch_per_stage_path(name, monkeypatch):
+    """CONCH-size tower, <= 112 compact rows, VLSA_TT_PERSIST=1: the 12 blocks as ONE persistent launch (opt-in: measured slower than
+    the default, profiles/r04_bench_text_persist.txt).  Same features as the launch-per-stage path up to the summation order of the K split (8 instead of 4 waves), same fixtures, with
+    and without saved activations (the backward pass reads what the persistent launch wrote), repeated calls bit-identical, and
+    no in-kernel wait timed out."""
+    if name.startswith("rank"):
+        case = next(c for c in TC.RANK_CASES if c[0] == name)
+        inp = TH.rank_case_inputs(case)
+        fx = inp["fx"]
+        enc = build_encoder(case[1], case[2])
+        pl = build_learner(case, inp).cuda()
+        with torch.no_grad():
+            pl.context_embeds.copy_(torch.from_numpy(fx["context_embeds"]))
+            pl.rank_embeds.copy_(torch.from_numpy(fx["rank_embeds"]))
+        L = pl.shared_prefix_len
+        kw = dict(prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=L)
+        run = lambda: enc(prompts_embedding=pl(), **kw)                                     # noqa: E731
+        plan = enc._plan(pl.pseudo_sentence_tokens, torch.device("cuda", 0), L)
+        grads = lambda: (pl.context_embeds.grad.clone(), pl.rank_embeds.grad.clone())      # noqa: E731
+        want = fx["text_features"]
+    else:
+        case = next(c for c in TC.TEXT_CASES if c[0] == name)
+        fx = TH.load(name)
+        enc = build_encoder(case[1], case[2])
+        ids = torch.from_numpy(fx["token_ids"]).cuda()
+        run = lambda: enc(prompts_text=ids)                                                 # noqa: E731      (68 rows, prompts straddle row tiles)
+        plan, grads, want = None, None, fx["text_features"]
+    assert plan is None or plan.M <= 112
+    monkeypatch.setenv("VLSA_TT_PERSIST", "1")
+    with torch.no_grad():
+        a = run()
+        names = _tower_kernels(run)
+        a2 = run()
+    assert any("k_tt_forward_persistent" in n for n in names) and not any("k_tt_gemm<1" in n for n in names), names
+    assert torch.equal(a, a2)
+    monkeypatch.setenv("VLSA_TT_PERSIST", "0")
+    with torch.no_grad():
+        b = run()
+        names = _tower_kernels(run)
+    assert not any("k_tt_forward_persistent" in n for n in names)
+    assert np.abs(a.cpu().numpy() - want).max() < TOL and np.abs(b.cpu().numpy() - want).max() < TOL
+    assert (a - b).abs().max().item() < 2e-5
+    if grads is not None:      # training route: persistent forward with saved activations -> the launch-per-stage backward
+        G = torch.from_numpy(fx["G"]).cuda()
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("VLSA_TT_PERSIST", mode)
+            pl.zero_grad(set_to_none=True)
+            f = run()
+            (f * G).sum().backward()
+            got[mode] = (f.detach().clone(),) + grads()
+        for x, y in zip(got["1"], got["0"]):
+            assert (x - y).abs().max().item() < 2e-5 * max(1.0, y.abs().max().item())
+        for key, g in (("grad_context", got["1"][1]), ("grad_rank", got["1"][2])):
+            assert np.abs(g.cpu().numpy() - fx[key]).max() < TOL * max(1.0, np.abs(fx[key]).max()), key
+    assert len(enc._plans) >= 1
+    for pln in enc._plans.values():
+        pln.check_status(wait=True)

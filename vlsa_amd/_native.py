@@ -128,6 +128,7 @@ _SIGNATURES = {
     "vlsa_normalize_many": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "vlsa_topk_mean": (c_int, [c_void_p, c_int, c_int64, c_int, c_float, c_void_p, c_void_p]),
     "vlsa_tt_workspace_bytes": (c_size_t, [c_void_p, c_void_p, c_int]),
+    "vlsa_tt_status_offset": (c_int64, [c_void_p, c_void_p, c_int]),
     "vlsa_tt_packed_bytes": (c_size_t, [c_void_p, c_int]),
     "vlsa_tt_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vlsa_tt_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),

@@ -33,6 +33,8 @@
 // (vlsa_txt_encoder_frozen: True, cfg_vlsa_conch.yaml:69; runner/vlsa_handler.py:131).
 #include "vlsa_common.h"
 
+#include <cstdlib>
+
 namespace vlsa {
 namespace tt {
 
@@ -716,6 +718,380 @@ __global__ __launch_bounds__(256) void k_tt_scatter(const float* __restrict__ dx
     for (int c = threadIdx.x; c < d; c += 256) o[c] = dx[(size_t)row * d + c];
 }
 
+
+// ===============================================================================================================
+// Persistent forward (round 4): the 12 blocks of the tower as ONE launch.
+//
+// Why: a forward pass over K = 12 rank prompts is 101 compact rows = 7 row tiles; every product of a block is 5 - 13 us of which
+// ~3 us is the launch boundary and ~1 us the weight loads that could have been in flight before the activations existed
+// (profiles/r03_text_kernel_stats.csv: 60 dependent launches = 616 us for 42 us of weight stream).  Here every workgroup walks
+// the same static schedule -- per block: QKV product, attention, out-proj, c_fc, c_proj, one task of <= 16 rows x 32 .. 96
+// columns per workgroup and stage -- and the stages are ordered by DATAFLOW, not by grid-wide barriers:
+//   * every task publishes its outputs write-through (agent-scope `sc1` stores), drains them, and adds 1 to the counter of the
+//     row tile(s) it wrote (one counter per block x stage x row tile: <= 36 arrivals each, not 256 on one word);
+//   * a task first issues the loads of its WEIGHT fragments (they depend on nothing), then ONE lane polls the counter(s) of the
+//     row tile it consumes (relaxed agent-scope loads + s_sleep), a workgroup barrier, then the activation loads -- `sc1` loads,
+//     which bypass the CU's L1 (the buffers are rewritten every block; L1 is never refreshed by another CU's stores) and are
+//     served memory-side of the per-XCD L2s (MI355X_MICROARCH.md "inter-workgroup visibility": {sc1 stores, sc1 loads} is a valid
+//     hand-off at any placement).  Row tile r of block L+1 can start while other tiles still finish block L.
+//   * deadlock freedom: a task only waits for tasks of EARLIER stages, every workgroup runs its tasks in stage order, and the
+//     grid (<= 256 workgroups of 512 threads) is resident at once; every spin is bounded and a time-out is reported in the
+//     workspace's status block (vlsa_tt_status_offset) -- the results of that launch are then void.
+// Buffers reused across blocks (x / qkv / attention / hidden activations) are safe by the dependency chain itself; the one
+// exception, the prefix rows of `qkv` (read by every prompt's attention task, rewritten by the next block's tile 0), is double
+// buffered by block parity.  Supported: width 768 / 12 heads (CONCH), <= 16 blocks, <= 112 compact rows, <= 64 keys per prompt.
+// RESULT (round 4): correct on the first run (tests/test_gpu_text_tower.py::test_persistent_forward_equals_...), and SLOWER than the
+// launch-per-stage path: 836 vs 616 us -- see persist_supported() and DESIGN.md 4.8; it is therefore opt-in (VLSA_TT_PERSIST=1).
+constexpr int kPMaxLayers = 16, kPMaxRT = 8, kPStages = 5;
+constexpr int kPAttnMaxS = 64;
+constexpr unsigned kPSpinLimit = 1u << 21;      // ~1 s of polling: only a non-resident workgroup (a foreign kernel hogging CUs) gets here
+
+struct PLayerPtrs {
+    const float *ln1_w, *ln1_b, *in_b, *out_b, *ln2_w, *ln2_b, *fc_b, *proj_b;
+};
+struct PArgs {
+    float* ws;                 // layer regions
+    const float* wset;         // packed (tiled) forward weights
+    float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *qkv_alt;
+    unsigned* ctr;             // [layers][kPStages][kPMaxRT], zeroed before the launch
+    unsigned* status;          // [4]: code, stage id, workgroup, spins
+    long long* stamps;         // null, or [layers][kPStages][6] shader-clock stamps of workgroup stamp_wg (VLSA_TT_STAMPS=<wg>):
+    int stamp_wg;              //   task start | dependency met | operands landed | arithmetic done | stores issued | drained + counted in
+    const int* seq_row0;
+    const unsigned char* cls_keep;
+    size_t LF;                 // floats per layer region
+    int d, heads, layers, M_pad, RT, n_seq, L, save;
+    int n[kPStages];           // tasks per stage
+    PLayerPtrs lp[kPMaxLayers];
+};
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ONE lane: spin until *c >= expect (relaxed agent-scope loads).  A time-out -- or one already reported by anybody -- ends the wait.
+__device__ __forceinline__ void p_wait_one(const unsigned* c, unsigned expect, unsigned* status, int stage) {
+    unsigned spins = 0;
+    while (ld_agent(c) < expect) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0u) {
+            if (ld_agent(status) != 0u) return;
+            if (spins >= kPSpinLimit) {
+                if (atomicCAS(status, 0u, 1u) == 0u) {
+                    __hip_atomic_store(status + 1, (unsigned)stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(status + 2, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(status + 3, ld_agent(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+        }
+    }
+}
+// what the attention stage writes into row tile t: one task per head for the prefix rows and for every prompt whose own rows
+// [seq_row0[s], seq_row0[s + 1]) touch the tile (pattn counts in on every tile of its row range)
+struct PAttnRows {
+    const int* seq_row0;   // null: the dependency is not the attention stage
+    int n_seq, L, heads;
+};
+__device__ __forceinline__ unsigned p_attn_expect(const PAttnRows& ar, int t) {
+    const int lo = t * 16, hi = lo + 16;
+    unsigned n = (ar.L > 0 && lo < ar.L) ? 1u : 0u;
+    for (int s = 0; s < ar.n_seq; ++s) n += (ar.seq_row0[s] < hi && ar.seq_row0[s + 1] > lo) ? 1u : 0u;
+    return n * (unsigned)ar.heads;
+}
+// dependency of a task: counters ctr[first .. first + count) must each have reached `expect` (count <= 64: lane t of the first
+// wave polls counter first + t, so that the round trips of the polls overlap instead of adding up)
+__device__ __forceinline__ void p_wait(const unsigned* ctr, int first, int count, unsigned expect, unsigned* status, int stage) {
+    if (ctr != nullptr && (int)threadIdx.x < count) p_wait_one(ctr + first + threadIdx.x, expect, status, stage);
+    __syncthreads();
+}
+// end of a task: every wave drains its write-through stores, then ONE lane counts the task in on the row tiles it wrote
+__device__ __forceinline__ void p_done(unsigned* ctr, int first, int count) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int t = first; t < first + count; ++t) __hip_atomic_fetch_add(ctr + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct PG {
+    const float *A, *W, *bias, *resid, *ln_w, *ln_b;
+    float *Y, *Yt, *Ypre;
+    int ldr, ldy, N, K, RT, M_pad;
+    long long* stamps;     // this task's six stamps, or null
+};
+#define P_STAMP(ptr, k)                                                                    \
+    do {                                                                                   \
+        if ((ptr) != nullptr && threadIdx.x == 0) (ptr)[k] = __builtin_readcyclecounter(); \
+    } while (0)
+
+// One 16-row x (16 NTW)-column tile of Y = pro(A) W^T (+ bias) (gelu) (+ resid): the arithmetic and operand layout of k_tt_gemm
+// (MT = 1), eight waves splitting K (G = K / 128 sixteen-column groups each), weights prefetched BEFORE the dependency wait.
+template <int PRO, int G, int NTW, int EPI>
+__device__ __forceinline__ void pgemm(const PG& p, int b, float* red, const unsigned* dep, unsigned dep_expect, const PAttnRows& ar,
+                                      unsigned* done, unsigned* status, int stage) {
+    constexpr int NW = 8, Q = NTW * 4, QW = (Q + NW - 1) / NW;
+    constexpr int PF = G < 8 ? G : 8;           // register ring: groups in flight (K = 768: the wave's whole K slice)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int K = p.K, N = p.N, RT = p.RT;
+    const int NT = N / (16 * NTW), NT8 = NT & ~7;
+    int ntile, mg;
+    if (b < NT8 * RT) {         // the RT workgroups that share a weight tile on one XCD (workgroup b -> XCD b % 8): W comes from ITS L2
+        const int j = b >> 3;
+        ntile = (j / RT) * 8 + (b & 7);
+        mg = j % RT;
+    } else {
+        const int bb = b - NT8 * RT;
+        ntile = NT8 + bb / RT;
+        mg = bb % RT;
+    }
+    const int n0 = ntile * (16 * NTW), m0 = mg * 16;
+    const int KG = K >> 4, kbeg = w * (G * 16);
+    P_STAMP(p.stamps, 0);
+    const float* Wp[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) Wp[u] = p.W + ((size_t)((n0 >> 4) + u) * KG + (kbeg >> 4)) * 256 + lane * 4;
+    // ---- weights first: they depend on nothing ------------------------------------------------------------------
+    f32x4 rb[PF][NTW];
+#pragma unroll
+    for (int sI = 0; sI < PF; ++sI)
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
+    float e_bias[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = w + i * NW;
+        e_bias[i] = (q < Q && (EPI & EPI_BIAS)) ? p.bias[n0 + 16 * ((q >> 2) % NTW) + r] : 0.f;
+    }
+    f32x4 gld = {0.f, 0.f, 0.f, 0.f}, bld = {0.f, 0.f, 0.f, 0.f};
+    if (PRO == PRO_LN && tid * 4 < K) {
+        gld = *reinterpret_cast<const f32x4*>(p.ln_w + tid * 4);
+        bld = *reinterpret_cast<const f32x4*>(p.ln_b + tid * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the activations of row tile mg exist once all their producers have counted in ----------------------------------
+    p_wait(dep, mg, 1, (ar.seq_row0 != nullptr && threadIdx.x == 0) ? p_attn_expect(ar, mg) : dep_expect, status, stage);
+    P_STAMP(p.stamps, 1);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((size_t)p.M_pad * K * sizeof(float)), 0x00020000);
+    const int a_off = (int)((((size_t)mg * KG + (kbeg >> 4)) * 256 + lane * 4) * sizeof(float));
+    auto ldA = [&](int jj) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off + jj * 1024, 0, 16 /* sc1 */));
+    };
+    constexpr int PFA = G;                      // activations: the wave's whole slab in ONE round of write-through-visible loads
+    f32x4 ra[PFA];
+#pragma unroll
+    for (int sI = 0; sI < PFA; ++sI) ra[sI] = ldA(sI);
+    float e_res[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = w + i * NW;
+        e_res[i] = 0.f;
+        if (q < Q && (EPI & EPI_RESID)) e_res[i] = ld_agent(p.resid + (size_t)(m0 + 4 * g + (q & 3)) * p.ldr + n0 + 16 * ((q >> 2) % NTW) + r);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.stamps != nullptr) {      // stamp 2 = this wave's operands have landed (only taken when stamps are on: it drains the loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P_STAMP(p.stamps, 2);
+    }
+
+    if constexpr (PRO == PRO_LN) {
+        static_assert(G <= 8, "fused LayerNorm keeps the wave's whole A slab in the ring");
+        // LayerNorm over the full row (K columns = the eight waves' slabs): two-pass statistics through LDS, as k_tt_gemm
+        float* sgam = red + 1024;
+        if (tid * 4 < K) {
+            *reinterpret_cast<f32x4*>(sgam + tid * 4) = gld;
+            *reinterpret_cast<f32x4*>(sgam + K + tid * 4) = bld;
+        }
+        float* st = red;                    // [NW][16] partial row statistics
+        float s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) s += (ra[jj][0] + ra[jj][1]) + (ra[jj][2] + ra[jj][3]);
+        s = quad_rows_sum(s);
+        if (g == 0) st[w * 16 + r] = s;
+        __syncthreads();
+        s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += st[ww * 16 + r];
+        const float mean = s / (float)K;
+        __syncthreads();
+        s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float c = ra[jj][i] - mean;
+                s = fmaf(c, c, s);
+            }
+        s = quad_rows_sum(s);
+        if (g == 0) st[w * 16 + r] = s;
+        __syncthreads();
+        s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += st[ww * 16 + r];
+        const float rstd = 1.f / sqrtf(s / (float)K + kLnEps);
+        const float* gw = sgam + kbeg + 4 * g;
+        const float* gb = sgam + K + kbeg + 4 * g;
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const f32x4 gam = *reinterpret_cast<const f32x4*>(gw + 16 * jj);
+            const f32x4 bet = *reinterpret_cast<const f32x4*>(gb + 16 * jj);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[jj][i] = fmaf((ra[jj][i] - mean) * rstd, gam[i], bet[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[jj][i], rb[jj][u][i], acc[u], 0, 0, 0);
+        __syncthreads();                    // every wave is done with gamma / beta in the buffer the reduction reuses
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < G; ++jj) {
+            const int sI = jj % PF;
+            const f32x4 a = ra[jj];
+            f32x4 bq[NTW];
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) bq[u] = rb[sI][u];
+            if (jj + PF < G) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bq[u][i], acc[u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- reduce the eight K slices through LDS (fixed order), epilogue, write-through stores ------------------------
+    P_STAMP(p.stamps, 3);
+#pragma unroll
+    for (int u = 0; u < NTW; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[(w * Q + u * 4 + v) * 64 + lane] = acc[u][v];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = w + i * NW;
+        if (q >= Q) break;
+        float val = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) val += red[(ww * Q + q) * 64 + lane];
+        const int u = (q >> 2) % NTW, v = q & 3;
+        const int row = m0 + 4 * g + v, col = n0 + 16 * u + r;
+        if (EPI & EPI_BIAS) val += e_bias[i];
+        if (EPI & EPI_GELU) {
+            if (p.Ypre) st_agent(p.Ypre + (size_t)row * p.ldy + col, val);
+            val = gelu(val);
+        }
+        if (EPI & EPI_RESID) val += e_res[i];
+        if (p.Y) st_agent(p.Y + (size_t)row * p.ldy + col, val);
+        if (p.Yt) st_agent(p.Yt + tiled_index(row, col, N), val);
+    }
+    P_STAMP(p.stamps, 4);
+    p_done(done, mg, 1);
+    P_STAMP(p.stamps, 5);
+}
+
+// attention of one (prompt, head) -- or of the shared prefix rows (seq == n_seq) -- as k_tt_attn_fwd, 512 threads, q / k / v read
+// with agent-scope loads, output written through; counts in on every row tile it wrote.
+__device__ __forceinline__ void pattn(const float* qkv, int ld, float* out_t, const int* __restrict__ seq_row0,
+                                      const unsigned char* __restrict__ cls_keep, int heads, int d, int n_seq, int L, int task, float* lds,
+                                      const unsigned* dep, int RT, unsigned dep_all, unsigned* done, unsigned* status, long long* stamps) {
+    constexpr int LDK = kHeadDim + 1;
+    P_STAMP(stamps, 0);
+    float* Ks = lds;
+    float* Vs = Ks + kPAttnMaxS * LDK;
+    float* Qs = Vs + kPAttnMaxS * LDK;
+    const int seq = task / heads, h = task % heads;
+    const bool pfx_block = seq == n_seq;
+    const int r0 = pfx_block ? 0 : seq_row0[seq];
+    const int S = pfx_block ? L : L + seq_row0[seq + 1] - r0;
+    const int qbeg = pfx_block ? 0 : L;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    auto grow = [&](int j) { return (pfx_block || j < L) ? j : r0 + (j - L); };
+    p_wait(dep, 0, RT, dep_all, status, 1);                // the keys live in the prefix tile(s) and in the prompt's own tile(s): all of them
+    P_STAMP(stamps, 1);
+    for (int e = tid; e < S * kHeadDim; e += 512) {
+        const int j = e >> 6, c = e & 63;
+        const size_t base = (size_t)grow(j) * ld + h * kHeadDim + c;
+        const float qv = ld_agent(qkv + base), kv = ld_agent(qkv + base + d), vv = ld_agent(qkv + base + 2 * d);
+        Qs[j * kHeadDim + c] = qv * 0.125f;
+        Ks[j * LDK + c] = kv;
+        Vs[j * LDK + c] = vv;
+    }
+    __syncthreads();
+    P_STAMP(stamps, 2);
+    for (int i = qbeg + w; i < S; i += 8) {
+        const float q = Qs[i * kHeadDim + lane];
+        const bool is_cls = !pfx_block && i == S - 1;
+        const int j = lane, jc = j < S ? j : S - 1;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < kHeadDim; ++c) dot = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), c)), Ks[jc * LDK + c], dot);
+        const bool ok = j < S && (is_cls ? cls_keep[grow(jc)] != 0 : j <= i);
+        const float sc = ok ? dot : -INFINITY;
+        const float m = wave_max(sc);
+        float pw = sc == -INFINITY ? 0.f : __expf(sc - m);
+        pw *= 1.f / wave_sum(pw);
+        float o = 0.f;
+        for (int jj = 0; jj < S; ++jj)
+            o = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw), __builtin_amdgcn_readfirstlane(jj))), Vs[jj * LDK + lane], o);
+        st_agent(out_t + tiled_index(grow(i), h * kHeadDim + lane, d), o);
+    }
+    const int first_row = grow(qbeg), last_row = grow(S - 1);
+    P_STAMP(stamps, 3);
+    P_STAMP(stamps, 4);
+    p_done(done, first_row >> 4, (last_row >> 4) - (first_row >> 4) + 1);
+    P_STAMP(stamps, 5);
+}
+
+__global__ __launch_bounds__(512) void k_tt_forward_persistent(const PArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float plds[];
+    const int wg = blockIdx.x;
+    const int d = a.d, Mp = a.M_pad, RT = a.RT;
+    const size_t dd = (size_t)d * d;
+    for (int L = 0; L < a.layers; ++L) {
+        unsigned* c = a.ctr + (size_t)L * kPStages * kPMaxRT;
+        const unsigned* prev = L > 0 ? c - kPMaxRT : nullptr;          // c_proj of the block before (block 0: the embedding launch)
+        const PLayerPtrs& lp = a.lp[L];
+        const PAttnRows no_ar{nullptr, 0, 0, 0}, ar{a.seq_row0, a.n_seq, a.L, a.heads};
+        long long* sp = (a.stamps != nullptr && wg == a.stamp_wg) ? a.stamps + (size_t)L * kPStages * 6 : nullptr;
+        const float* wl = a.wset + (size_t)L * 12 * dd;
+        float* x_in = a.ws + (a.save ? (size_t)L : 0) * a.LF;
+        float* qkv = (a.save || !(L & 1)) ? x_in + (size_t)Mp * d : a.qkv_alt;
+        float* x_mid = x_in + (size_t)Mp * 4 * d;
+        float* h_pre = x_mid + (size_t)Mp * d;
+        float* x_next = (L + 1 < a.layers) ? (a.save ? a.ws + (size_t)(L + 1) * a.LF : x_in) : a.x_final;
+        if (wg < a.n[0]) {      // qkv = ln_1(x_in) W_in^T + b
+            PG p{a.xin_t, wl, lp.in_b, nullptr, lp.ln1_w, lp.ln1_b, qkv, nullptr, nullptr, 0, 3 * d, 3 * d, d, RT, Mp, sp};
+            pgemm<PRO_LN, 6, 4, EPI_BIAS>(p, wg, plds, prev, (unsigned)(d / 32), no_ar, c, a.status, 0);
+        }
+        if (wg < a.n[1])
+            pattn(qkv, 3 * d, a.attn_t, a.seq_row0, a.cls_keep, a.heads, d, a.n_seq, a.L, wg, plds, c, RT, (unsigned)(3 * d / 64),
+                  c + kPMaxRT, a.status, sp ? sp + 6 : nullptr);
+        if (wg < a.n[2]) {      // x_mid = x_in + attn W_out^T + b
+            PG p{a.attn_t, wl + 3 * dd, lp.out_b, x_in, nullptr, nullptr, x_mid, a.xmid_t, nullptr, d, d, d, d, RT, Mp, sp ? sp + 12 : nullptr};
+            pgemm<PRO_NONE, 6, 2, EPI_BIAS | EPI_RESID>(p, wg, plds, c + kPMaxRT, 0u, ar, c + 2 * kPMaxRT, a.status, 2);
+        }
+        if (wg < a.n[3]) {      // h = gelu(ln_2(x_mid) W_fc^T + b)
+            PG p{a.xmid_t, wl + 4 * dd, lp.fc_b, nullptr, lp.ln2_w, lp.ln2_b, nullptr, a.hact_t, a.save ? h_pre : nullptr, 0, 4 * d, 4 * d, d, RT, Mp, sp ? sp + 18 : nullptr};
+            pgemm<PRO_LN, 6, 6, EPI_BIAS | EPI_GELU>(p, wg, plds, c + 2 * kPMaxRT, (unsigned)(d / 32), no_ar, c + 3 * kPMaxRT, a.status, 3);
+        }
+        if (wg < a.n[4]) {      // x_next = x_mid + h W_proj^T + b
+            PG p{a.hact_t, wl + 8 * dd, lp.proj_b, x_mid, nullptr, nullptr, x_next, a.xin_t, nullptr, d, d, d, 4 * d, RT, Mp, sp ? sp + 24 : nullptr};
+            pgemm<PRO_NONE, 24, 2, EPI_BIAS | EPI_RESID>(p, wg, plds, c + 3 * kPMaxRT, (unsigned)(4 * d / 96), no_ar, c + 4 * kPMaxRT, a.status, 4);
+        }
+    }
+}
+
 }  // namespace tt
 }  // namespace vlsa
 
@@ -770,10 +1146,14 @@ struct Scratch {   // behind the layer regions; *_t = tiled
     float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *dattn, *dqkv_t;                    // backward
     float* pfx;             // shared prefix: per (block, head) partial dK / dV of the prefix rows [(n_seq + 1)][heads][L][128]
     unsigned int* cnt;      // [heads] tickets (zero between launches: the workspace is zeroed once by the caller)
+    float* qkv_alt;         // persistent forward without saved activations: qkv of the odd blocks (see k_tt_forward_persistent)
+    unsigned int* pctr;     // persistent forward: [kPMaxLayers][kPStages][kPMaxRT] task counters | 8 status words
 };
+constexpr size_t kPCtrWords = (size_t)kPMaxLayers * kPStages * kPMaxRT;
 inline size_t pfx_floats(const Shape& s) { return (size_t)(s.n_seq + 1) * s.heads * (s.L > 0 ? s.L : 0) * 128 + 64; }
 inline size_t scratch_floats(const Shape& s) {
-    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s);
+    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s)
+           + (size_t)s.M_pad * 3 * s.d + kPCtrWords + 8 + 2 * (size_t)kPMaxLayers * kPStages * 6 + 2;
 }
 inline Scratch scratch_of(float* p, const Shape& s) {
     const size_t md = (size_t)s.M_pad * s.d;
@@ -796,7 +1176,9 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     c.feat = p; p += (size_t)s.ns_pad * s.out_dim;
     c.dout_t = p; p += (size_t)s.ns_pad * s.out_dim;
     c.cnt = reinterpret_cast<unsigned int*>(p); p += 64;
-    c.pfx = p;
+    c.pfx = p; p += pfx_floats(s) - 64;
+    c.qkv_alt = p; p += (size_t)s.M_pad * 3 * s.d;
+    c.pctr = reinterpret_cast<unsigned int*>(p);
     return c;
 }
 
@@ -878,6 +1260,21 @@ inline GemmArgs gemm_args(const float* A, const float* W, int N, int K) {
     return a;
 }
 
+
+// ---- persistent forward: when it applies, and its launch --------------------------------------------------------
+bool persist_supported(const Shape& s, const vlsa_tt_rows* r) {
+    // OPT-IN (VLSA_TT_PERSIST=1; read per call: tests and benches flip it inside one process).  Measured on MI355X, K = 12 rank prompts
+    // (profiles/r04_bench_text_persist.txt, r04_tt_persist_stamps.txt): 836-872 us against 616 us for the launch-per-stage path -- a
+    // stage's in-kernel hand-off (drain of the write-through stores + counter + poll + first round of sc1 loads, ~3.5 us) costs MORE
+    // than the ~3.2 us kernel boundary it replaces, and the 4-byte sc1 epilogue stores are 2x slower than plain ones; the weight
+    // prefetch it buys (task bodies 5.8 vs 8.5 us for QKV) does not make up for it.  Kept, tested and off by default.
+    const char* e = getenv("VLSA_TT_PERSIST");
+    if (!e || atoi(e) == 0) return false;
+    const int RT = (s.M + 15) / 16;       // 7 row tiles x 36 QKV column tiles = 252 workgroups: one round of the CUs
+    return s.d == 768 && s.heads == 12 && s.layers <= kPMaxLayers && RT <= 7 && RT * 16 <= s.M_pad && r->max_len <= kPAttnMaxS
+           && (s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads <= 256;
+}
+
 #define TT_TRY(expr)                  \
     do {                              \
         const int rc_ = (expr);       \
@@ -954,6 +1351,16 @@ extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_
     return (regions * layer_floats(s) + scratch_floats(s)) * sizeof(float);
 }
 
+extern "C" int64_t vlsa_tt_status_offset(const vlsa_tt_model* m, const vlsa_tt_rows* r, int save_for_backward) {
+    Shape s;
+    if (!r || !shape_of(m, r, s)) return -1;
+    if (!persist_supported(s, r)) return -1;         // the launch-per-stage path has no in-kernel waits
+    const size_t nreg = save_for_backward ? (size_t)s.layers : 1;
+    float* base = nullptr;
+    const Scratch c = scratch_of(base + nreg * layer_floats(s), s);
+    return (int64_t)((reinterpret_cast<const char*>(c.pctr + kPCtrWords)) - reinterpret_cast<const char*>(base));
+}
+
 extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* emb,
                                int64_t emb_seq_stride, int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out,
                                void* stream) {
@@ -972,7 +1379,36 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), c.xin_t, d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
                        r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
     TT_LAUNCHED();
-    for (int L = 0; L < s.layers; ++L) {
+    const bool persist = persist_supported(s, r);
+    if (persist) {
+        PArgs a{};
+        a.ws = ws; a.wset = wset;
+        a.x_final = c.x_final; a.xin_t = c.xin_t; a.xmid_t = c.xmid_t; a.attn_t = c.attn_t; a.hact_t = c.hact_t; a.qkv_alt = c.qkv_alt;
+        a.ctr = c.pctr; a.status = c.pctr + kPCtrWords;
+        if (const char* e = getenv("VLSA_TT_STAMPS")) {      // measurement aid (tools/tt_persist_stamps.py): stamps behind the status words
+            a.stamps = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(c.pctr + kPCtrWords + 8) + 7) & ~(uintptr_t)7);
+            a.stamp_wg = atoi(e);
+        }
+        a.seq_row0 = r->seq_row0; a.cls_keep = r->cls_keep;
+        a.LF = LF; a.d = d; a.heads = s.heads; a.layers = s.layers; a.M_pad = Mp; a.RT = (s.M + 15) / 16; a.n_seq = s.n_seq; a.L = s.L;
+        a.save = save_for_backward ? 1 : 0;
+        a.n[0] = a.RT * (3 * d / 64); a.n[1] = (s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads; a.n[2] = a.RT * (d / 32);
+        a.n[3] = a.RT * (4 * d / 96); a.n[4] = a.RT * (d / 32);
+        int grid = 0;
+        for (int i = 0; i < kPStages; ++i) grid = a.n[i] > grid ? a.n[i] : grid;
+        for (int L = 0; L < s.layers; ++L) {
+            const vlsa_tt_layer& w = m->layer[L];
+            a.lp[L] = PLayerPtrs{w.ln1_w, w.ln1_b, w.in_b, w.out_b, w.ln2_w, w.ln2_b, w.fc_b, w.proj_b};
+        }
+        // every polled word back to zero before the launch (a memset node: replayed first under graph capture too)
+        if (hipMemsetAsync(c.pctr, 0, (kPCtrWords + 8) * sizeof(unsigned), st) != hipSuccess) return VLSA_ELAUNCH;
+        constexpr size_t lds = 12544 * sizeof(float);      // max(reduction 8 x 24 x 64, attention 3 x 64 x 65, LayerNorm scratch)
+        static DeviceOnce once;
+        if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_forward_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_tt_forward_persistent, dim3(grid), dim3(512), lds, st, a);
+        TT_LAUNCHED();
+    }
+    for (int L = 0; L < (persist ? 0 : s.layers); ++L) {
         const vlsa_tt_layer& w = m->layer[L];
         const PackedLayer pw = packed_layer(wset, s, L);
         float* x_in = region(L);

@@ -121,6 +121,34 @@ class _RowPlan:
                          self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr(), self.prefix_len)
         self.ws = None    # inference workspace (no activations kept), allocated on first use
         self._rp, self._dense = rp, None
+        self._status = []  # (pinned int32[4], event): status words of persistent launches on their way to the host
+
+    def watch_status(self, words: torch.Tensor):
+        host = torch.empty(4, dtype=torch.int32).pin_memory()
+        host.copy_(words, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._status.append((host, ev))
+        if len(self._status) > 64:
+            self.check_status(wait=True)
+
+    def check_status(self, wait: bool = False):
+        """Raise if a persistent text-tower launch reported a timed-out in-kernel wait (vlsa_tt_status_offset): its text features
+        -- and everything computed from them -- are void."""
+        keep = []
+        for host, ev in self._status:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((host, ev))
+                continue
+            code, stage, wg, seen = (int(v) for v in host)
+            if code != 0:
+                self._status = []
+                raise VlsaNativeError(f"text tower: the persistent forward launch timed out in stage {stage} (workgroup {wg}, counter {seen}): "
+                                      "not all of its workgroups were resident (another kernel held CUs).  Its outputs are void; "
+                                      "VLSA_TT_PERSIST=0 selects the launch-per-stage path")
+        self._status = keep
 
     def dense_tables(self, device):
         """For the trainable-tower route (torch ops over the same compact rows): the additive attention mask [M, M] (0 / -inf)
@@ -177,9 +205,16 @@ class _TextTowerFn(torch.autograd.Function):
         out = torch.empty(plan.n_seq, enc.output_dim, dtype=torch.float32, device=emb.device)
         s = ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)
         packed = enc._packed_weights(emb.device, with_backward=bool(save))
+        plan.check_status()                  # a time-out of an EARLIER persistent launch (see below) surfaces here at the latest
         nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(packed.data_ptr()),
                                       ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), save,
                                       ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
+        off = lib.vlsa_tt_status_offset(ctypes.byref(model), ctypes.byref(plan.c), save)
+        if off >= 0:
+            # the persistent launch reports a timed-out wait in its workspace: read the four words back WITHOUT stalling the
+            # caller (pinned buffer + event) and look at them once the copy has landed -- here at the next call, in backward,
+            # or through ``check_status(wait=True)``
+            plan.watch_status(ws[off:off + 16].view(torch.int32))
         if save:
             ctx.ws, ctx.plan, ctx.enc, ctx.shape, ctx.packed = ws, plan, enc, tuple(emb.shape), packed
         ctx.keep = x
@@ -189,6 +224,7 @@ class _TextTowerFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = nat.load()
         enc, plan = ctx.enc, ctx.plan
+        plan.check_status()
         model = enc._c_model(dout.device)
         g = dout.detach().float().contiguous()
         demb = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
