@@ -1,6 +1,6 @@
 """Eager launch sequence vs hipGraph replay of a batch, small and large bags."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"

@@ -1,6 +1,6 @@
 """Do the small tail kernels co-run with a resident persistent streaming kernel?  (timeline experiment for rocprofv3)"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"

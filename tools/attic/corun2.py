@@ -1,8 +1,8 @@
 import sys, os, time, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools/probes/libcorun_probe.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools/probes/libcorun_probe.so"))
 dev = "cuda"
 B, n = 32, 50000
 bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(B)]

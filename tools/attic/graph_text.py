@@ -1,6 +1,6 @@
 """Does a hipGraph replay of the text tower's ~65 forward launches beat the eager launch sequence?  (tower alone, no grad)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch
 import text_cases as TC

@@ -4,7 +4,7 @@ import sys, os
 gated = bool(int(sys.argv[1])) if len(sys.argv) > 1 else False
 os.environ["VLSA_GS_HG2"] = sys.argv[2] if len(sys.argv) > 2 else "1"
 os.environ["VLSA_GS_SPLIT"] = "0"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 import gc; gc.collect(); gc.freeze()

@@ -1,5 +1,5 @@
 import os, ctypes, torch, collections
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools/probes/libhwid.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools/probes/libhwid.so"))
 out = torch.zeros(256 * 8, dtype=torch.int32, device="cuda")
 rc = lib.hwid_launch(ctypes.c_void_p(out.data_ptr()), 256, 151552, None)
 torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 """Kernel-only timing of the streaming kernel via hipGraph of back-to-back launches (no python overhead)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 

@@ -1,7 +1,7 @@
-"""Same-box A/B of two builds of the library: VLSA_AB_LIB=<path of the other .so> python tools/kbench_ab.py -- the streaming kernel
+"""Same-box A/B of two builds of the library: VLSA_AB_LIB=<path of the other .so> python tools/attic/kbench_ab.py -- the streaming kernel
 over 32 x 50k bf16 bags, alternating rounds (each library in its own process would not share the box's momentary state)."""
 import ctypes, os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, ROOT)
     from vlsa_amd import _native

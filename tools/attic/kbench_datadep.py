@@ -1,7 +1,7 @@
 """Does the streaming kernel's bandwidth depend on the DATA (the chip clocks to its power budget: zeroed operands toggle fewer
 wires)?  32 x 50k bf16 bags of N(0,1) values / of zeros / of one repeated row, same process, interleaved rounds."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 dev = "cuda"

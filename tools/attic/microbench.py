@@ -1,7 +1,7 @@
 """Per-kernel timing of the VLFAN forward pieces (development tool; bench.py is the contract benchmark)."""
 import argparse
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 

@@ -1,7 +1,7 @@
 """Host profile of a handler-shaped training step with a DeepMIL encoder inside VLSA (one net(X) per bag, cat, one backward), the
 backward on the calling thread so that cProfile sees the Python side of the autograd nodes."""
 import sys, os, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn as nn

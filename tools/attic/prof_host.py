@@ -1,6 +1,6 @@
 """Host-side profile (cProfile) of one batched module call: python tools/prof_host.py zeroshot|deepmil|vlfan [N]"""
 import sys, os, time, cProfile, pstats
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd.vlsa import VLSA
 dev = "cuda"

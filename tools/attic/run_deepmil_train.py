@@ -1,6 +1,6 @@
 """DeepMIL(gated_attention) forward + backward, 20 iterations (kernel census with rocprofv3 --kernel-trace --stats)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd.deepmil import DeepMIL
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000

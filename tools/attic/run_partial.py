@@ -1,6 +1,6 @@
 """Launch only the streaming kernel a few times (for rocprofv3 PMC passes)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vlsa_amd import functional as F
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
