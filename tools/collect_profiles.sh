@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): full GPU test suite, bench lines, rocprofv3 kernel stats of the bench command, separate PMC
-# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r03/ (copied into profiles/ afterwards).
+# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r04/ (copied into profiles/ afterwards).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03; mkdir -p $O
-(timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
+O=gpurun_out/r04; mkdir -p $O
+(VLSA_GRAD_ERRORS_OUT=$O/grad_errors.txt timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-extra --streams 1 > $O/bench_profiled_streams1.json 2>/dev/null
@@ -106,6 +106,11 @@ python tools/bench_module.py > $O/bench_module.txt 2>&1
 python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2> $O/bench_sh1.err
+# the N > 1 code path started the way the driver starts it (python bench.py --gpus 2: self-launch), two ranks sharing this GPU over gloo
+VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-extra > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err
+# round 4: persistent text-tower forward vs launch-per-stage (+ its in-kernel stamps), the whole-row score kernel vs the default
+for m in 1 0; do VLSA_TT_PERSIST=$m python tools/bench_text.py 2>&1 | grep "GPU forward" | sed "s/^/VLSA_TT_PERSIST=$m: /"; done > $O/bench_text_persist.txt
+VLSA_TT_PERSIST=1 python tools/tt_persist_stamps.py 2>&1 | grep -v amdgpu > $O/tt_persist_stamps.txt
 # ---- round 3: backward kernels of the N-sized layers, attention-weights traffic, text tower with the shared prefix
 python tools/kbench_mlp_bwd.py > $O/kbench_mlp_bwd.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mb -- python tools/run_mlp_bwd.py 50000 > /dev/null 2>&1

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): PMC passes of the attention-score kernel alone (gated and ungated module, N patches per bag):
-# gpurun_out/r03/pmc_scores_<gated|ungated>_<N>.json
+# gpurun_out/r04/pmc_scores_<gated|ungated>_<N>.json
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 N=${1:-393216}     # 12 whole rounds of the gated kernel: one launch per call
 pmc() { tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2>&1; }

@@ -1,6 +1,6 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 (timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
 bash tools/pmc_gated.sh 393216 > /dev/null 2>&1
