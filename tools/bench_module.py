@@ -55,25 +55,38 @@ for n, dt, n_items in ((50000, torch.bfloat16, 256), (2798, torch.bfloat16, 512)
     loader = torch.utils.data.DataLoader(rb, batch_size=1, shuffle=False, num_workers=0)
     items = [torch.utils.data.default_collate([rb[i]])[1][0] for i in range(n_items)]       # uploads; tagged [1, N, 512] views
     res = {}
-    for la in (64, 0):
-        net.lookahead_bags = la
-        with torch.no_grad():
+    calls = []
+    orig = net._forward_bags_fused
+    net._forward_bags_fused = lambda bags, tf, **kw: (calls.append(len(bags)), orig(bags, tf, **kw))[1]
+
+    def whole_loop():
+        out = []
+        for data_idx, data_x, data_y in loader:
+            X = data_x[0].cuda()
+            raw, *_ = net(X)
+            pred = torch.softmax(raw, dim=-1)
+            out.append(raw.detach().cpu()); out.append(pred.detach().cpu())
+
+    with torch.no_grad():
+        for la in (0, 64):          # the whole loop first (every iteration synchronises), then the model calls alone
+            net.lookahead_bags = la
+            whole_loop()
+            calls.clear()
+            gc.collect()            # (a generation-2 pass inside the timed loop would be ~40 ms: profiles/README.md)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            whole_loop(); whole_loop()
+            t_loop = (time.perf_counter() - t0) / 2 / n_items * 1e6
+            res[la] = [0.0, t_loop, list(calls)]
+        for la in (0, 64):
+            net.lookahead_bags = la
             for _ in range(2):
                 for X in items: net(X)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
                 for X in items: net(X)
-            torch.cuda.synchronize(); t_calls = (time.perf_counter() - t0) / 3 / n_items * 1e6
-            t0 = time.perf_counter()
-            for _ in range(2):
-                out = []
-                for data_idx, data_x, data_y in loader:
-                    X = data_x[0].cuda()
-                    raw, *_ = net(X)
-                    pred = torch.softmax(raw, dim=-1)
-                    out.append(raw.detach().cpu()); out.append(pred.detach().cpu())
-            t_loop = (time.perf_counter() - t0) / 2 / n_items * 1e6
-        res[la] = (t_calls, t_loop)
+            torch.cuda.synchronize(); res[la][0] = (time.perf_counter() - t0) / 3 / n_items * 1e6
     print(f"N={n:6d} {str(dt)[6:]:9s}: handler eval loop over {n_items} resident items: net(X) {res[64][0]:6.2f} us/bag with look-ahead "
           f"({n / res[64][0] / 1e3:.2f} G patches/s), {res[0][0]:6.2f} without;   whole loop incl. DataLoader + softmax + 2 x .cpu(): "
-          f"{res[64][1]:6.1f} us/bag with, {res[0][1]:6.1f} without")
+          f"{res[64][1]:6.1f} us/bag with, {res[0][1]:6.1f} without  (windows of the last two passes: {res[64][2]})")
+    net._forward_bags_fused = orig
+    del rb, loader, items

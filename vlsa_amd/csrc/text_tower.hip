@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 // [seq_row0[s], seq_row0[s + 1]) = its positions L .. m_s + its CLS row.  Block (s, h) then attends with the keys [prefix rows |
 // own rows]; one more block per head (s == n_seq) serves the prefix rows themselves (causal among themselves).
 constexpr int kAttnMaxS = 128;
-__global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out_t,
+__global__ __launch_bounds__(1024) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out_t,
                                                     const int* __restrict__ seq_row0, const unsigned char* __restrict__ cls_keep,
                                                     int heads, int d, int n_seq, int L) {
     __shared__ float Ks[kAttnMaxS][kHeadDim + 1];
@@ -432,8 +432,9 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
     const int S = pfx_block ? L : L + seq_row0[seq + 1] - r0;   // keys: [prefix | own rows]
     const int qbeg = pfx_block ? 0 : L;                        // first query (key index)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nthr = blockDim.x, nwave = nthr >> 6;       // round 4: one wave per query row (16 waves) instead of four rows per wave
     auto grow = [&](int j) { return (pfx_block || j < L) ? j : r0 + (j - L); };     // key / query index -> compact row
-    for (int e = tid; e < S * kHeadDim; e += 256) {   // q, k, v of the prompt in ONE round of global loads
+    for (int e = tid; e < S * kHeadDim; e += nthr) {   // q, k, v of the prompt in ONE round of global loads
         const int j = e >> 6, c = e & 63;
         const size_t base = (size_t)grow(j) * ld + h * kHeadDim + c;
         const float qv = qkv[base], kv = qkv[base + d], vv = qkv[base + 2 * d];
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
         Vs[j][c] = vv;
     }
     __syncthreads();
-    for (int i = qbeg + w; i < S; i += 4) {
+    for (int i = qbeg + w; i < S; i += nwave) {
         const float q = Qs[i][lane];
         const bool is_cls = !pfx_block && i == S - 1;
         float s[2] = {-INFINITY, -INFINITY}, p[2];
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_fwd(const float* __restrict__ q
 // the last arriver adds the n_seq + 1 partials in block order (deterministic) into dqkv.  pfx: [(n_seq + 1)][heads][L][128] floats,
 // cnt: [heads] zeroed unsigned ints (handed back zeroed).
 constexpr int kAttnBwdMaxS = 64;
-__global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ qkv, int ld, const float* __restrict__ dout, int ldo,
+__global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ qkv, int ld, const float* __restrict__ dout, int ldo,
                                                     float* __restrict__ dqkv, const int* __restrict__ seq_row0,
                                                     const unsigned char* __restrict__ cls_keep, int heads, int d, int n_seq, int L,
                                                     float* __restrict__ pfx, unsigned int* __restrict__ cnt) {
@@ -497,8 +498,9 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
     const int S = pfx_block ? L : L + seq_row0[seq + 1] - r0;
     const int qbeg = pfx_block ? 0 : L;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nthr = blockDim.x, nwave = nthr >> 6;       // round 4: 16 waves -- a wave per row in both phases
     auto grow = [&](int j) { return (pfx_block || j < L) ? j : r0 + (j - L); };
-    for (int e = tid; e < S * kHeadDim; e += 256) {
+    for (int e = tid; e < S * kHeadDim; e += nthr) {
         const int j = e >> 6, c = e & 63;
         const size_t base = (size_t)grow(j) * ld + h * kHeadDim + c;
         Qs[j * LD + c] = qkv[base];
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
         Os[j * LD + c] = dout[(size_t)grow(j) * ldo + h * kHeadDim + c];
     }
     __syncthreads();
-    for (int i = w; i < S; i += 4) {   // lane j: score, weight and their gradients for key j of query row i
+    for (int i = w; i < S; i += nwave) {   // lane j: score, weight and their gradients for key j of query row i
         const int j = lane;
         if (i < qbeg) {                // prefix rows are queries of the prefix block only
             Pm[i * LD + j] = 0.f;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
     }
     __syncthreads();
     const bool shared_keys = L > 0;
-    for (int rr = w; rr < S; rr += 4) {   // lane = feature c of row rr: dQ, dK, dV
+    for (int rr = w; rr < S; rr += nwave) {   // lane = feature c of row rr: dQ, dK, dV
         float dq = 0.f, dk = 0.f, dv = 0.f;
         for (int j = 0; j < S; ++j) {
             dq = fmaf(Dm[rr * LD + j], Ks[j * LD + lane], dq);
@@ -566,13 +568,13 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
     // not one per block: the loop is a chain of write-through-visible loads) and added in block order
     // Round 4: a wave's (row, dK | dV) pairs THREE at a time -- 48 loads in flight per lane instead of 16: the tail of the last
     // arriver was three dependent L2 round trips for L = 5 prefix rows (10 pairs over four waves), now one.
-    for (int pr0 = w; pr0 < 2 * L; pr0 += 12) {
+    for (int pr0 = w; pr0 < 2 * L; pr0 += 3 * nwave) {
         float acc[3] = {0.f, 0.f, 0.f};
         for (int b0 = 0; b0 <= n_seq; b0 += 16) {
             float t[3][16];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int pr = pr0 + 4 * k, rr = pr >> 1, which = pr & 1;
+                const int pr = pr0 + nwave * k, rr = pr >> 1, which = pr & 1;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int b = b0 + u;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void k_tt_attn_bwd(const float* __restrict__ q
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int pr = pr0 + 4 * k, rr = pr >> 1, which = pr & 1;
+            const int pr = pr0 + nwave * k, rr = pr >> 1, which = pr & 1;
             if (pr < 2 * L) dqkv[tiled_index(rr, h * kHeadDim + lane + (which ? 2 * d : d), 3 * d)] = acc[k];
         }
     }
@@ -613,6 +615,64 @@ __device__ __forceinline__ void ln_stats(const float (&v)[kLnSlots], int nslot, 
             s2 = fmaf(c, c, s2);
         }
     rstd = 1.f / sqrtf(wave_sum(s2) / (float)d + kLnEps);
+}
+
+// dx[row] = dres[row] + LayerNorm'(x[row]; gamma)^T da[row]   (dres nullable).  Round 4: 16-byte accesses -- a lane owns the four
+// consecutive columns 4 lane + 256 k (contiguous in the row-major arrays AND in a 16 x 16 tile of the tiled copy): 3 loads per array
+// and 2 x 3 stores per lane at d = 768 instead of 12 and 24 four-byte ones; d % 256 == 0 (else the 4-byte path below).
+constexpr int kLnSlots4 = 4;
+__global__ __launch_bounds__(256) void k_tt_ln_bwd4(const float* __restrict__ da, const float* __restrict__ x,
+                                                   const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                   float* __restrict__ dx, float* __restrict__ dxt, int d, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nslot = d >> 8;
+    f32x4 xv[kLnSlots4], gv[kLnSlots4], rv[kLnSlots4];
+#pragma unroll
+    for (int k = 0; k < kLnSlots4; ++k)
+        if (k < nslot) {   // every load of the row in one round
+            const int c = 4 * lane + 256 * k;
+            xv[k] = *reinterpret_cast<const f32x4*>(x + (size_t)row * d + c);
+            gv[k] = *reinterpret_cast<const f32x4*>(da + (size_t)row * d + c) * *reinterpret_cast<const f32x4*>(gamma + c);
+            rv[k] = dres ? *reinterpret_cast<const f32x4*>(dres + (size_t)row * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnSlots4; ++k)
+        if (k < nslot) s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+    const float mean = wave_sum(s) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnSlots4; ++k)
+        if (k < nslot)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float c = xv[k][i] - mean;
+                s2 = fmaf(c, c, s2);
+            }
+    const float rstd = 1.f / sqrtf(wave_sum(s2) / (float)d + kLnEps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnSlots4; ++k)
+        if (k < nslot)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xv[k][i] = (xv[k][i] - mean) * rstd;
+                sg += gv[k][i];
+                sgx = fmaf(gv[k][i], xv[k][i], sgx);
+            }
+    sg = wave_sum(sg) / (float)d;
+    sgx = wave_sum(sgx) / (float)d;
+#pragma unroll
+    for (int k = 0; k < kLnSlots4; ++k)
+        if (k < nslot) {
+            const int c = 4 * lane + 256 * k;
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = rv[k][i] + rstd * (gv[k][i] - sg - xv[k][i] * sgx);
+            *reinterpret_cast<f32x4*>(dx + (size_t)row * d + c) = o;
+            *reinterpret_cast<f32x4*>(dxt + tiled_index(row, c, d)) = o;      // columns c .. c + 3: one k-slot of the tile, contiguous
+        }
 }
 
 // dx[row] = dres[row] + LayerNorm'(x[row]; gamma)^T da[row]   (dres nullable)
@@ -1273,6 +1333,24 @@ inline GemmArgs gemm_args(const float* A, const float* W, int N, int K) {
 }
 
 
+void launch_ln_bwd(const float* da, const float* x, const float* gamma, const float* dres, float* dx, float* dxt, int d, int rows,
+                   hipStream_t st) {
+    if (d % 256 == 0 && d <= 256 * kLnSlots4)
+        hipLaunchKernelGGL(k_tt_ln_bwd4, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows);
+    else
+        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows);
+}
+
+// threads of an attention workgroup: a wave per row of the prompt (up to 16 waves); VLSA_TT_ATTN_THREADS overrides (A/B hook)
+int attn_threads(int max_len) {
+    if (const char* e = getenv("VLSA_TT_ATTN_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) return v;
+    }
+    int wv = max_len < 4 ? 4 : (max_len > 16 ? 16 : max_len);
+    return 64 * wv;
+}
+
 // ---- persistent forward: when it applies, and its launch --------------------------------------------------------
 bool persist_supported(const Shape& s, const vlsa_tt_rows* r) {
     // OPT-IN (VLSA_TT_PERSIST=1; read per call: tests and benches flip it inside one process).  Measured on MI355X, K = 12 rank prompts
@@ -1445,7 +1523,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             else if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(256), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0,
+        hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0,
                            r->cls_keep, s.heads, d, s.n_seq, s.L);
         TT_LAUNCHED();
         {
@@ -1533,7 +1611,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             a.Y = c.da; a.ldy = d;
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp);
+        launch_ln_bwd(c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp, st);
         TT_LAUNCHED();
         // attention branch
         {   // d attn = dx_mid @ W_out
@@ -1541,7 +1619,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             a.Y = c.dattn; a.ldy = d;
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(256), attn_lds, st, qkv, 3 * d, c.dattn, d,
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
                            c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
         TT_LAUNCHED();
         {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
@@ -1549,7 +1627,7 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             a.Y = c.da; a.ldy = d;
             TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_ln_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp);
+        launch_ln_bwd(c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp, st);
         TT_LAUNCHED();
     }
     if (hipMemsetAsync(demb, 0, (size_t)demb_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
