@@ -146,8 +146,8 @@ def cpu_baseline(seconds=10.0):
 
 
 def load_pmc():
-    names = (("r03_pmc_batch_kernel_b64.json",) if BAGS_PER_LAUNCH == 64 else
-             ("r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
+    names = (("r04_pmc_batch_kernel_b64.json", "r03_pmc_batch_kernel_b64.json") if BAGS_PER_LAUNCH == 64 else
+             ("r04_pmc_batch_kernel.json", "r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
