@@ -27,7 +27,13 @@ for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfl
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(40): net.forward_bags(bags2)
         torch.cuda.synchronize(); t3 = (time.perf_counter() - t0) / 40 / 64 * 1e6
-    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag")
+        from vlsa_amd.functional import BagSet
+        bs = BagSet(bags2)                       # the same 64 bags, checked once: descriptor rows and bags-in-flight choice kept
+        for i in range(10): net.forward_bags(bs)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(40): net.forward_bags(bs)
+        torch.cuda.synchronize(); t4 = (time.perf_counter() - t0) / 40 / 64 * 1e6
+    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag   forward_bags(BagSet of 64) {t4:7.2f} us/bag")
 
 
 # ---- the handler's evaluation loop (runner/vlsa_handler.py:315-345) over a ResidentBags dataset: net(X) once per bag, look-ahead

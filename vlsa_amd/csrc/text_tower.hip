@@ -566,34 +566,25 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
     if (!s_last) return;
     // (row, dK | dV) pairs over the four waves; the blocks' shares of a pair are loaded 16 at a time (one L2 round trip per 16 blocks,
     // not one per block: the loop is a chain of write-through-visible loads) and added in block order
-    // Round 4: a wave's (row, dK | dV) pairs THREE at a time -- 48 loads in flight per lane instead of 16: the tail of the last
-    // arriver was three dependent L2 round trips for L = 5 prefix rows (10 pairs over four waves), now one.
-    for (int pr0 = w; pr0 < 2 * L; pr0 += 3 * nwave) {
-        float acc[3] = {0.f, 0.f, 0.f};
+    // (row, dK | dV) pairs over the waves -- with a wave per row of the prompt (round 4: up to 16 waves) every pair of the L <= 8
+    // prefix rows has a wave of its own, so the blocks' shares of all pairs come in with ONE round of L2 round trips; the shares of
+    // a pair are loaded 16 at a time and added in block order
+    for (int pr = w; pr < 2 * L; pr += nwave) {
+        const int rr = pr >> 1, which = pr & 1;
+        float acc = 0.f;
         for (int b0 = 0; b0 <= n_seq; b0 += 16) {
-            float t[3][16];
+            float t[16];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int pr = pr0 + nwave * k, rr = pr >> 1, which = pr & 1;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int b = b0 + u;
-                    t[k][u] = (pr < 2 * L && b <= n_seq)
-                                  ? __hip_atomic_load(pfx + (((size_t)b * heads + h) * L + rr) * 128 + 64 * which + lane, __ATOMIC_RELAXED,
+            for (int u = 0; u < 16; ++u) {
+                const int b = b0 + u;
+                t[u] = b <= n_seq ? __hip_atomic_load(pfx + (((size_t)b * heads + h) * L + rr) * 128 + 64 * which + lane, __ATOMIC_RELAXED,
                                                       __HIP_MEMORY_SCOPE_AGENT)
                                   : 0.f;
-                }
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc[k] += t[k][u];      // fixed order (the padding adds exact zeros)
+            for (int u = 0; u < 16; ++u) acc += t[u];      // fixed order (the padding adds exact zeros)
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int pr = pr0 + nwave * k, rr = pr >> 1, which = pr & 1;
-            if (pr < 2 * L) dqkv[tiled_index(rr, h * kHeadDim + lane + (which ? 2 * d : d), 3 * d)] = acc[k];
-        }
+        dqkv[tiled_index(rr, h * kHeadDim + lane + (which ? 2 * d : d), 3 * d)] = acc;
     }
     if (tid == 0) __hip_atomic_store(cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ticket back to zero
 }

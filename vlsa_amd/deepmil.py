@@ -308,8 +308,9 @@ class VLFAN(VF.nat.TransientCaches, nn.Module):
         Q = self.get_query()
         scale = self.coattn_scale()
         outs, attn = [], []
+        is_set = isinstance(bags, VF.BagSet)        # checked once, descriptor rows kept: sub-sets stay BagSets
         for i in range(0, len(bags), 64):
-            r = VF.vlfan_cross_attention_bags(bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale,
+            r = VF.vlfan_cross_attention_bags(bags.chunk(i, 64) if is_set else bags[i:i + 64], Q, gated=self.gated_query, coattn_scale=scale,
                                               want_attn=ret_with_attn)
             if ret_with_attn:
                 outs.append(r[0])

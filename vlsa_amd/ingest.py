@@ -193,6 +193,11 @@ class DeviceBagArena:
             ev = None
         return ev is None
 
+    def bag_set(self, keys: Sequence):
+        """the bags of ``keys`` as a checked ``vlsa_amd.functional.BagSet`` (validated once, descriptor rows kept) for ``forward_bags``"""
+        from .functional import BagSet
+        return BagSet([self.bag(k) for k in keys])
+
     def batches(self, keys: Sequence, batch_size: int = 32) -> Iterable[List[torch.Tensor]]:
         for i in range(0, len(keys), batch_size):
             yield [self.bag(k) for k in keys[i:i + batch_size]]
@@ -296,7 +301,7 @@ class ResidentBags(torch.utils.data.Dataset):
         return len(self.dataset)
 
     def __getattr__(self, name):          # uid, get_meta_data, summary, ...: whatever the handler asks the dataset for
-        if name in ("dataset", "_segments", "_where", "_rest", "_views", "_next_rows", "_warned_worker", "_tag_views"):
+        if name in ("dataset", "_segments", "_where", "_rest", "_views", "_next_rows", "_warned_worker", "_tag_views", "_la_sets"):
             raise AttributeError(name)
         return getattr(self.dataset, name)
 
@@ -308,6 +313,22 @@ class ResidentBags(torch.utils.data.Dataset):
         self._next_rows = min(2 * max(self._next_rows, need), self._segment_rows)
         self._segments.append(seg)
         return seg
+
+    def bag_set(self, indices=None):
+        """The resident bags (all, or those of ``indices``) as a checked ``vlsa_amd.functional.BagSet`` for ``net.forward_bags``: an
+        evaluation / training loop over a split then pays the per-bag validation and descriptor building once, not per call."""
+        from .functional import BagSet
+        idx = range(len(self)) if indices is None else indices
+        views = []
+        for i in idx:
+            v = self.resident_view(i)
+            if v is None:
+                self[i]                                  # reads + uploads the item
+                v = self.resident_view(i)
+            if v is None:
+                raise VlsaNativeError(f"item {i} is not a bag of patch features: it cannot be made resident")
+            views.append(v)
+        return BagSet(views)
 
     def resident_bytes(self) -> int:
         return sum(s.data.numel() * s.data.element_size() for s in self._segments)

@@ -589,13 +589,24 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             views.append(v)
         if not views or (len(views) < 2 and not la["rows"]):
             return len(views)                         # nothing to batch
+        # the same windows come back every epoch: their checked bag set (descriptor rows, bags in flight) is kept on the dataset
+        sets = rb.__dict__.setdefault("_la_sets", {})
+        bagset = sets.get((lo, len(views)))
+        if bagset is None or any(a is not b for a, b in zip(bagset, views)):
+            if len(sets) > 256:
+                sets.clear()
+            bagset = sets[(lo, len(views))] = VF.BagSet(views)
         with torch.no_grad():
-            out = self._forward_bags_fused(views, text_features, trusted=True)
+            out = self._forward_bags_fused(bagset, text_features)
         logits, feats, That = out[0], out[1], out[2]
         per_bag = isinstance(feats, torch.Tensor) and feats.dim() == 2 and feats.shape[0] == len(views)
+        # the rows are produced on the stream that is current NOW; a later hit may run under another current stream: an event per
+        # window, waited for (on the consumer's stream) until the host has seen it complete
+        win = {"ev": torch.cuda.Event(), "done": False}
+        win["ev"].record()
         rows = la["rows"]
         for b in range(len(views)):
-            rows[lo + b] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag)
+            rows[lo + b] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag, win)
         la["hi"] = lo + len(views) - 1
         la["computed"] += len(views)
         la["trigger"] = lo + len(views) // 2          # ... at which the window behind this one is launched
@@ -618,7 +629,12 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         self._lookahead_window(la, text_features, la["width"])
 
     def _lookahead_row(self, row, X):
-        logits, f, That, has_feats = row
+        logits, f, That, has_feats, win = row
+        if not win["done"]:
+            if win["ev"].query():
+                win["done"] = True
+            else:
+                torch.cuda.current_stream(logits.device).wait_event(win["ev"])
         if not has_feats:       # identity FeatMIL: the per-patch unit features of THIS bag, as the per-bag route returns them
             f = VF.normalize_many(VF._bag2d(X.as_subclass(torch.Tensor))) if getattr(self, "return_patch_features", True) else None
         return logits, f, That
@@ -678,7 +694,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         skipped -- with 64 small bags per call they are most of the host time"""
         enc = self.mil_encoder
         spec = enc.fused_head_spec() if isinstance(enc, VLFAN) else None
-        flat = list(bags) if trusted else [VF._bag2d(x) for x in bags]
+        bagset = bags if isinstance(bags, VF.BagSet) else None      # checked once (vlsa_amd.functional.BagSet): trusted, rows kept
+        trusted = trusted or bagset is not None
+        flat = bags if bagset is not None else (list(bags) if trusted else [VF._bag2d(x) for x in bags])
         projected = False
         if (getattr(enc, "feat_proj", None) is not None and isinstance(enc, (VLFAN, mil_encoders.DeepMIL)) and len(flat) > 0
                 and all(x.is_cuda and x.shape[0] > 0 for x in flat)):
@@ -725,7 +743,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         pwc = None if pw is None else pw.detach().float().reshape(-1).contiguous()
         step = 64          # bags per persistent launch (the kernels' maximum: fewer launches and host calls per bag)
         for i in range(0, len(flat), step):
-            chunk = flat[i:i + step]
+            chunk = bagset.chunk(i, step) if (bagset is not None and not projected) else flat[i:i + step]
             key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else 0)
             plan = self._plans.get(key)
             if plan is None:
