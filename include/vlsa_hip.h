@@ -187,7 +187,12 @@ typedef struct vlsa_rows_desc {
     int64_t ld;
 } vlsa_rows_desc;
 
-int vlsa_batch_max_bags(void);                                /* B <= this (64) */
+int vlsa_batch_max_bags(void);                                /* B <= this (64): every batched entry point */
+/* B <= this (256) for the FORWARD launches (vlsa_vlfan_forward_batch[_attn], vlsa_vlfan_partial_batch*, vlsa_attn_normalise_batch):
+ * an evaluation pass over slide-sized bags (the reference's TCGA bags hold 2-12k patches, runner/vlsa_handler.py:315-345 walks them
+ * one by one) amortises the launch's fixed latency chain over four times more bags.  Above 64 bags the bags in flight `groups` are
+ * raised to >= B / 64 (a workgroup keeps its own <= 64 bags in LDS), which also keeps the workspace at a 64-bag launch's size. */
+int vlsa_batch_forward_max_bags(void);
 int vlsa_batch_partials_per_bag(int B);                       /* partial records per bag the batch kernel leaves (256/S) */
 size_t vlsa_batch_workspace_bytes(int B, int P, int D);       /* zero it ONCE after allocation; calls leave it reusable */
 

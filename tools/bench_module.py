@@ -33,7 +33,17 @@ for n, dt in ((50000, torch.bfloat16), (10000, torch.bfloat16), (2798, torch.bfl
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(40): net.forward_bags(bs)
         torch.cuda.synchronize(); t4 = (time.perf_counter() - t0) / 40 / 64 * 1e6
-    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag   forward_bags(BagSet of 64) {t4:7.2f} us/bag")
+        t5 = None
+        if n <= 12000:                          # slide-sized bags: up to 256 per forward launch (round 4); distinct rows per bag
+            wide = torch.randn(256 * n, 512, device=dev).to(dt)
+            bs = BagSet([wide[i * n:(i + 1) * n] for i in range(256)])
+            for i in range(10): net.forward_bags(bs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(40): net.forward_bags(bs)
+            torch.cuda.synchronize(); t5 = (time.perf_counter() - t0) / 40 / 256 * 1e6
+            del bs, wide
+    print(f"N={n:6d} {str(dt)[6:]:9s}: net(X) {t1:7.1f} us/bag   forward_bags(32) {t2:7.2f} us/bag   forward_bags(64) {t3:7.2f} us/bag   forward_bags(BagSet of 64) {t4:7.2f} us/bag"
+          + (f"   forward_bags(BagSet of 256) {t5:7.2f} us/bag = {n / t5 / 1e3:5.2f} G patches/s" if t5 else ""))
 
 
 # ---- the handler's evaluation loop (runner/vlsa_handler.py:315-345) over a ResidentBags dataset: net(X) once per bag, look-ahead

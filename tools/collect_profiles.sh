@@ -99,6 +99,8 @@ python tools/bench_step.py > $O/bench_step.txt 2>&1
 python tools/bench_train.py > $O/bench_train.txt 2>&1
 python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1
 python tools/kbench_batch_f32.py 2>&1 | grep "N=" > $O/kbench_batch_f32.txt
+python tools/kbench_wide.py 2>&1 | grep "N=" > $O/kbench_wide.txt
+python tools/kbench_wide.py 50000 20000 2>&1 | grep "bfloat" > $O/kbench_wide_50k.txt
 python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
 python tools/kbench_featproj.py 2>&1 | grep "N=" > $O/kbench_featproj.txt
 python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1

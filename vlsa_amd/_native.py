@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vlsa_vlfan_backward_bag": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_int, c_float] + [c_void_p] * 14 + [c_int]
                                 + [c_void_p] * 10 + [c_int] + [c_void_p] * 3),
     "vlsa_batch_max_bags": (c_int, []),
+    "vlsa_batch_forward_max_bags": (c_int, []),
     "vlsa_batch_partials_per_bag": (c_int, [c_int]),
     "vlsa_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "vlsa_vlfan_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),

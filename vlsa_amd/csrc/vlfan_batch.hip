@@ -60,8 +60,9 @@ constexpr int kExchWave = 2048 + 128;
 constexpr int kExchGroup = 4 * kExchWave;
 constexpr int kTabOff = kRingBytes + 2 * kExchGroup;  // bag table: kTabInts ints per bag
 constexpr int kTabInts = 12;                          // 8 stream-descriptor ints + score pointer (lo, hi) + score pitch + pad
-constexpr int kMaxBags = 64;
-constexpr int kMlOff = kTabOff + kMaxBags * kTabInts * 4;  // (M, l) hand-off: 8 waves x 32 floats
+constexpr int kMaxLocal = 64;                         // bags per WORKGROUP (LDS table entries); a launch takes S x that, <= kMaxBags
+constexpr int kMaxBags = 256;
+constexpr int kMlOff = kTabOff + kMaxLocal * kTabInts * 4;  // (M, l) hand-off: 8 waves x 32 floats
 constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;        // 152,576 B
 constexpr float kThr = 16.0f;
 }  // namespace bt
@@ -107,15 +108,19 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
     int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
 
-    // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
-    if (tid < B) {
-        const BagDesc d = bags[tid];
+    // ---- bag table: the workgroup streams the bags grp, grp + S, grp + 2 S, ... only, so the LDS table holds THOSE bags
+    // (local index lb <-> bag grp + lb * S: at most kMaxLocal entries whatever B is); thread lb describes this workgroup's
+    // rows of its lb-th bag
+    const int nloc = grp < B ? (B - grp + S - 1) / S : 0;
+    if (tid < nloc) {
+        const int bag_id = grp + tid * S;
+        const BagDesc d = bags[bag_id];
         // 64-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
         // unit rotates with the bag index so that the extra iterations even out over the batch
         const unsigned long long units = (unsigned long long)((d.N + 63) >> 6);
         const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
-        const unsigned int vb = (unsigned int)((b + (tid / S) * 37) % G);  // virtual workgroup index for this bag
-        const bool mine = (tid % S) == grp;
+        const unsigned int vb = (unsigned int)((b + tid * 37) % G);  // virtual workgroup index for this bag
+        constexpr bool mine = true;
         const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
         const long long rbeg = (long long)(ubeg << 6);
         long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 6);
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 2ull;
         int_ma* e = tab + tid * kTabInts;
         if constexpr (kScores) {
-            const RowsDesc sd = sdesc[tid];
+            const RowsDesc sd = sdesc[bag_id];
             const unsigned long long sp = sd.ptr ? reinterpret_cast<unsigned long long>(sd.ptr + rbeg) : 0ull;
             e[8] = (int)(unsigned int)sp;
             e[9] = (int)(sp >> 32);
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
             return;
         }
         nb = bag + 1;
-        while (nb < B && tab_get(nb, 5) <= rg) ++nb;
+        while (nb < nloc && tab_get(nb, 5) <= rg) ++nb;
         nt = rg;
     };
 
@@ -206,14 +211,13 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
     int k0 = 0, k1 = 0;  // tiles consumed so far by row group 0 / 1 (for the epilogue's free-slot bookkeeping)
     {
         int fb = 0;  // first own tile of the whole batch
-        while (fb < B && tab_get(fb, 5) <= rg) ++fb;
-        if (fb < B) issue_tile(fb, rg, 0);
+        while (fb < nloc && tab_get(fb, 5) <= rg) ++fb;
+        if (fb < nloc) issue_tile(fb, rg, 0);
     }
 
     int stamp = 0;
     BSTAMP(stamp++);
-    for (int bag = 0; bag < B; ++bag) {
-        if (tab_get(bag, 7) == 0) continue;  // another group's bag (workgroup-uniform)
+    for (int bag = 0; bag < nloc; ++bag) {   // `bag` = local index; the batch's bag index is grp + bag * S
         const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
         const int niter = (ntiles + 1) >> 1;
         f32x4 acc[8];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 next_of(bag, tile, ntiles, nb, nt);
                 ISTAMP(0, 0.f);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
-                if (nb < B) {
+                if (nb < nloc) {
                     issue_tile(nb, nt, slot ^ 1);
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this tile landed; the next 8 pieces stay in flight
                 } else {
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 am[r] = (Mm4[r] == -INFINITY) ? 0.f : fast_exp2(Mm4[r] - mn);
                 ao[r] = (Mo4[r] == -INFINITY) ? 0.f : fast_exp2(Mo4[r] - mn);
             }
-            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
+            const size_t slotg = (size_t)(grp + bag * S) * G + tab_get(bag, 6);
             if (w == 0 && g == 0 && i16 < P) {
                 const float Mn = fmaxf(M, Mo);
                 const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
@@ -676,11 +680,19 @@ extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
 static inline int batch_groups(int B) { return B >= 8 ? 8 : (B >= 4 ? 4 : (B >= 2 ? 2 : 1)); }
 // S = bags streamed concurrently (each by workgroups / S workgroups).  Auto: 8 for B >= 8.  Small bags want more: every
 // workgroup should see >= ~8 lock-step iterations (512 rows) of a bag per bag epilogue, so the host may ask for S up to 64.
+// More than 64 bags per launch (round 4, up to kMaxBags = 256): a workgroup's LDS table holds its own <= 64 bags, so S >= B / 64; that
+// also bounds the partial records of a launch (B x 256 / S <= 16 384, the workspace of a 64-bag launch).
+static inline int min_groups(int B) {
+    int m = 1;
+    while (m * bt::kMaxLocal < B) m *= 2;
+    return m;
+}
 static inline int resolve_groups(int B, int groups) {
     int S = groups > 0 ? groups : batch_groups(B);
     int p2 = 1;
-    while (p2 * 2 <= S && p2 * 2 <= B && p2 * 2 <= 64) p2 *= 2;  // power of two, <= B, <= 64
-    return p2;
+    while (p2 * 2 <= S && p2 * 2 <= B && p2 * 2 <= 256) p2 *= 2;  // power of two, <= B, <= 256
+    const int m = min_groups(B);
+    return p2 < m ? m : p2;
 }
 // workgroups of the persistent kernels when `reserved_cus` CUs are to stay free for concurrently running tail /
 // communication kernels (next to a persistent workgroup only kernels with <= 96 VGPRs / 8 KiB LDS get scheduled)
@@ -702,7 +714,7 @@ extern "C" int vlsa_batch_groups(const int64_t* rows_host, int B, int reserved_c
     if (!rows_host || B < 1) return 1;
     int best = 1;
     double best_cost = 1e300;
-    for (int S = 1; S <= 64 && S <= B; S *= 2) {
+    for (int S = min_groups(B); S <= 256 && S <= B; S *= 2) {
         const int Gb = batch_workgroups(S, reserved_cus) / S;
         double worst = 0.0;
         for (int g = 0; g < S; ++g) {
@@ -721,11 +733,12 @@ extern "C" int vlsa_batch_groups(const int64_t* rows_host, int B, int reserved_c
     return best;
 }
 
-extern "C" int vlsa_batch_max_bags(void) { return bt::kMaxBags; }
+extern "C" int vlsa_batch_max_bags(void) { return 64; }                       // every batched entry point (forward, backward, scores)
+extern "C" int vlsa_batch_forward_max_bags(void) { return bt::kMaxBags; }     // the forward streaming launches + their tails
 
 extern "C" size_t vlsa_batch_workspace_bytes(int B, int P, int D) {
-    const size_t G = 256;
-    return ((size_t)B * G * kPStride * 2 + (size_t)B * G * P * D) * sizeof(float) + (size_t)B * 64;
+    const size_t recs = (size_t)(B < bt::kMaxLocal ? B : bt::kMaxLocal) * 256;   // B x partials per bag, see min_groups
+    return (recs * kPStride * 2 + recs * P * D) * sizeof(float) + (size_t)B * 64;
 }
 
 int vlsa_launch_partial_f32_batch(const void* bag_desc, int B, const float* qeff, const float* qmeta, int P, float* pm,

@@ -41,8 +41,8 @@ constexpr int kExchWave = 1024 + 64;             // S partials (one f32x4 per la
 constexpr int kExchGroup = 4 * kExchWave;
 constexpr int kTabOff = kRingBytes + 2 * kExchGroup;
 constexpr int kTabInts = 12;                     // 8 stream-descriptor ints + score pointer (lo, hi) + score pitch + pad
-constexpr int kMaxBags = 64;
-constexpr int kMlOff = kTabOff + kMaxBags * kTabInts * 4;
+constexpr int kMaxLocal = 64;                    // bags per workgroup (LDS table entries); a launch takes up to S x that
+constexpr int kMlOff = kTabOff + kMaxLocal * kTabInts * 4;
 constexpr int kLdsBytes = kMlOff + 8 * 32 * 4;
 constexpr float kThr = 16.0f;
 }  // namespace bf
@@ -83,15 +83,18 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     unsigned char* exch = smem + kRingBytes + rg * kExchGroup;
     int_ma* tab = reinterpret_cast<int_ma*>(smem + kTabOff);
 
-    // ---- bag table: thread t describes this workgroup's rows of bag t -------------------------------------------
-    if (tid < B) {
-        const BagDesc d = bags ? bags[tid] : one;   // bags == null: ONE bag, described in the kernel arguments (single-slide calls)
+    // ---- bag table: the workgroup's own bags grp, grp + S, ... only (local index lb <-> bag grp + lb * S, <= kMaxLocal entries
+    // whatever B is, see k_vlfan_partial_dma_batch); thread lb describes this workgroup's rows of its lb-th bag
+    const int nloc = grp < B ? (B - grp + S - 1) / S : 0;
+    if (tid < nloc) {
+        const int bag_id = grp + tid * S;
+        const BagDesc d = bags ? bags[bag_id] : one;   // bags == null: ONE bag, described in the kernel arguments (single-slide calls)
         // 32-row units (= one lock-step iteration of the two row groups); the workgroup that gets the remainder
         // unit rotates with the bag index so that the extra iterations even out over the batch
         const unsigned long long units = (unsigned long long)((d.N + 31) >> 5);
         const unsigned int uq = (unsigned int)(units / (unsigned int)G), ur = (unsigned int)(units % (unsigned int)G);
-        const unsigned int vb = (unsigned int)((b + (tid / S) * 37) % G);  // virtual workgroup index for this bag
-        const bool mine = (tid % S) == grp;
+        const unsigned int vb = (unsigned int)((b + tid * 37) % G);  // virtual workgroup index for this bag
+        constexpr bool mine = true;
         const unsigned long long ubeg = (unsigned long long)vb * uq + (vb < ur ? vb : ur);
         const long long rbeg = (long long)(ubeg << 5);
         long long rend = (long long)((ubeg + uq + (vb < ur ? 1u : 0u)) << 5);
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
         const unsigned long long addr = reinterpret_cast<unsigned long long>(d.X) + (unsigned long long)rbeg * d.ldx * 4ull;
         int_ma* e = tab + tid * kTabInts;
         if constexpr (kScores) {
-            const RowsDesc sd = sdesc[tid];
+            const RowsDesc sd = sdesc[bag_id];
             const unsigned long long sp = sd.ptr ? reinterpret_cast<unsigned long long>(sd.ptr + rbeg) : 0ull;
             e[8] = (int)(unsigned int)sp;
             e[9] = (int)(sp >> 32);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
             return;
         }
         nb = bag + 1;
-        while (nb < B && tab_get(nb, 5) <= rg) ++nb;
+        while (nb < nloc && tab_get(nb, 5) <= rg) ++nb;
         nt = rg;
     };
 
@@ -181,13 +184,12 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
     int k0 = 0, k1 = 0;  // tiles consumed so far by row group 0 / 1 (for the epilogue's free-slot bookkeeping)
     {
         int fb = 0;  // first own tile of the whole batch
-        while (fb < B && tab_get(fb, 5) <= rg) ++fb;
-        if (fb < B) issue_tile(fb, rg, 0);
+        while (fb < nloc && tab_get(fb, 5) <= rg) ++fb;
+        if (fb < nloc) issue_tile(fb, rg, 0);
     }
 
     
-    for (int bag = 0; bag < B; ++bag) {
-        if (tab_get(bag, 7) == 0) continue;  // another group's bag (workgroup-uniform)
+    for (int bag = 0; bag < nloc; ++bag) {   // `bag` = local index; the batch's bag index is grp + bag * S
         const int nrows = tab_get(bag, 4), ntiles = tab_get(bag, 5);
         const int niter = (ntiles + 1) >> 1;
         f32x4 acc[8];
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                 int nb, nt;
                 next_of(bag, tile, ntiles, nb, nt);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of slot^1's old contents have returned
-                if (nb < B) {
+                if (nb < nloc) {
                     issue_tile(nb, nt, slot ^ 1);
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this tile landed; the next 8 pieces stay in flight
                 } else {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                 am[r] = (Mm4[r] == -INFINITY) ? 0.f : fast_exp2(Mm4[r] - mn);
                 ao[r] = (Mo4[r] == -INFINITY) ? 0.f : fast_exp2(Mo4[r] - mn);
             }
-            const size_t slotg = (size_t)bag * G + tab_get(bag, 6);
+            const size_t slotg = (size_t)(grp + bag * S) * G + tab_get(bag, 6);
             if (w == 0 && g == 0 && i16 < P) {
                 const float Mn = fmaxf(M, Mo);
                 const float fm = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);

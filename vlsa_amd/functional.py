@@ -652,6 +652,11 @@ def vlfan_cross_attention(X: torch.Tensor, Q: torch.Tensor, gated: bool = False,
 _GROUPS_CACHE: dict = {}
 
 
+def forward_max_bags() -> int:
+    """bags one forward launch of the batched path takes (256; the backward kernels and the score / pooling launches take 64)"""
+    return int(nat.load().vlsa_batch_forward_max_bags())
+
+
 def choose_groups(sizes, reserved_cus: int = 0) -> int:
     """Bags the persistent kernels keep in flight for these bag sizes (vlsa_batch_groups: slowest-group model)."""
     key = (tuple(sizes), int(reserved_cus))
@@ -1460,8 +1465,8 @@ class VlfanBatchPlan:
         on the other 224: the HBM-bound streaming kernel loses ~2 %, the step gains ~4 % (0 for a single stream)."""
         lib = nat.load()
         self.reserved_cus = int(reserved_cus)
-        if not (1 <= B <= lib.vlsa_batch_max_bags()):
-            raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_max_bags()}]")
+        if not (1 <= B <= lib.vlsa_batch_forward_max_bags()):
+            raise ValueError(f"batch size {B} outside [1, {lib.vlsa_batch_forward_max_bags()}]")
         self.lib, self.B, self.D, self.P, self.K = lib, B, D, P, K
         self.gated, self.pool, self.identity_head, self.scale = gated, _POOL_CODES[pool], identity_head, float(coattn_scale)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731

@@ -741,7 +741,14 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         Wc = None if W is None else W.detach().float().contiguous()
         bc = None if b is None else b.detach().float().contiguous()
         pwc = None if pw is None else pw.detach().float().reshape(-1).contiguous()
-        step = 64          # bags per persistent launch (the kernels' maximum: fewer launches and host calls per bag)
+        # bags per persistent launch: 64 x 50k-patch bags are 3.3 GB per launch already; slide-sized bags (the reference's TCGA bags:
+        # 2-12k patches) go up to the forward kernels' 256 per launch -- the launch's fixed latency chain and the host calls are
+        # paid per launch (2 798-patch bags: 0.62 -> 0.47 us per bag in the streaming kernel)
+        step = 64
+        if len(flat) > 64:
+            rows = sum(bagset.sizes if bagset is not None else [x.shape[0] for x in flat]) / len(flat)
+            while step < VF.forward_max_bags() and step < len(flat) and 2 * step * rows <= 64 * 50_000:
+                step *= 2
         for i in range(0, len(flat), step):
             chunk = bagset.chunk(i, step) if (bagset is not None and not projected) else flat[i:i + step]
             key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else 0)
