@@ -519,8 +519,8 @@ typedef struct vlsa_tt_rows {
  * (element [s, t] at emb + s * emb_seq_stride + t * emb_tok_stride, unit inner stride) -> text features out [n_seq, out_dim].
  * workspace: vlsa_tt_workspace_bytes(model, rows, save_for_backward) bytes, zeroed once by the caller; with
  * save_for_backward != 0 it keeps every block's inputs for vlsa_tt_backward, which turns dout [n_seq, out_dim] into d prompts_embedding (demb, same strides;
- * demb_floats = size of the whole demb allocation, zeroed here first).  The tower's own weights get no gradient: frozen in
- * every shipped configuration (cfg_vlsa_conch.yaml:69).
+ * demb_floats = size of the whole demb allocation, zeroed here first).  The tower's own weights get no gradient from this call:
+ * frozen in every shipped configuration (cfg_vlsa_conch.yaml:69); vlsa_tt_backward_train below is the training variant.
  */
 /* The products read the weights from "tiled" (MFMA-fragment-major) copies: 1 KB per load instruction instead of 16 rows x 64 B.
  * vlsa_tt_pack_weights writes them into `packed` (vlsa_tt_packed_bytes(model, with_backward) bytes; with_backward also packs
@@ -540,6 +540,19 @@ int vlsa_tt_forward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const 
                     void* stream);
 int vlsa_tt_backward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const void* packed, const float* dout, void* workspace,
                      float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream);
+/*
+ * A tower whose OWN parameters train (`vlsa_txt_encoder_frozen: False`, runner/vlsa_handler.py:131 -- model/conch/transformer.py:191-247
+ * and model/prompt_encoder.py:267-322 under autograd; off in every shipped configuration): vlsa_tt_forward with
+ * save_for_backward == 2 also keeps every block's attention output, and this call produces, next to demb, the gradient of every tower
+ * parameter.  `grads` is a vlsa_tt_model whose pointers are the gradient buffers (same shapes as the parameters: layer[i].in_w
+ * [3 width, width] ..., pos_emb [ctx_len, width], cls_emb [width], lnf_w / lnf_b [width], text_proj [width, out_dim]); they are WRITTEN,
+ * not accumulated (positions of pos_emb no compact row uses get zeros).  `packed` must hold the backward set of the CURRENT weights
+ * (re-pack after every optimizer step).  Four dW = dY^T act products per block over the <= 128 compact rows (k_tt_dw, f32 MFMA),
+ * bias / LayerNorm parameter gradients as fixed-order column sums: deterministic.
+ */
+int vlsa_tt_backward_train(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const void* packed, const float* dout, void* workspace,
+                           float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats,
+                           const vlsa_tt_model* grads, void* stream);
 
 /* Diagnostics used by the GPU tests to pin hardware-layout assumptions (MFMA fragment / LDS tr-read). */
 int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream);

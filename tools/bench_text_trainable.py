@@ -19,4 +19,4 @@ for _ in range(5): fb()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): fb()
 torch.cuda.synchronize()
-print(f"trainable tower (torch route over 101 compact rows), forward + backward incl. all weight gradients: {(time.perf_counter()-t0)/20*1e3:.2f} ms")
+print(f"trainable tower (K = {case[3]} prompts, compact rows + shared prefix; HIP forward + backward incl. ALL weight gradients, vlsa_tt_backward_train): {(time.perf_counter()-t0)/20*1e3:.2f} ms   (torch route until round 4: 14.4 ms)")

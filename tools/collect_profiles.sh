@@ -112,6 +112,9 @@ VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_
 VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-extra > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err
 # round 4: persistent text-tower forward vs launch-per-stage (+ its in-kernel stamps), the whole-row score kernel vs the default
 for m in 1 0; do VLSA_TT_PERSIST=$m python tools/bench_text.py 2>&1 | grep "GPU forward" | sed "s/^/VLSA_TT_PERSIST=$m: /"; done > $O/bench_text_persist.txt
+python tools/bench_text_trainable.py 2>&1 | tail -1 > $O/bench_text_trainable.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/text_train -- python tools/bench_text_trainable.py > /dev/null 2>&1
+cp $(find $O/text_train -name "*kernel_stats.csv" | head -1) $O/text_train_kernel_stats.csv 2>/dev/null
 VLSA_TT_PERSIST=1 python tools/tt_persist_stamps.py 2>&1 | grep -v amdgpu > $O/tt_persist_stamps.txt
 # ---- round 3: backward kernels of the N-sized layers, attention-weights traffic, text tower with the shared prefix
 python tools/kbench_mlp_bwd.py > $O/kbench_mlp_bwd.txt 2>&1

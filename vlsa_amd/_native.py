@@ -134,6 +134,8 @@ _SIGNATURES = {
     "vlsa_tt_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "vlsa_tt_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "vlsa_tt_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "vlsa_tt_backward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                       c_void_p]),
     "vlsa_mlp_bwd_tile_rows": (c_int, [c_int]),
     "vlsa_mlp_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "vlsa_attn_scores_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

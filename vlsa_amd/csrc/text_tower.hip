@@ -783,6 +783,191 @@ __global__ __launch_bounds__(256) void k_tt_scatter(const float* __restrict__ dx
 
 
 // ===============================================================================================================
+// Weight gradients: a tower whose OWN parameters train (`vlsa_txt_encoder_frozen: False`, runner/vlsa_handler.py:131; off in every
+// shipped configuration).  Until round 4 that case ran as torch library GEMMs over the compact rows (14.4 ms forward + backward for
+// K = 12 prompts); now the activations the input-gradient pass already has in the workspace feed four more products per block:
+//   dW[o, i] = sum_m dY[m, o] act[m, i]      for in_proj / out_proj / c_fc / c_proj (and text_projection),
+// i.e. a contraction over the <= 128 compact rows -- the M index is the MFMA k index, so BOTH operands are read as they lie (dY tiled
+// [M_pad, N]: every producer of the pass writes a tiled copy; act row-major or tiled), no transposes.  v_mfma_f32_16x16x4_f32 as
+// everywhere in the tower (fp32 in, fp32 accumulate: bit-equal to an fmaf chain); k-slot g of step s of row block mb contracts row
+// 16 mb + 4 s + g.  Workgroup = 4 waves = 128 outputs x 64 inputs, a wave 32 x 64 (8 accumulator tiles): per step 2 + 4 operand
+// dwords for 8 MFMAs.  Rows >= M are padding that may hold anything: both operands are masked to zero there.
+// The bias gradient (column sums of dY) falls out of the first operand in the workgroups of input tile 0.
+enum { DW_ROWS = 0, DW_TILED = 2 };
+struct DwArgs {
+    const float* A;   // tiled [M_pad, N]: gradient w.r.t. the product's output
+    const float* B;   // the product's input: row-major [.., ldb] (DW_ROWS) or tiled [M_pad, K] (DW_TILED)
+    float* dW;        // row-major [N, K]
+    float* dbias;     // [N] or null
+    int N, K, M, ldb;
+};
+template <int BSRC>
+__global__ __launch_bounds__(256) void k_tt_dw(const DwArgs p) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int o0 = blockIdx.y * 128 + w * 32, j0 = blockIdx.x * 64;
+    const int NT = p.N >> 4, KT = p.K >> 4;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float asum[2] = {0.f, 0.f};
+    const int in_tile = ((i >> 2) * 16) * 4 + (i & 3);       // tiled operand: element (row, col 16 c + i) at tile + in_tile + 4 (row & 15)
+    const int nmb = (p.M + 15) >> 4;
+    // The 24 operand dwords of a row block are loaded one block AHEAD of their MFMAs (two register sets).  Every load is
+    // unconditional -- rows >= M read row M - 1 instead and the FIRST operand is zeroed by a select (0 x finite = 0) -- so the loop
+    // body is straight-line code: with per-load branches (or `if (mb + 1 < nmb)` around the prefetch) every basic-block edge became an
+    // `s_waitcnt vmcnt(0)` and the kernel ran at 25-30 us for 1 us of matrix-pipe work.
+    float a[2][4][2], b[2][4][4];
+    auto load = [&](int mb, float (&av)[4][2], float (&bv)[4][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = 16 * mb + 4 * s + g;
+            const int mc = m < p.M ? m : p.M - 1, mcb = mc >> 4, mcr = mc & 15;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float v = p.A[((size_t)mcb * NT + ((o0 >> 4) + t)) * 256 + in_tile + 4 * mcr];
+                av[s][t] = m < p.M ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                bv[s][u] = BSRC == DW_TILED ? p.B[((size_t)mcb * KT + ((j0 >> 4) + u)) * 256 + in_tile + 4 * mcr]
+                                            : p.B[(size_t)mc * p.ldb + j0 + 16 * u + i];
+        }
+    };
+    auto mac = [&](const float (&av)[4][2], const float (&bv)[4][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                asum[t] += av[s][t];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[s][u], acc[t][u], 0, 0, 0);
+            }
+        }
+    };
+    load(0, a[0], b[0]);
+    for (int mb = 0; mb < nmb; mb += 2) {       // (a block index past the end loads row M - 1 and contributes zeros)
+        load(mb + 1, a[1], b[1]);
+        mac(a[0], b[0]);
+        load(mb + 2, a[0], b[0]);
+        mac(a[1], b[1]);
+    }
+    // result lane (j = i, g) holds D[out 4 g + v][in j]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) p.dW[(size_t)(o0 + 16 * t + 4 * g + v) * p.K + j0 + 16 * u + i] = acc[t][u][v];
+    if (p.dbias && blockIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float s = asum[t];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (g == 0) p.dbias[o0 + 16 * t + i] = s;
+        }
+    }
+}
+
+// y[row] = LayerNorm(x[row]) * gamma + beta (row-major), stats[row] = (mean, rstd): the input of a product whose weight gradient is
+// wanted (the forward's fused-LayerNorm products never store it) and the statistics the gamma / beta gradients need.  Wave per row.
+__global__ __launch_bounds__(256) void k_tt_ln_rows(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats,
+                                                   int d, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nslot = d >> 6;
+    float xv[kLnSlots];
+#pragma unroll
+    for (int k = 0; k < kLnSlots; ++k)
+        if (k < nslot) xv[k] = x[(size_t)row * d + lane + 64 * k];
+    float mean, rstd;
+    ln_stats(xv, nslot, d, mean, rstd);
+#pragma unroll
+    for (int k = 0; k < kLnSlots; ++k)
+        if (k < nslot && y) y[(size_t)row * d + lane + 64 * k] = fmaf((xv[k] - mean) * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+// y = gelu(h) over the first `rows` rows of a row-major [.., C] matrix: the input of c_proj, which the forward only keeps as h_pre
+// (evaluating erf inside the weight-gradient product would repeat it 24 times per element: 37 us per block instead of 13 + 3)
+__global__ __launch_bounds__(256) void k_tt_gelu_rows(const float* __restrict__ h, float* __restrict__ y, size_t n4) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(h)[idx];
+    reinterpret_cast<f32x4*>(y)[idx] = f32x4{gelu(v[0]), gelu(v[1]), gelu(v[2]), gelu(v[3])};
+}
+
+// dgamma[c] = sum_n dy[n, c] xhat[row(n), c], dbeta[c] = sum_n dy[n, c] over n < count; row(n) = n, or the CLS row of prompt n
+// (seq_row0[n + 1] - 1) for ln_final.  Workgroup = 32 columns x 8 row groups (row n -> group n % 8), partial sums folded through LDS in
+// a fixed order (deterministic).  (The first version -- a thread per column walking all rows -- took 29 us per call.)
+__global__ __launch_bounds__(256) void k_tt_ln_param_bwd(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ stats, const int* __restrict__ seq_row0, int count,
+                                                        int d, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float sg = 0.f, sb = 0.f;
+    if (c < d)
+        for (int n = rgp; n < count; n += 8) {
+            const int row = seq_row0 ? seq_row0[n + 1] - 1 : n;
+            const float g = dy[(size_t)n * d + c];
+            sg = fmaf(g, (x[(size_t)row * d + c] - stats[2 * row]) * stats[2 * row + 1], sg);
+            sb += g;
+        }
+    red[0][rgp][cl] = sg;
+    red[1][rgp][cl] = sb;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[which][k][cl];
+        if (c < d) (which ? dbeta : dgamma)[c] = t;
+    }
+}
+
+// d positional_embedding[p] = sum of dx0 over the compact rows at position p (block p < ctx_len; positions no row uses get zeros),
+// d cls_emb = sum over the CLS rows (block ctx_len).  model/prompt_encoder.py:283-292.  The matching rows are listed first (all
+// threads test rows in parallel, wave 0 compacts them in row order), then summed in that order.
+constexpr int kPosRowsMax = 1024;
+__global__ __launch_bounds__(256) void k_tt_pos_cls_bwd(const float* __restrict__ dx, const int* __restrict__ row_pos,
+                                                       const int* __restrict__ row_src, int M, int d, int ctx_len,
+                                                       float* __restrict__ dpos, float* __restrict__ dcls) {
+    __shared__ unsigned char hit[kPosRowsMax];
+    __shared__ short rows[kPosRowsMax];
+    __shared__ int nrows;
+    const int p = blockIdx.x;
+    for (int m = threadIdx.x; m < M; m += 256) hit[m] = (p < ctx_len ? row_pos[m] == p : row_src[m] < 0) ? 1 : 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int base = 0; base < M; base += 64) {
+            const int m = base + threadIdx.x;
+            const bool h = m < M && hit[m];
+            const unsigned long long mask = __ballot(h);
+            if (h) rows[n + __popcll(mask & ((1ull << threadIdx.x) - 1ull))] = (short)m;
+            n += __popcll(mask);
+        }
+        if (threadIdx.x == 0) nrows = n;
+    }
+    __syncthreads();
+    float* out = p < ctx_len ? dpos + (size_t)p * d : dcls;
+    const int n = nrows;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s += dx[(size_t)rows[k] * d + c];
+        out[c] = s;
+    }
+}
+
+// ===============================================================================================================
 // Persistent forward (round 4): the 12 blocks of the tower as ONE launch.
 //
 // Why: a forward pass over K = 12 rank prompts is 101 compact rows = 7 row tiles; every product of a block is 5 - 13 us of which
@@ -1203,12 +1388,14 @@ inline const float* packed_proj(const float* set, const Shape& s) { return set +
 
 // ---- workspace (floats).  Per-layer region (kept for backward when save != 0, else one region reused):
 //      x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]     (all row-major)
-inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 9; }
+//      | attn [M_pad, d] tiled: the attention output, kept per block only with save == 2 (its out_proj weight gradient needs it)
+inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 10; }
 struct Scratch {   // behind the layer regions; *_t = tiled
     float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
     float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *dattn, *dqkv_t;                    // backward
     float* pfx;             // shared prefix: per (block, head) partial dK / dV of the prefix rows [(n_seq + 1)][heads][L][128]
     unsigned int* cnt;      // [heads] tickets (zero between launches: the workspace is zeroed once by the caller)
+    float *lnout, *lnstats; // weight gradients: LayerNorm output [M_pad, d] row-major and (mean, rstd) per row of the block at hand
     float* qkv_alt;         // persistent forward without saved activations: qkv of the odd blocks (see k_tt_forward_persistent)
     unsigned int* pctr;     // persistent forward: [kPMaxLayers][kPStages][kPMaxRT] task counters | 8 status words
 };
@@ -1216,7 +1403,7 @@ constexpr size_t kPCtrWords = (size_t)kPMaxLayers * kPStages * kPMaxRT;
 inline size_t pfx_floats(const Shape& s) { return (size_t)(s.n_seq + 1) * s.heads * (s.L > 0 ? s.L : 0) * 128 + 64; }
 inline size_t scratch_floats(const Shape& s) {
     return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s)
-           + (size_t)s.M_pad * 3 * s.d + kPCtrWords + 8 + 2 * (size_t)kPMaxLayers * kPStages * 6 + 2;
+           + (size_t)s.M_pad * 3 * s.d + kPCtrWords + 8 + 2 * (size_t)kPMaxLayers * kPStages * 6 + 2 + (size_t)s.M_pad * (s.d + 2);
 }
 inline Scratch scratch_of(float* p, const Shape& s) {
     const size_t md = (size_t)s.M_pad * s.d;
@@ -1238,6 +1425,8 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     c.dpool = p; p += (size_t)s.ns_pad * s.d;
     c.feat = p; p += (size_t)s.ns_pad * s.out_dim;
     c.dout_t = p; p += (size_t)s.ns_pad * s.out_dim;
+    c.lnout = p; p += (size_t)s.M_pad * s.d;
+    c.lnstats = p; p += (size_t)s.M_pad * 2;
     c.cnt = reinterpret_cast<unsigned int*>(p); p += 64;
     c.pfx = p; p += pfx_floats(s) - 64;
     c.qkv_alt = p; p += (size_t)s.M_pad * 3 * s.d;
@@ -1435,7 +1624,7 @@ extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_
 extern "C" int64_t vlsa_tt_status_offset(const vlsa_tt_model* m, const vlsa_tt_rows* r, int save_for_backward) {
     Shape s;
     if (!r || !shape_of(m, r, s)) return -1;
-    if (!persist_supported(s, r)) return -1;         // the launch-per-stage path has no in-kernel waits
+    if (save_for_backward == 2 || !persist_supported(s, r)) return -1;         // the launch-per-stage path has no in-kernel waits
     const size_t nreg = save_for_backward ? (size_t)s.layers : 1;
     float* base = nullptr;
     const Scratch c = scratch_of(base + nreg * layer_floats(s), s);
@@ -1460,7 +1649,8 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), c.xin_t, d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
                        r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
     TT_LAUNCHED();
-    const bool persist = persist_supported(s, r);
+    const bool keep_attn = save_for_backward == 2;          // a training tower: the attention output of every block stays
+    const bool persist = !keep_attn && persist_supported(s, r);
     if (persist) {
         PArgs a{};
         a.ws = ws; a.wset = wset;
@@ -1497,6 +1687,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         float* x_mid = qkv + (size_t)Mp * 3 * d;
         float* h_pre = x_mid + (size_t)Mp * d;
         float* x_next = (L + 1 < s.layers) ? (save_for_backward ? region(L + 1) : x_in) : c.x_final;
+        float* attn_t = keep_attn ? h_pre + (size_t)Mp * 4 * d : c.attn_t;
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
         {
             GemmArgs a = gemm_args(c.xin_t, pw.in_w, 3 * d, d);
@@ -1514,11 +1705,11 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             else if (Mp % 32 == 0 && ((s.M + 31) / 32) * nt <= 256) TT_TRY((launch_gemm_wide<2, 4, PRO_LN, 12>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), 0, st, qkv, 3 * d, c.attn_t, r->seq_row0,
+        hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), 0, st, qkv, 3 * d, attn_t, r->seq_row0,
                            r->cls_keep, s.heads, d, s.n_seq, s.L);
         TT_LAUNCHED();
         {
-            GemmArgs a = gemm_args(c.attn_t, pw.out_w, d, d);
+            GemmArgs a = gemm_args(attn_t, pw.out_w, d, d);
             a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = c.xmid_t; a.epi = EPI_BIAS | EPI_RESID;
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
@@ -1553,8 +1744,23 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     return VLSA_OK;
 }
 
-extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* dout, void* workspace,
-                                float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream) {
+namespace {
+// dW = dY^T act (+ dbias = column sums of dY) for one product; act row-major (optionally through gelu) or tiled
+int launch_dw(int bsrc, const float* dY_t, const float* act, int ldb, float* dW, float* dbias, int N, int K, int M, hipStream_t st) {
+    if (!dW) return VLSA_OK;
+    if ((N % 128) || (K % 64)) return VLSA_EUNSUPPORTED;
+    const DwArgs a{dY_t, act, dW, dbias, N, K, M, ldb};
+    const dim3 grid(K / 64, N / 128);
+    if (bsrc == DW_TILED) hipLaunchKernelGGL(k_tt_dw<DW_TILED>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_tt_dw<DW_ROWS>, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// gr != null: ALSO the gradients of the tower's own parameters, written (not accumulated) into the buffers gr points at -- a
+// vlsa_tt_model whose pointers are the gradient tensors, each shaped like the parameter it belongs to; the forward must have run
+// with save_for_backward == 2.
+int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* dout, void* workspace, float* demb,
+                int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, const vlsa_tt_model* gr, void* stream) {
     Shape s;
     if (!r || !shape_of(m, r, s)) return VLSA_EINVAL;
     if (!packed || !dout || !workspace || !demb || demb_floats < 0) return VLSA_EINVAL;
@@ -1576,6 +1782,17 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
     hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.dpool, c.x_final, r->row_seq, r->row_src, m->lnf_w, c.dxa,
                        c.dxa_t, d, s.M, Mp);
     TT_LAUNCHED();
+    if (gr) {
+        if (!gr->layer || !gr->pos_emb || !gr->cls_emb || !gr->lnf_w || !gr->lnf_b || !gr->text_proj || (d % 64) || d > 64 * kLnSlots)
+            return VLSA_EINVAL;
+        if (s.M > kPosRowsMax) return VLSA_EUNSUPPORTED;
+        // text_projection [d, out_dim]: pooled^T dout;  ln_final: gamma / beta from d pooled and the CLS rows of x_final
+        TT_TRY(launch_dw(DW_ROWS, c.pooled_t, dout, s.out_dim, (float*)gr->text_proj, nullptr, d, s.out_dim, s.n_seq, st));
+        hipLaunchKernelGGL(k_tt_ln_rows, dim3((s.M + 3) / 4), dim3(256), 0, st, c.x_final, m->lnf_w, m->lnf_b, (float*)nullptr, c.lnstats, d, s.M);
+        hipLaunchKernelGGL(k_tt_ln_param_bwd, dim3((d + 31) / 32), dim3(256), 0, st, c.dpool, c.x_final, c.lnstats, r->seq_row0, s.n_seq, d,
+                           (float*)gr->lnf_w, (float*)gr->lnf_b);
+        TT_LAUNCHED();
+    }
     static DeviceOnce once;
     const size_t attn_lds = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
     if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds);
@@ -1597,13 +1814,32 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
                 TT_TRY((launch_gemm_g<2, 4, PRO_NONE, 12, 4>(a, Mp, st)));
             else TT_TRY((launch_gemm_wide<3, 4, PRO_NONE, 12>(a, Mp, st)));
         }
+        const vlsa_tt_layer* g = gr ? &gr->layer[L] : nullptr;
+        const float* attn_t = h_pre + (size_t)Mp * 4 * d;      // (kept by the forward with save == 2)
+        if (g) {   // c_proj [d, 4d]: dx_out^T gelu(h_pre);  c_fc [4d, d]: d h_pre^T ln_2(x_mid)
+            const size_t n4 = (size_t)s.M * d;               // s.M rows x 4 d columns in float4s; c.hact_t: forward scratch, free here
+            hipLaunchKernelGGL(k_tt_gelu_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, h_pre, c.hact_t, n4);
+            TT_LAUNCHED();
+            TT_TRY(launch_dw(DW_ROWS, c.dxa_t, c.hact_t, 4 * d, (float*)g->proj_w, (float*)g->proj_b, d, 4 * d, s.M, st));
+            hipLaunchKernelGGL(k_tt_ln_rows, dim3((s.M + 3) / 4), dim3(256), 0, st, x_mid, w.ln2_w, w.ln2_b, c.lnout, c.lnstats, d, s.M);
+            TT_LAUNCHED();
+            TT_TRY(launch_dw(DW_ROWS, c.dh_t, c.lnout, d, (float*)g->fc_w, (float*)g->fc_b, 4 * d, d, s.M, st));
+        }
         {   // d ln_2 out = d h_pre @ W_fc
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
             a.Y = c.da; a.ldy = d;
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
+        if (g) {
+            hipLaunchKernelGGL(k_tt_ln_param_bwd, dim3((d + 31) / 32), dim3(256), 0, st, c.da, x_mid, c.lnstats, (const int*)nullptr, s.M, d,
+                               (float*)g->ln2_w, (float*)g->ln2_b);
+            TT_LAUNCHED();
+        }
         launch_ln_bwd(c.da, x_mid, w.ln2_w, c.dxa, c.dxb, c.dxb_t, d, Mp, st);
         TT_LAUNCHED();
+        if (g) {   // out_proj [d, d]: dx_mid^T attention output
+            TT_TRY(launch_dw(DW_TILED, c.dxb_t, attn_t, 0, (float*)g->out_w, (float*)g->out_b, d, d, s.M, st));
+        }
         // attention branch
         {   // d attn = dx_mid @ W_out
             GemmArgs a = gemm_args(c.dxb_t, pw.out_w, d, d);
@@ -1618,10 +1854,36 @@ extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, c
             a.Y = c.da; a.ldy = d;
             TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
+        if (g) {   // in_proj [3d, d]: dqkv^T ln_1(x_in);  ln_1 gamma / beta
+            hipLaunchKernelGGL(k_tt_ln_rows, dim3((s.M + 3) / 4), dim3(256), 0, st, x_in, w.ln1_w, w.ln1_b, c.lnout, c.lnstats, d, s.M);
+            TT_LAUNCHED();
+            TT_TRY(launch_dw(DW_ROWS, c.dqkv_t, c.lnout, d, (float*)g->in_w, (float*)g->in_b, 3 * d, d, s.M, st));
+            hipLaunchKernelGGL(k_tt_ln_param_bwd, dim3((d + 31) / 32), dim3(256), 0, st, c.da, x_in, c.lnstats, (const int*)nullptr, s.M, d,
+                               (float*)g->ln1_w, (float*)g->ln1_b);
+            TT_LAUNCHED();
+        }
         launch_ln_bwd(c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp, st);
+        TT_LAUNCHED();
+    }
+    if (gr) {   // positional_embedding [ctx_len, d] and cls_emb [d] from the gradient of the embedded rows
+        hipLaunchKernelGGL(k_tt_pos_cls_bwd, dim3(m->ctx_len + 1), dim3(256), 0, st, c.dxa, r->row_pos, r->row_src, s.M, d, m->ctx_len,
+                           (float*)gr->pos_emb, (float*)gr->cls_emb);
         TT_LAUNCHED();
     }
     if (hipMemsetAsync(demb, 0, (size_t)demb_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     hipLaunchKernelGGL(k_tt_scatter, dim3(s.M), dim3(256), 0, st, c.dxa, d, demb, emb_seq_stride, emb_tok_stride, r->row_seq, r->row_src, s.M);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+}  // namespace
+
+extern "C" int vlsa_tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* dout, void* workspace,
+                                float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride, int64_t demb_floats, void* stream) {
+    return tt_backward(m, r, packed, dout, workspace, demb, emb_seq_stride, emb_tok_stride, demb_floats, nullptr, stream);
+}
+
+extern "C" int vlsa_tt_backward_train(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packed, const float* dout,
+                                      void* workspace, float* demb, int64_t emb_seq_stride, int64_t emb_tok_stride,
+                                      int64_t demb_floats, const vlsa_tt_model* grads, void* stream) {
+    if (!grads) return VLSA_EINVAL;
+    return tt_backward(m, r, packed, dout, workspace, demb, emb_seq_stride, emb_tok_stride, demb_floats, grads, stream);
 }

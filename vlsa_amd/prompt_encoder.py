@@ -9,7 +9,8 @@ positions that can reach the pooled CLS token are evaluated (a 13-row problem pe
 the kernel file), f32 MFMA throughout.  Differentiable w.r.t. ``prompts_embedding`` (the learnable context / rank
 embeddings of the prompt learner); the tower itself is frozen in every shipped configuration
 (``vlsa_txt_encoder_frozen: True``, cfg_vlsa_conch.yaml:69).  A tower whose own parameters require grad
-(``vlsa_txt_encoder_frozen: False``) takes a differentiable torch route over the same compact rows (``_forward_trainable``).
+(``vlsa_txt_encoder_frozen: False``) runs the same kernels plus the weight-gradient products of ``vlsa_tt_backward_train``
+(``_TextTowerTrainFn``; until round 4 that case was a torch route).
 """
 from __future__ import annotations
 
@@ -120,7 +121,7 @@ class _RowPlan:
         self.c = _TTRows(self.n_seq, self.M, self.M_pad, self.max_len, self.row_seq.data_ptr(), self.row_pos.data_ptr(),
                          self.row_src.data_ptr(), self.seq_row0.data_ptr(), self.cls_keep.data_ptr(), self.prefix_len)
         self.ws = None    # inference workspace (no activations kept), allocated on first use
-        self._rp, self._dense = rp, None
+        self._rp = rp
         self._status = []  # (pinned int32[4], event): status words of persistent launches on their way to the host
 
     def watch_status(self, words: torch.Tensor):
@@ -149,39 +150,6 @@ class _RowPlan:
                                       "not all of its workgroups were resident (another kernel held CUs).  Its outputs are void; "
                                       "VLSA_TT_PERSIST=0 selects the launch-per-stage path")
         self._status = keep
-
-    def dense_tables(self, device):
-        """For the trainable-tower route (torch ops over the same compact rows): the additive attention mask [M, M] (0 / -inf)
-        that restates which rows a row sees -- prefix rows: causal among themselves; a prompt's token rows: the prefix and the
-        prompt's own rows up to their position; a CLS row: the rows flagged in cls_keep (model/prompt_encoder.py:245-252,
-        299-303) -- plus index tensors for the row gather and the CLS rows."""
-        if self._dense is not None and self._dense[0].device == torch.device(device):
-            return self._dense
-        rp, M, L = self._rp, self.M, self.prefix_len
-        seq, pos, src, keep = rp["row_seq"], rp["row_pos"], rp["row_src"], rp["cls_keep"]
-        allow = torch.zeros(M, M, dtype=torch.bool)
-        for i in range(M):
-            i_prefix, i_cls = i < L, src[i] < 0
-            for j in range(M):
-                j_prefix = j < L
-                if i_prefix:
-                    ok = j_prefix and j <= i
-                elif j_prefix:
-                    ok = bool(keep[j]) if i_cls else True
-                elif seq[j] != seq[i]:
-                    ok = False
-                elif i_cls:
-                    ok = bool(keep[j])
-                else:
-                    ok = src[j] >= 0 and pos[j] <= pos[i]
-                allow[i, j] = ok
-        mask = torch.zeros(M, M).masked_fill_(~allow, float("-inf")).to(device)
-        idx = lambda v: torch.tensor(v, dtype=torch.long, device=device)   # noqa: E731
-        tok_rows = [r for r in range(M) if src[r] >= 0]
-        cls_rows = [r for r in range(M) if src[r] < 0]
-        self._dense = (mask, idx(tok_rows), idx([seq[r] for r in tok_rows]), idx([src[r] for r in tok_rows]), idx(cls_rows),
-                       idx(pos[:M]))
-        return self._dense
 
 
 class _TextTowerFn(torch.autograd.Function):
@@ -235,6 +203,71 @@ class _TextTowerFn(torch.autograd.Function):
                   "vlsa_tt_backward")
         ctx.ws = ctx.packed = None
         return demb, None, None
+
+
+class _TextTowerTrainFn(torch.autograd.Function):
+    """The tower with its OWN parameters under training (``vlsa_txt_encoder_frozen: False``, runner/vlsa_handler.py:131; off in
+    every shipped configuration).  Same kernels as ``_TextTowerFn``; the forward keeps every block's attention output
+    (``save_for_backward == 2``) and the backward is ONE C call (``vlsa_tt_backward_train``) that writes d prompts_embedding and
+    the gradient of every tower parameter -- four dW = dY^T act products per block over the compact rows on the f32 matrix pipe,
+    bias / LayerNorm gradients as fixed-order column sums (vlsa_amd/csrc/text_tower.hip: k_tt_dw).  ``tensors`` = the tower's
+    parameters in ``_tower_tensors`` order (autograd inputs: their ``.grad`` is what the optimizer reads)."""
+
+    @staticmethod
+    def forward(ctx, emb, enc, plan, *tensors):
+        lib = nat.load()
+        model = enc._c_model(emb.device)
+        nbytes = lib.vlsa_tt_workspace_bytes(ctypes.byref(model), ctypes.byref(plan.c), 2)
+        if nbytes == 0:
+            raise VlsaNativeError("text tower: unsupported shape (width % 128, width <= 768, 64 features per head, <= 128 rows per prompt)")
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=emb.device)
+        x = emb.detach()
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            x = x.float().contiguous()
+        out = torch.empty(plan.n_seq, enc.output_dim, dtype=torch.float32, device=emb.device)
+        s = ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)
+        packed = enc._packed_weights(emb.device, with_backward=True)       # of the CURRENT weights (keyed on their versions)
+        nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(packed.data_ptr()),
+                                      ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), 2,
+                                      ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
+        ctx.ws, ctx.plan, ctx.enc, ctx.shape, ctx.packed = ws, plan, enc, tuple(emb.shape), packed
+        ctx.versions = [t._version for t in tensors]
+        ctx.keep = x
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = nat.load()
+        enc, plan = ctx.enc, ctx.plan
+        ts = enc._tower_tensors()
+        if [t._version for t in ts] != ctx.versions:
+            raise RuntimeError("text tower: a weight was modified in place between forward and backward (the packed copies the "
+                               "backward reads belong to the forward's weights)")
+        model = enc._c_model(dout.device)
+        g = dout.detach().float().contiguous()
+        demb = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        # one allocation for all parameter gradients, handed out as views shaped like the parameters; the C struct mirrors _c_model
+        sizes = [t.numel() for t in ts]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dout.device)
+        grads, o = [], 0
+        for t, n in zip(ts, sizes):
+            grads.append(flat[o:o + n].view(t.shape))
+            o += n
+        nl = (len(ts) - 5) // 12
+        arr = (_TTLayer * nl)()
+        for i in range(nl):
+            for j, (name, _) in enumerate(_TTLayer._fields_):
+                setattr(arr[i], name, grads[5 + 12 * i + j].data_ptr())
+        gm = _TTModel(model.width, model.heads, model.layers, model.out_dim, model.ctx_len, arr, grads[0].data_ptr(), grads[1].data_ptr(),
+                      grads[2].data_ptr(), grads[3].data_ptr(), grads[4].data_ptr())
+        s = ctypes.c_void_p(torch.cuda.current_stream(dout.device).cuda_stream)
+        nat.check(lib.vlsa_tt_backward_train(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(ctx.packed.data_ptr()),
+                                             ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(ctx.ws.data_ptr()),
+                                             ctypes.c_void_p(demb.data_ptr()), demb.stride(0), demb.stride(1), demb.numel(),
+                                             ctypes.byref(gm), s), "vlsa_tt_backward_train")
+        ctx.ws = ctx.packed = None
+        need = ctx.needs_input_grad
+        return (demb if need[0] else None, None, None) + tuple(gr if need[3 + i] else None for i, gr in enumerate(grads))
 
 
 class CONCHPromptEncoder(nat.TransientCaches, nn.Module):
@@ -435,34 +468,5 @@ class CONCHPromptEncoder(nat.TransientCaches, nn.Module):
                                   "oracle under oracle/ is test infrastructure)")
         plan = self._plan(prompts_pseudo_tokens, x.device, shared_prefix_len if prompts_text is None else 0)
         if torch.is_grad_enabled() and any(t.requires_grad for t in self._tower_tensors()):
-            return self._forward_trainable(x, plan)      # vlsa_txt_encoder_frozen: False
+            return _TextTowerTrainFn.apply(x, self, plan, *self._tower_tensors())      # vlsa_txt_encoder_frozen: False
         return _TextTowerFn.apply(x, self, plan)
-
-    def _forward_trainable(self, emb, plan):
-        """A tower whose own weights train (``vlsa_txt_encoder_frozen: False``, runner/vlsa_handler.py:131; off in every shipped
-        configuration): the HIP kernels produce d prompts_embedding only, so this case runs as differentiable torch ops
-        (library GEMMs) over the SAME compact rows -- 13 rows per rank prompt instead of 128, shared prefix once --
-        model/conch/transformer.py:191-247 restated on [M, width] rows with the plan's dense mask."""
-        ts = self._tower_tensors()
-        for t in ts:
-            if not t.is_cuda or t.device != emb.device:
-                raise VlsaNativeError("the text tower runs on the MI355X only: its weights must be on the device of the prompts")
-        mask, tok_rows, tok_seq, tok_src, cls_rows, pos = plan.dense_tables(emb.device)
-        d, H = self.positional_embedding.shape[1], self.heads
-        M = plan.M
-        x = torch.zeros(M, d, dtype=torch.float32, device=emb.device)
-        x = x.index_put((tok_rows,), emb.float()[tok_seq, tok_src])
-        x = x.index_put((cls_rows,), self.cls_emb.float().expand(cls_rows.numel(), d))
-        x = x + self.positional_embedding[pos]
-        F = torch.nn.functional
-        for blk in self.transformer.resblocks:
-            h = F.layer_norm(x, (d,), blk.ln_1.weight, blk.ln_1.bias, 1e-5)
-            qkv = h @ blk.attn.in_proj_weight.t() + blk.attn.in_proj_bias
-            q, k, v = (t.reshape(M, H, d // H).transpose(0, 1) for t in qkv.chunk(3, dim=-1))        # [H, M, 64]
-            att = torch.softmax(q @ k.transpose(1, 2) * (d // H) ** -0.5 + mask, dim=-1) @ v          # [H, M, 64]
-            x = x + att.transpose(0, 1).reshape(M, d) @ blk.attn.out_proj.weight.t() + blk.attn.out_proj.bias
-            h = F.layer_norm(x, (d,), blk.ln_2.weight, blk.ln_2.bias, 1e-5)
-            h = F.gelu(h @ blk.mlp.c_fc.weight.t() + blk.mlp.c_fc.bias)
-            x = x + h @ blk.mlp.c_proj.weight.t() + blk.mlp.c_proj.bias
-        pooled = F.layer_norm(x[cls_rows], (d,), self.ln_final.weight, self.ln_final.bias, 1e-5)
-        return pooled @ self.text_projection
