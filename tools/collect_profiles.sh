@@ -113,6 +113,10 @@ VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-extr
 # round 4: persistent text-tower forward vs launch-per-stage (+ its in-kernel stamps), the whole-row score kernel vs the default
 for m in 1 0; do VLSA_TT_PERSIST=$m python tools/bench_text.py 2>&1 | grep "GPU forward" | sed "s/^/VLSA_TT_PERSIST=$m: /"; done > $O/bench_text_persist.txt
 python tools/bench_text_trainable.py 2>&1 | tail -1 > $O/bench_text_trainable.txt
+pmc tt_fetch FETCH_SIZE -- python tools/run_text.py
+pmc tt_write WRITE_SIZE -- python tools/run_text.py
+mkdir -p $O/pmc_tt && cp -r $O/pmc_tt_fetch $O/pmc_tt_write $O/pmc_tt/ 2>/dev/null
+python tools/run_text.py summarise $O/pmc_tt > $O/pmc_text_tower.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/text_train -- python tools/bench_text_trainable.py > /dev/null 2>&1
 cp $(find $O/text_train -name "*kernel_stats.csv" | head -1) $O/text_train_kernel_stats.csv 2>/dev/null
 VLSA_TT_PERSIST=1 python tools/tt_persist_stamps.py 2>&1 | grep -v amdgpu > $O/tt_persist_stamps.txt

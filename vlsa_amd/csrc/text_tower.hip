@@ -155,10 +155,20 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     int ntile, mg;
     {
         const int b = blockIdx.x;
-        if (p.xcd_map) {   // the MG workgroups that share a weight tile run on one XCD (block b -> XCD b % 8): W comes from ITS L2
+        // the MG workgroups that share a weight tile run on one XCD (block b -> XCD b % 8): W comes from ITS L2.  A column-tile count
+        // that is no multiple of 8 maps its whole rounds of 8 tiles that way and spreads the last NT % 8 tiles linearly (round 4: the QKV
+        // product, 36 tiles, ran unmapped until the tower's FETCH_SIZE pass showed 52.6 MB per launch for 7.1 MB of weights -- each of a
+        // tile's 7 row-group workgroups pulled it into a different XCD's L2, profiles/r04_pmc_text_tower.json; padding to 40 tile slots
+        // instead put 35 workgroups on four XCDs' 32 CUs and cost 40 us per pass)
+        const int NTf = (N / (16 * NTW)) & ~7;
+        if (p.xcd_map && b < NTf * MG) {
             const int j = b >> 3;
             ntile = (j / MG) * 8 + (b & 7);
             mg = j % MG;
+        } else if (p.xcd_map) {
+            const int rr = b - NTf * MG;
+            ntile = NTf + rr / MG;
+            mg = rr % MG;
         } else {
             ntile = b / MG;
             mg = b % MG;
@@ -1449,7 +1459,7 @@ int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
     a.MG = a.M_real > 0 ? (a.M_real + 16 * MT - 1) / (16 * MT) : M_pad / (16 * MT);
     if (a.MG * 16 * MT > M_pad) a.MG = M_pad / (16 * MT);
     const int NT = a.N / (16 * NTW);
-    a.xcd_map = (NT % 8 == 0) ? 1 : 0;
+    a.xcd_map = NT >= 8 ? 1 : 0;      // XCD-aware block -> tile map (whole rounds of 8 tiles; the rest linear)
     size_t lds = (size_t)NW * MT * NTW * 4 * 64 * sizeof(float);
     if (PRO == PRO_LN && lds < (size_t)(1024 + 2 * a.K) * sizeof(float)) lds = (size_t)(1024 + 2 * a.K) * sizeof(float);
     if (lds > 64 * 1024) {
