@@ -40,7 +40,12 @@ case = TC.RANK_CASES[0]
 inp = TH.rank_case_inputs(case)
 enc = build_encoder(case[1], case[2])
 pl = build_learner(case, inp).cuda()
-with torch.no_grad():
+if "--bwd" in sys.argv:              # forward + backward passes (d prompts; the tower frozen)
     for _ in range(PASSES + WARM):
-        enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=pl.shared_prefix_len)
+        pl.zero_grad(set_to_none=True)
+        enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=pl.shared_prefix_len).sum().backward()
+else:
+    with torch.no_grad():
+        for _ in range(PASSES + WARM):
+            enc(prompts_embedding=pl(), prompts_pseudo_tokens=pl.pseudo_sentence_tokens, shared_prefix_len=pl.shared_prefix_len)
 torch.cuda.synchronize()
