@@ -7,15 +7,24 @@
 
 namespace vlsa {
 
-__global__ __launch_bounds__(64) void k_surv_loss(const float* __restrict__ x, const int64_t* __restrict__ t_,
+// Per-sample K-vectors live in LDS, [vector][k][thread] (conflict free): as dynamically indexed private arrays they sat in scratch
+// memory and the launch took 18.6 us for 32 samples x 12 bins (round 4: profiles/r04_step_kernel_stats.csv).  Same serial order per
+// sample as before: results are bit-identical.
+constexpr int kLossThreads = 32;
+struct LossVec {
+    float* p;
+    __device__ __forceinline__ float& operator[](int k) const { return p[k * kLossThreads]; }
+};
+__global__ __launch_bounds__(kLossThreads) void k_surv_loss(const float* __restrict__ x, const int64_t* __restrict__ t_,
                                                    const float* __restrict__ e_, int B, int K, int from_logits,
                                                    const float* __restrict__ logit_scale_exp, float alpha, float eps, int p,
                                                    int raw_distance, float w_ifmle, float w_emd,
                                                    float* __restrict__ out_ifmle, float* __restrict__ out_emd,
                                                    float* __restrict__ grad) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float sm[5][VLSA_MAX_K][kLossThreads];
+    const int i = blockIdx.x * kLossThreads + threadIdx.x;
     if (i >= B) return;
-    float inc[VLSA_MAX_K], g[VLSA_MAX_K];
+    const LossVec inc{&sm[0][0][threadIdx.x]}, g{&sm[1][0][threadIdx.x]};
     const float* xi = x + (size_t)i * K;
     int t = (int)t_[i];
     t = t < 0 ? 0 : (t >= K ? K - 1 : t);
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(64) void k_surv_loss(const float* __restrict__ x, c
     if (w_emd != 0.f || out_emd != nullptr) {
         const float ls = logit_scale_exp[0];
         const int ei = (int)e;  // e.long() of the reference
-        float pd[VLSA_MAX_K], td[VLSA_MAX_K], dp[VLSA_MAX_K];
+        const LossVec pd{&sm[2][0][threadIdx.x]}, td{&sm[3][0][threadIdx.x]}, dp{&sm[4][0][threadIdx.x]};
         float mp = -INFINITY, mt = -INFINITY;
         for (int k = 0; k < K; ++k) {
             const float tg = (k == t ? 1.f : 0.f) + (k > t ? (float)(1 - ei) : 0.f);   // convert_survival_label
@@ -116,7 +125,7 @@ extern "C" int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, 
     if (!x || !t || !e || B < 1 || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
     if ((w_emd != 0.f || out_emd) && !logit_scale_exp) return VLSA_EINVAL;
     if (p != 1 && p != 2) return VLSA_EUNSUPPORTED;
-    hipLaunchKernelGGL(k_surv_loss, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, t, e, B, K, from_logits, logit_scale_exp,
+    hipLaunchKernelGGL(k_surv_loss, dim3((B + kLossThreads - 1) / kLossThreads), dim3(kLossThreads), 0, (hipStream_t)stream, x, t, e, B, K, from_logits, logit_scale_exp,
                        alpha, eps, p, raw_distance, w_ifmle, w_emd, out_ifmle, out_emd, grad);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
