@@ -55,6 +55,9 @@ for label, sizes in (("TCGA-like 2k-12k", [int(x) for x in torch.randint(2000, 1
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / R
 
+    if "--only-batched" in sys.argv:      # (for rocprofv3: nothing but the batched step in the trace)
+        print(f"{label}: {dt * 1e3:.2f} ms per optimizer step")
+        continue
     # the same step over a checked BagSet (vlsa_amd.functional.BagSet: per-bag validation and descriptor rows once per split);
     # every step takes its own 32 bags out of the set, as a training loop over a resident split does
     from vlsa_amd.functional import BagSet

@@ -669,6 +669,9 @@ int vlsa_launch_head_batch(const float* rows, int B, int P, int D, int pool_mode
 int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float* W, const float* b, const float* That, int K,
                                   const float* logit_scale, float* v, float* vhat, float* vnorm, float* logits,
                                   float* incidence, hipStream_t s);  // vlfan_tail.hip
+int vlsa_launch_head_rows_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                const float* b, const float* That, int K, const float* logit_scale, float* pooled, float* v,
+                                float* vhat, float* vnorm, float* logits, float* incidence, hipStream_t s);  // vlfan_tail.hip
 
 #ifdef VLSA_TIMING
 extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
@@ -889,6 +892,11 @@ extern "C" int vlsa_head_forward_batch(const float* rows, int B, int P, int D, i
                                        void* stream) {
     if (!rows || !That || !logit_scale || !counters || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
     if (B < 1 || P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D <= 0 || D > VLSA_MAX_D || (D % 4) != 0) return VLSA_EINVAL;
+    // B > 1, pooling over the P rows: pool once per bag, then the ticket-free pooled route (16 instead of 34 us for 32 bags); the
+    // tickets are not touched (they stay zeroed, as the ticketed kernel hands them back)
+    if (B > 1 && pool_mode >= VLSA_POOL_MEAN && pool_mode <= VLSA_POOL_WEIGHT && pooled != rows)
+        return vlsa_launch_head_rows_batch(rows, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, pooled, v, vhat, vnorm, logits,
+                                           incidence, (hipStream_t)stream);
     return vlsa_launch_head_batch(rows, B, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, static_cast<unsigned int*>(counters),
                                   pooled, v, vhat, vnorm, logits, incidence, (hipStream_t)stream);
 }

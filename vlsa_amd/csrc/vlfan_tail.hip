@@ -496,6 +496,37 @@ int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float
     return launch_status();
 }
 
+// Batched head from the aggregated rows [B, P, D] without tickets (the training forward, round 4): one pooling launch (a workgroup per
+// bag, `pooled_col` as in k_head), then the two launches of the pooled route.  The ticketed k_head over (D / 8) x B workgroups took
+// 33.8 us for 32 bags (every workgroup re-pools its bag's rows and runs the drain + ticket chain; profiles/r04_step_kernel_stats.csv).
+namespace vlsa {
+__global__ __launch_bounds__(256) void k_pool_rows(const float* __restrict__ rows, int P, int D, int pool_mode,
+                                                    const float* __restrict__ pool_w, float* __restrict__ pooled) {
+    __shared__ float spw[VLSA_MAX_P];
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
+    const int tid = threadIdx.x, bag = blockIdx.x;
+    if (pool_mode == VLSA_POOL_WEIGHT) {
+        if (tid == 0) {
+            float mx = -INFINITY, s = 0.f;
+            for (int p = 0; p < P; ++p) mx = fmaxf(mx, pool_w[p]);
+            for (int p = 0; p < P; ++p) { spw[p] = expf(pool_w[p] - mx); s += spw[p]; }
+            for (int p = 0; p < P; ++p) spw[p] /= s;
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < D; c += 256) pooled[(size_t)bag * D + c] = pooled_col(rows + (size_t)bag * P * D, P, D, c, pool_mode, spw);
+}
+}  // namespace vlsa
+int vlsa_launch_head_rows_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                const float* b, const float* That, int K, const float* logit_scale, float* pooled, float* v,
+                                float* vhat, float* vnorm, float* logits, float* incidence, hipStream_t s) {
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    hipLaunchKernelGGL(vlsa::k_pool_rows, dim3(B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, pooled);
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
+}
+
 extern "C" int vlsa_debug_probe(int which, void* out, size_t out_bytes, void* stream) {
     if (!out || out_bytes < 64 * 4 * sizeof(float)) return VLSA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -540,7 +571,7 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
 //   model/vlsa.py:188-192).  Two launches instead of ~25 autograd kernels -- the optimizer step is bound by its number of
 //   dependent launches.  k_head_bwd_dv (one workgroup per bag): d v^ = exp(ls) dlogits T^ (+ g_vhat), d v = (d v^ - v^ (v^ . d v^)) / |v|,
 //   and the bag's share of d ls = sum_k dlogits logits.  k_head_bwd_params: block j < D: dW[j, :] = sum_b dv[b, j] pooled[b, :],
-//   db[j] = sum_b dv[b, j]; the next D / 64 blocks: d pooled[:, 64 columns] = dv W (identity head: dv), d rows[b, p, :] = d pooled[b] / P;
+//   db[j] = sum_b dv[b, j]; the next (D / 32) x (B / 8) blocks: d pooled[8 bags, 32 columns] = dv W (identity head: dv), d rows[b, p, :] = d pooled[b] / P;
 //   the next K blocks: d T^[k] = exp(ls) sum_b dlogits[b, k] v^[b] (+ g_That), d T = (d T^ - T^ (T^ . d T^)) / |T|; the last: d ls.
 namespace vlsa {
 __global__ __launch_bounds__(256) void k_head_bwd_dv(const float* __restrict__ dlogits, const float* __restrict__ g_vhat,
@@ -614,51 +645,54 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
         return;
     }
     blk -= nW;
-    const int nC = (D + 63) / 64;                     // d pooled -> d rows: one workgroup per 64 columns, all bags
+    // d pooled -> d rows: a workgroup per (32 columns, 8 bags).  d pooled[b, c] = sum_j dv[b, j] W[j, c]: thread (c, js) walks an eighth
+    // of the j range, 16 W loads in flight per round (dv staged in LDS, W row pieces coalesced), the eight slices are summed through
+    // LDS in a fixed order.  (Until round 4 eight workgroups -- one per 64 columns -- walked ALL bags and the whole of W four times: 67 us
+    // of the 32-bag optimizer step, profiles/r04_step_kernel_stats.csv; now (D / 32) x (B / 8) workgroups of 4 rounds each.)
+    const int nCB = (D + 31) / 32, nC = nCB * ((B + 7) / 8);
     if (blk < nC) {
-        // d pooled[b, c] = sum_j dv[b, j] W[j, c]: thread (c, js) walks a quarter of the j range for 8 bags at a time (dv staged in
-        // LDS, W row pieces coalesced, 8 independent loads in flight), the four quarters are summed through LDS
         __shared__ float sdv[8][VLSA_MAX_D];
-        __shared__ float sred[4][8][64];
-        const int c = blk * 64 + (tid & 63), js = tid >> 6;
+        __shared__ float sred[8][8][32];
+        const int cb = blk % nCB, b0 = (blk / nCB) * 8;
+        const int cl = tid & 31, js = tid >> 5, c = cb * 32 + cl;
         const float invP = 1.f / (float)P;
-        const int jq = (D + 3) / 4;
-        for (int b0 = 0; b0 < B; b0 += 8) {
-            __syncthreads();
-            for (int e = tid; e < 8 * D; e += 256) {
-                const int b = e / D, j = e % D;
-                sdv[b][j] = b0 + b < B ? dv[(size_t)(b0 + b) * D + j] : 0.f;
+        const int jq = (D + 7) / 8;
+        for (int e = tid; e < 8 * D; e += 256) {
+            const int b = e / D, j = e % D;
+            sdv[b][j] = b0 + b < B ? dv[(size_t)(b0 + b) * D + j] : 0.f;
+        }
+        __syncthreads();
+        float acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+        if (W != nullptr) {
+            const int jbeg = js * jq, jend = min(D, jbeg + jq);
+            for (int j0 = jbeg; j0 < jend; j0 += 16) {
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = (j0 + u < jend && c < D) ? W[(size_t)(j0 + u) * D + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (j0 + u < jend) {
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) acc[b] = fmaf(sdv[b][j0 + u], wv[u], acc[b]);
+                    }
             }
-            __syncthreads();
-            float acc[8];
+        } else if (js == 0 && c < D) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) acc[b] = 0.f;
-            if (W != nullptr) {
-                const int jbeg = js * jq, jend = min(D, jbeg + jq);
-                for (int j0 = jbeg; j0 < jend; j0 += 8) {
-                    float wv[8];
+            for (int b = 0; b < 8; ++b) acc[b] = sdv[b][c];
+        }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) wv[u] = (j0 + u < jend && c < D) ? W[(size_t)(j0 + u) * D + c] : 0.f;
+        for (int b = 0; b < 8; ++b) sred[js][b][cl] = acc[b];
+        __syncthreads();
+        {
+            const int b = tid >> 5, col = cb * 32 + cl;       // 256 threads = 8 bags x 32 columns
+            if (b0 + b < B && col < D) {
+                float v = 0.f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (j0 + u < jend) {
-#pragma unroll
-                            for (int b = 0; b < 8; ++b) acc[b] = fmaf(sdv[b][j0 + u], wv[u], acc[b]);
-                        }
-                }
-            } else if (js == 0 && c < D) {
-#pragma unroll
-                for (int b = 0; b < 8; ++b) acc[b] = sdv[b][c];
-            }
-#pragma unroll
-            for (int b = 0; b < 8; ++b) sred[js][b][tid & 63] = acc[b];
-            __syncthreads();
-            for (int e = tid; e < 8 * 64; e += 256) {
-                const int b = e >> 6, cc = e & 63, col = blk * 64 + cc;
-                if (b0 + b < B && col < D) {
-                    const float v = ((sred[0][b][cc] + sred[1][b][cc]) + (sred[2][b][cc] + sred[3][b][cc])) * invP;
-                    for (int p = 0; p < P; ++p) drows[((size_t)(b0 + b) * P + p) * D + col] = v;
-                }
+                for (int q = 0; q < 8; ++q) v += sred[q][b][cl];
+                v *= invP;
+                for (int p = 0; p < P; ++p) drows[((size_t)(b0 + b) * P + p) * D + col] = v;
             }
         }
         return;
@@ -711,7 +745,7 @@ extern "C" int vlsa_head_backward_batch(const float* dlogits, const float* g_vha
     float* dv = workspace;
     float* dls_part = workspace + (size_t)B * D;
     hipLaunchKernelGGL(vlsa::k_head_bwd_dv, dim3(B), dim3(256), 0, s, dlogits, g_vhat, vhat, vnorm, That, logits, logit_scale, D, K, dv, dls_part);
-    hipLaunchKernelGGL(vlsa::k_head_bwd_params, dim3((W ? D : 0) + (D + 63) / 64 + K + 1), dim3(256), 0, s, dv, pooled, W, dlogits, g_That, vhat, That,
+    hipLaunchKernelGGL(vlsa::k_head_bwd_params, dim3((W ? D : 0) + ((D + 31) / 32) * ((B + 7) / 8) + K + 1), dim3(256), 0, s, dv, pooled, W, dlogits, g_That, vhat, That,
                        tnorm, logit_scale, dls_part, B, P, D, K, dW, db, drows, dT, dls);
     return launch_status();
 }
