@@ -185,6 +185,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VLSA_BENCH_WATCHDOG"):        # development aid: every rank dumps its Python stacks to stderr after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VLSA_BENCH_WATCHDOG"]), repeat=False, exit=False)
     if not torch.cuda.is_available():
         sys.exit(f"bench.py (rank {rank} of {world}): no GPU visible -- the hot path is HIP only, there is no CPU fallback to time")
     # VLSA_BENCH_BACKEND=gloo: development aid to walk the N > 1 code path with several ranks sharing ONE GPU (RCCL refuses

@@ -110,6 +110,9 @@ python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2> $O/bench_sh1.err
 # the N > 1 code path started the way the driver starts it (python bench.py --gpus 2: self-launch), two ranks sharing this GPU over gloo
 VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-extra > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err
+# ... and with 8 ranks sharing the GPU (short clock ramp: every gloo exchange of 8 processes on one device takes ~0.1-1 s): world = 8
+# shard bounds, the 8-record fold and the gathered verification walk through; timings meaningless
+VLSA_BENCH_RAMP=1 VLSA_BENCH_WATCHDOG=300 VLSA_BENCH_BACKEND=gloo timeout 500 python bench.py --gpus 8 --steps 2 --warmup 1 --no-extra > $O/bench_8ranks_gloo_one_gpu.json 2> $O/bench_8ranks.err
 # round 4: persistent text-tower forward vs launch-per-stage (+ its in-kernel stamps), the whole-row score kernel vs the default
 for m in 1 0; do VLSA_TT_PERSIST=$m python tools/bench_text.py 2>&1 | grep "GPU forward" | sed "s/^/VLSA_TT_PERSIST=$m: /"; done > $O/bench_text_persist.txt
 python tools/bench_text_trainable.py 2>&1 | tail -1 > $O/bench_text_trainable.txt
