@@ -16,4 +16,4 @@ def test_fuzz_batched_launches_against_single_bag_kernels(seed):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_batch.py"), "60", str(seed)], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "fuzz ok:" in r.stdout and "fuzz ok (other encoders):" in r.stdout
+    assert "fuzz ok:" in r.stdout and "fuzz ok (other encoders):" in r.stdout and "fuzz ok (wide launches):" in r.stdout

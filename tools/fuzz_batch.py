@@ -92,3 +92,43 @@ for it in range(rounds // 2):
         assert ea < 5e-6 and ep < 2e-5, ("deepmil", it, i, sizes[i], dt, gated, ea, ep)
 torch.cuda.synchronize()
 print("fuzz ok (other encoders):", rounds // 2, "rounds; worst absolute differences", worst2)
+
+# ---- wide forward launches (round 4: up to 256 bags per launch, a workgroup's table holds its own bags only): random bag counts,
+# bags in flight (auto and forced, incl. one workgroup per bag), both dtypes, with and without attention weights
+worst3 = {"out": 0.0, "A": 0.0}
+for it in range(max(4, rounds // 6)):
+    dt = rng.choice([torch.bfloat16, torch.float32])
+    B = rng.choice([65, 97, 128, 129, 200, 255, 256])
+    P = rng.choice([1, 4, 12, 12, 13, 16])
+    gated = rng.random() < 0.3
+    sizes = [rng.choice(special) if rng.random() < 0.5 else (rng.randint(1, 3000) if rng.random() < 0.97 else rng.randint(20_000, 60_000))
+             for _ in range(B)]
+    bags = []
+    for n in sizes:
+        o = rng.randint(0, 70_000 - n)
+        bags.append(pool_d[dt][o:o + n])
+    Q = torch.randn(P + (1 if gated else 0), 512, generator=g).to(dev)
+    T = torch.randn(4, 512, generator=g).to(dev)
+    Wh = (torch.randn(512, 512, generator=g) / 22).to(dev)
+    bh = torch.randn(512, generator=g).to(dev)
+    ls = torch.tensor(4.03, device=dev)
+    want = rng.random() < 0.4
+    plan = F.VlfanBatchPlan(B, P, 4, dev, gated=gated, want_attn=want)
+    plan.set_bags(bags)
+    forced = rng.choice([0, 0, 4, 16, 64, 128, 256])
+    if forced:
+        plan.groups = forced
+    plan.run(Q, T, ls, Wh, bh)
+    out = plan.out.clone()
+    for i in rng.sample(range(B), 24):
+        o, A = F.vlfan_cross_attention(bags[i], Q, gated=gated, want_attn=want)
+        e = (o - out[i]).abs().max().item() / max(1.0, o.abs().max().item())
+        worst3["out"] = max(worst3["out"], e)
+        assert e < 6e-5, ("wide out", it, i, sizes[i], dt, P, gated, B, forced, e)
+        if want:
+            ea = (A - plan.attn.views[i]).abs().max().item()
+            worst3["A"] = max(worst3["A"], ea)
+            assert ea < 2e-5, ("wide A", it, i, sizes[i], dt, P, gated, B, forced, ea)
+    del plan
+torch.cuda.synchronize()
+print("fuzz ok (wide launches):", max(4, rounds // 6), "rounds; worst differences", worst3)
