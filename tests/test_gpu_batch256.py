@@ -89,6 +89,30 @@ def test_wide_launch_attention_weights(dtype, gated):
         assert (logits[i:i + 1].cpu() - _oracle_logits(bags[i], Q, params, gated)).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_wide_launch_with_empty_bags_and_one_big_bag(dtype):
+    """empty bags (no defined softmax: their rows are skipped, as in the narrow tests), a 70k-patch bag among slide-sized ones (its
+    group's workgroups carry it alone), a second run on the same plan (workspace / descriptor reuse)"""
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    sizes = [SIZES[i % len(SIZES)] for i in range(140)]
+    for i in (0, 63, 64, 65, 139):
+        sizes[i] = 0
+    sizes[77] = 70_000
+    bags = [cases.make_bag(n, 9800 + i).to(dtype) if n > 0 else torch.empty(0, 512, dtype=dtype) for i, n in enumerate(sizes)]
+    params = cases.make_params(12, 4, 9801)
+    Q = 0.5 * params["resid"] + params["prompt"]
+    args = [t.to(dev) for t in (Q, params["T"], torch.tensor(cases.LOGIT_SCALE), params["W"], params["b"])]
+    plan = F.VlfanBatchPlan(140, 12, 4, dev)
+    plan.set_bags([x.to(dev) for x in bags])
+    first = plan.run(*args).clone()
+    logits = plan.run(*args).clone()
+    live = [i for i, n in enumerate(sizes) if n > 0]
+    assert torch.equal(first[live], logits[live])
+    for i in (1, 62, 66, 77, 100, 138):
+        assert (logits[i:i + 1].cpu() - _oracle_logits(bags[i], Q, params)).abs().max().item() < TOL, (i, sizes[i])
+
+
 def test_module_picks_the_launch_width_from_the_bag_sizes():
     from vlsa_amd import functional as F
     from test_gpu_bagset import _net
