@@ -159,7 +159,7 @@ def test_reference_handler_builds_the_hip_model_after_one_line_patch(hooks_insta
     import model.utils as ref_utils
     import model.vlsa as ref_vlsa
     from runner.vlsa_handler import VLSAHandler
-    from vlsa_amd.model_utils import patch_reference
+    from vlsa_amd.model_utils import patch_reference, unpatch_reference
     from vlsa_amd.vlsa import VLSA
     saved = patch_reference()
     try:
@@ -167,9 +167,9 @@ def test_reference_handler_builds_the_hip_model_after_one_line_patch(hooks_insta
             p_init, p_proto = HC.write_prompt_files(tmp)
             model = VLSAHandler.func_load_model(HC.make_cfg(p_init, p_proto))
     finally:
-        ref_utils.VLSA, ref_vlsa.VLSA = saved["VLSA_utils"], saved["VLSA_vlsa"]
-        ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = saved["VLFAN"], saved["FeatMIL"], saved["DeepMIL"]
-        ref_mil.logit_pooling = ref_vlsa.logit_pooling = saved["logit_pooling"]
+        assert VLSA.defer_training_calls is True                      # (patch_reference switches the handler's training loop to deferred calls)
+        unpatch_reference(saved)
+        assert VLSA.defer_training_calls is False and ref_utils.VLSA is saved["VLSA_utils"] and ref_mil.VLFAN is saved["VLFAN"]
         os.chdir(cwd)
     assert isinstance(model, VLSA)
     ref = json.load(open(os.path.join(GOLDEN, "handler_keys.json")))
@@ -204,10 +204,9 @@ def test_patch_reference_can_make_the_handlers_datasets_resident(hooks_installed
         patch_reference(resident_bags=True)                                # idempotent: not wrapped twice
         assert not isinstance(ref_sa.prepare_surv_dataset(["p1"], {}).dataset, ResidentBags)
     finally:
+        from vlsa_amd.model_utils import unpatch_reference
+        unpatch_reference(saved)
         ref_ds.prepare_surv_dataset = ref_sa.prepare_surv_dataset = original
-        ref_utils.VLSA, ref_vlsa.VLSA = saved["VLSA_utils"], saved["VLSA_vlsa"]
-        ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = saved["VLFAN"], saved["FeatMIL"], saved["DeepMIL"]
-        ref_mil.logit_pooling = ref_vlsa.logit_pooling = saved["logit_pooling"]
         os.chdir(cwd)
 
 

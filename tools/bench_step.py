@@ -132,6 +132,16 @@ for label, sizes in (("TCGA-like 2k-12k", [int(x) for x in torch.randint(2000, 1
     torch.cuda.synchronize()
     dth = (time.perf_counter() - t0) / R
     print(f"{label}: handler-shaped step (32 x net(X), cat, one backward): {dth * 1e3:.2f} ms")
+    net.defer_training_calls = True          # vlsa_amd/deferred.py: the same loop, its calls served by ONE forward_bags at torch.cat
+    for _ in range(5):
+        hstep()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(R):
+        hstep()
+    torch.cuda.synchronize()
+    dthd = (time.perf_counter() - t0) / R
+    net.defer_training_calls = False
+    print(f"{label}: the same handler-shaped loop with net.defer_training_calls = True (what patch_reference() sets): {dthd * 1e3:.2f} ms")
     if "--profile-handler" in sys.argv:
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable()

@@ -114,7 +114,7 @@ def func_load_model(cfg: dict):
     return model
 
 
-def patch_reference(resident_bags: bool = False, **resident_kw):
+def patch_reference(resident_bags: bool = False, defer_training_calls: bool = True, **resident_kw):
     """Point the reference's factory at this package (call once, before the handler is built):
 
         import vlsa_amd.model_utils; vlsa_amd.model_utils.patch_reference()
@@ -129,6 +129,8 @@ def patch_reference(resident_bags: bool = False, **resident_kw):
       not be fed rounded features silently); ``dtype=torch.bfloat16`` in ``resident_kw`` halves the footprint and the streaming
       time at ~1e-2 on the logits.  Needs ``num_workers: 0`` in the run's config (a worker process has no device: items pass
       through unchanged there, with a one-time warning).
+    * ``defer_training_calls`` (default True): ``VLSA.defer_training_calls`` -- the handler's ``net(xs[i])`` calls of a training batch run
+      as ONE batched forward the moment ``torch.cat(y_hat)`` looks at them (vlsa_amd/deferred.py): 1.9 instead of 4.5 ms per 32-bag step.
     Returns the patched reference modules (for un-patching in tests)."""
     import model.deepmil as ref_mil
     import model.utils as ref_utils
@@ -139,6 +141,10 @@ def patch_reference(resident_bags: bool = False, **resident_kw):
                  DeepMIL=ref_mil.DeepMIL, logit_pooling=ref_mil.logit_pooling)
     ref_utils.VLSA = VLSA
     ref_vlsa.VLSA = VLSA
+    # the handler's bag-by-bag training loop (runner/vlsa_handler.py:260-289) at the batched step's speed: its net(X) calls are recorded
+    # and run as ONE forward_bags when torch.cat first looks at a prediction (vlsa_amd/deferred.py)
+    saved["defer_training_calls"] = VLSA.defer_training_calls
+    VLSA.defer_training_calls = defer_training_calls
     ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = fast.VLFAN, fast.FeatMIL, fast.DeepMIL
     ref_mil.logit_pooling = ref_vlsa.logit_pooling = fast.logit_pooling
     if resident_bags:
@@ -161,3 +167,25 @@ def patch_reference(resident_bags: bool = False, **resident_kw):
                 if mod is not None and getattr(mod, "prepare_surv_dataset", None) is original:
                     mod.prepare_surv_dataset = prepare_surv_dataset
     return saved
+
+
+def unpatch_reference(saved) -> None:
+    """Undo ``patch_reference`` (``saved`` = what it returned): the reference's own classes, dataset factory and the class-wide
+    ``VLSA.defer_training_calls`` flag are back as they were."""
+    import model.deepmil as ref_mil
+    import model.utils as ref_utils
+    import model.vlsa as ref_vlsa
+    from .vlsa import VLSA
+    ref_utils.VLSA, ref_vlsa.VLSA = saved["VLSA_utils"], saved["VLSA_vlsa"]
+    ref_mil.VLFAN, ref_mil.FeatMIL, ref_mil.DeepMIL = saved["VLFAN"], saved["FeatMIL"], saved["DeepMIL"]
+    ref_mil.logit_pooling = ref_vlsa.logit_pooling = saved["logit_pooling"]
+    VLSA.defer_training_calls = saved.get("defer_training_calls", False)
+    if "prepare_surv_dataset" in saved:
+        import sys
+        import dataset.utils as ref_ds
+        patched = ref_ds.prepare_surv_dataset
+        ref_ds.prepare_surv_dataset = saved["prepare_surv_dataset"]
+        for name in ("runner.sa_handler", "runner.vlsa_handler", "runner.base_handler"):
+            mod = sys.modules.get(name)
+            if mod is not None and getattr(mod, "prepare_surv_dataset", None) is patched:
+                mod.prepare_surv_dataset = saved["prepare_surv_dataset"]

@@ -59,11 +59,16 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
 
     _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
                   "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
-                  "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None}
+                  "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None,
+                  "_pending_calls": lambda: None, "_materialising": lambda: False}
 
     #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
     #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
     lookahead_bags = 64
+    #: True: a grad-enabled ``net(X)`` in training mode is recorded, not run; the first torch operation on any of its outputs runs ONE
+    #: ``forward_bags`` over all recorded bags (vlsa_amd/deferred.py) -- the reference handler's bag-by-bag training loop
+    #: (runner/vlsa_handler.py:260-289) at the batched step's speed.  ``patch_reference()`` switches it on; off by default.
+    defer_training_calls = False
 
     def __init__(self, text_encoder_cfg, image_encoder_cfg, prompt_learner_cfg, pretrained_prompt_learner_cfg=None,
                  info_prefix="VLSA-UNI", **kwargs):
@@ -163,6 +168,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         self._train_plans = {}
         self._tower_lists = None
         self._la = self._la_lists = None                      # look-ahead window + kept module / tensor lists (see _lookahead)
+        self._pending_calls, self._materialising = None, False  # deferred training calls (vlsa_amd/deferred.py)
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ / queries were computed from
         self._prepared_query, self._prepared_qver = None, -1
@@ -463,6 +469,11 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         ``DistributedDataParallel`` with bags as the data-parallel unit -- see the batched path too)."""
         if isinstance(X, (list, tuple)):
             return self.forward_bags(list(X))
+        pc = self._pending_calls
+        if pc is not None and self.defer_training_calls and not self._materialising and self.training and torch.is_grad_enabled():
+            # a further call of an open batch of deferred training calls (vlsa_amd/deferred.py): nothing to evaluate here
+            if pc.same_state() and pc.takes(X):
+                return pc.add(X)
         src = getattr(X, "_vlsa_src", None)          # a ResidentBags item as the handler's loader delivers it (vlsa_amd/ingest.py)
         text_features = self._text_features()
         needs_grad = self._needs_grad(text_features)
@@ -478,6 +489,10 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 return fused
         else:
             self._la = None                      # a differentiable forward: parameters are about to move
+            if self.defer_training_calls and self.training and not self._materialising:
+                deferred = self._defer_call(X, text_features)
+                if deferred is not None:
+                    return deferred
             trained = self._slide_train(X, text_features)
             if trained is not None:
                 return trained
@@ -507,13 +522,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             _, logits = logit_pooling(logits, self.image_encoder_cfg["pooling"])
         return logits, image_features, text_features
 
-    # -- look-ahead: the reference handler's bag-by-bag evaluation loop at batched speed ---------------------------------------
-    def _eval_state(self, text_features):
-        """Everything an inference result depends on besides the bag: the text-feature tensor (object + in-place version: the text
-        side's own cache hands out the same object as long as ITS key -- every provider tensor's version and flags -- holds) and
-        every parameter / buffer (object + version) and train / eval flag of the MIL encoder (query network included), the logit
-        scale, the co-attention scale.  The module / tensor lists are kept between calls and rebuilt by an exact walk whenever a
-        window is computed, on ``_apply`` and on ``load_state_dict``."""
+    # -- deferred training calls: the reference handler's bag-by-bag TRAINING loop at batched speed (vlsa_amd/deferred.py) -------
+    def _encoder_lists(self):
         ll = self._la_lists
         if ll is None or ll[0] is not self._modules["mil_encoder"]:
             enc = self._modules["mil_encoder"]
@@ -523,6 +533,47 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             if isinstance(cs, torch.Tensor):
                 tensors.append(cs)
             ll = self._la_lists = (enc, sub, tensors)
+        return ll
+
+    def _defer_key(self):
+        """Everything a training-mode output depends on besides the bag: the text side (fixed features: the buffer's version; a
+        provider: its modules' tensors / flags, ``_provider_key``), the MIL encoder's tensors and flags, the logit scale.  None: a
+        text provider this object cannot see into -- such calls are not deferred."""
+        fixed = self._buffers.get("pretrained_text_features") if "pretrained_text_features" in self._buffers else None
+        pk = None
+        if fixed is None:
+            pk = self._provider_key()
+            if pk is None:
+                return None
+        ll = self._encoder_lists()
+        return (pk, None if fixed is None else (id(fixed), fixed._version), tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])),
+                self.training)
+
+    def _defer_call(self, X, text_features):
+        from .deferred import TrainingCalls
+        if not (TrainingCalls.takes(X) and text_features.dim() == 2):
+            return None
+        pc = self._pending_calls
+        if pc is None or not pc.same_state():
+            self._la_lists = None                           # an exact walk of the encoder for the batch's key
+            key = self._defer_key()
+            if key is None:
+                return None
+            sub, tensors = self._walk_module(self)
+            if any(isinstance(m, nn.modules.dropout._DropoutNd) and m.p > 0 and m.training for m in sub):
+                return None                                  # per-call random masks: every call is its own evaluation
+            pc = self._pending_calls = TrainingCalls(self, key, [t for t in tensors if t.requires_grad], text_features.shape[0],
+                                                     text_features.shape[1], X.device)
+        return pc.add(X)
+
+    # -- look-ahead: the reference handler's bag-by-bag evaluation loop at batched speed ---------------------------------------
+    def _eval_state(self, text_features):
+        """Everything an inference result depends on besides the bag: the text-feature tensor (object + in-place version: the text
+        side's own cache hands out the same object as long as ITS key -- every provider tensor's version and flags -- holds) and
+        every parameter / buffer (object + version) and train / eval flag of the MIL encoder (query network included), the logit
+        scale, the co-attention scale.  The module / tensor lists are kept between calls and rebuilt by an exact walk whenever a
+        window is computed, on ``_apply`` and on ``load_state_dict``."""
+        ll = self._encoder_lists()
         return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version)
 
     @staticmethod
