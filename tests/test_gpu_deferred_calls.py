@@ -143,3 +143,41 @@ def test_what_is_not_deferred():
     net._pending_calls = None
     net.mil_encoder.visual_adapter = torch.nn.Sequential(torch.nn.Dropout(0.1), net.mil_encoder.visual_adapter)   # an active dropout layer
     assert not isinstance(net(bags[0])[0], DeferredOutput)
+
+
+def test_an_epoch_over_resident_bags_with_the_handlers_collector_loop(hooks_installed):  # noqa: F811
+    """``_train_each_epoch`` (runner/vlsa_handler.py:192-236): a shuffled loader over ``ResidentBags`` items, ``data_x[0].cuda()`` collected
+    into mini-batches of ``bp_every_batch`` bags, ``_update_network`` per mini-batch.  With deferred calls every mini-batch is ONE batched
+    forward (the tagged resident views go in as they are); the trajectory equals the bag-by-bag one within rounding."""
+    from test_gpu_handler_loop import _PatchItems
+    from vlsa_amd.ingest import ResidentBags
+    sizes = [700, 64, 1, 2798, 333, 4100, 65, 900, 17, 1200, 300, 2047]
+    ds = _PatchItems(sizes)
+    K = None
+    runs = {}
+    for deferred in (False, True):
+        model, cfg = _build()
+        model.defer_training_calls = deferred
+        model.train()
+        opt = HL.make_optimizer(model, cfg)
+        rb = ResidentBags(ds, dtype=torch.float32)
+        g = torch.Generator().manual_seed(5)
+        loader = torch.utils.data.DataLoader(rb, batch_size=1, shuffle=True, generator=g, num_workers=0)
+        calls = []
+        orig = model.forward_bags
+        model.forward_bags = lambda bags, **kw: (calls.append(len(bags)), orig(bags, **kw))[1]
+        losses, xs, ys = [], [], []
+        for epoch in range(2):
+            for i_batch, (_idx, data_x, data_y) in enumerate(loader, 1):
+                xs.append(data_x[0].cuda())
+                K = K or int(model.forward_text_only().shape[0])
+                ys.append(torch.stack([data_y[:, 0] % K, data_y[:, 1]], dim=1).cuda())
+                if i_batch % 4 == 0 or i_batch == len(loader):
+                    loss, _ = HL.update_network(model, opt, O.vlsa_objective, xs, ys)
+                    losses.append(loss)
+                    xs, ys = [], []
+        runs[deferred] = (losses, calls, model.prompt_learner.context_embeds.detach().cpu().clone())
+    assert runs[False][1] == [] and runs[True][1] == [4] * 6                  # six mini-batches of four bags: six batched calls
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) < 5e-5 * max(1.0, abs(a)), (a, b)
+    _bulk(runs[True][2], runs[False][2], "context after two epochs", cfg["opt_lr"], 6)
