@@ -60,7 +60,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
                   "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
                   "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None,
-                  "_pending_calls": lambda: None, "_materialising": lambda: False}
+                  "_pending_calls": lambda: None, "_materialising": lambda: False, "_provider_walks": dict}
 
     #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
     #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
@@ -169,6 +169,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         self._tower_lists = None
         self._la = self._la_lists = None                      # look-ahead window + kept module / tensor lists (see _lookahead)
         self._pending_calls, self._materialising = None, False  # deferred training calls (vlsa_amd/deferred.py)
+        self._provider_walks = {}
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ / queries were computed from
         self._prepared_query, self._prepared_qver = None, -1
@@ -224,6 +225,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             return None
         tower = getattr(self, "prompt_encoder", None)
         key = [torch.is_grad_enabled()]
+        walks = {}
         for m in mods:
             if m is tower:
                 tl = self._tower_lists
@@ -233,7 +235,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 key.append((id(m), len(tl[2]), tuple(map(_GET_TRAINING, tl[1])), tuple(map(_GET_VERSION, tl[2]))))
             else:
                 sub, tensors = self._walk_module(m)
+                walks[id(m)] = (sub, tensors)
                 key.append((id(m), tuple([(id(x), x.training) for x in sub]), tuple([(id(t), t._version) for t in tensors])))
+        self._provider_walks = walks          # the exact walks of this call (deferred training calls read them right after)
         return tuple(key)
 
     @staticmethod
@@ -559,7 +563,16 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             key = self._defer_key()
             if key is None:
                 return None
-            sub, tensors = self._walk_module(self)
+            # every module / tensor of the model from the walks the key was just built from (text-side modules: `_provider_walks`
+            # + the kept tower lists; the encoder: `_la_lists`) -- no second walk over the ~120 modules of the tower
+            sub, tensors = list(self._la_lists[1]), list(self._la_lists[2])
+            if key[0] is not None:
+                for m in self._provider_modules():
+                    w = self._tower_lists[1:] if (self._tower_lists is not None and self._tower_lists[0] is m) else self._provider_walks.get(id(m))
+                    if w is None:
+                        w = self._walk_module(m)
+                    sub += w[0]
+                    tensors += w[1]
             if any(isinstance(m, nn.modules.dropout._DropoutNd) and m.p > 0 and m.training for m in sub):
                 return None                                  # per-call random masks: every call is its own evaluation
             pc = self._pending_calls = TrainingCalls(self, key, [t for t in tensors if t.requires_grad], text_features.shape[0],
