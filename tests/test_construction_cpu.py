@@ -237,3 +237,31 @@ def test_func_load_model_and_the_run_directory_loader(hooks_installed):
         assert _read_run_cfg(run) == cfg
         with pytest.raises(RuntimeError):
             _read_run_cfg(tmp)
+
+
+def test_provider_key_sees_reassigned_parameters_without_walking_per_call(hooks_installed):
+    """The text-feature cache key reads kept module / tensor lists (no walk per ``net(X)`` call); the lists are exact because every
+    parameter / buffer / submodule registration in the process bumps a structure epoch (torch's global registration hooks).  A
+    re-assigned learner parameter -- same ``_version`` as the old one -- must change the key; an unrelated module built elsewhere must not."""
+    model, _ = _build()
+    walks = []
+    orig = type(model)._walk_module
+    type(model)._walk_module = staticmethod(lambda m: (walks.append(type(m).__name__), orig(m))[1])
+    try:
+        k0 = model._provider_key()
+        n0 = len(walks)
+        assert model._provider_key() == k0 and len(walks) == n0                       # steady state: no walk at all
+        nn.Linear(3, 3)                                                                # somebody builds a module: lists are re-walked ...
+        assert model._provider_key() == k0 and len(walks) > n0                        # ... found unchanged: same key
+        old = model.prompt_learner.context_embeds
+        model.prompt_learner.context_embeds = nn.Parameter(old.detach().clone() + 1.0)
+        assert model.prompt_learner.context_embeds._version == old._version
+        k1 = model._provider_key()
+        assert k1 != k0                                                                # the new object is seen
+        with torch.no_grad():
+            model.prompt_learner.context_embeds.add_(1.0)
+        assert model._provider_key() != k1                                             # in-place change: version
+        model.prompt_encoder.eval() if model.prompt_encoder.training else model.prompt_encoder.train()
+        assert model._provider_key() != k1                                             # train / eval flag
+    finally:
+        type(model)._walk_module = staticmethod(orig)

@@ -96,6 +96,7 @@ cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_batch_kernel_st
 python tools/bench_attn.py > $O/bench_attn.txt 2>&1
 python tools/bench_attn.py 50000 fp32 2>&1 | grep want_attn >> $O/bench_attn.txt
 python tools/bench_step.py > $O/bench_step.txt 2>&1
+python tools/bench_epoch.py 2>&1 | grep -v amdgpu > $O/bench_epoch.txt
 python tools/bench_train.py > $O/bench_train.txt 2>&1
 python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1
 python tools/kbench_batch_f32.py 2>&1 | grep "N=" > $O/kbench_batch_f32.txt

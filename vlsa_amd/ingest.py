@@ -244,6 +244,9 @@ class ResidentBagView(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        if func in _view_meta_funcs():          # shape / dtype / device / dim / ...: no tensor comes back, nothing to untag
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
         with torch._C.DisableTorchFunctionSubclass():
             if func is torch.stack and not kwargs.get("out"):
                 seq = args[0] if args else kwargs.get("tensors")
@@ -258,6 +261,11 @@ class ResidentBagView(torch.Tensor):
                 return out.as_subclass(torch.Tensor)
             out = func(*args, **kwargs)
         return _untag(out)
+
+
+def _view_meta_funcs():
+    from .deferred import _meta_funcs
+    return _meta_funcs()
 
 
 def _untag(out):

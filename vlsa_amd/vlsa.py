@@ -28,6 +28,29 @@ from .deepmil import FeatMIL, VLFAN, logit_pooling
 
 _GET_TRAINING, _GET_VERSION = operator.attrgetter("training"), operator.attrgetter("_version")    # C-level loops in _provider_key
 
+# Structure epoch: bumped whenever ANY nn.Module in the process registers a parameter, buffer or submodule (torch's global registration
+# hooks; `module.x = nn.Parameter(...)` goes through them).  Module / tensor lists kept for the cache keys below are valid for the epoch
+# they were walked in -- a re-assigned parameter of the prompt learner is seen at the next key, without walking the learner per call.
+_STRUCT_EPOCH = [0, 0]          # [registrations seen, walks that found a changed structure]
+
+
+def _bump_structure_epoch(*_args, **_kwargs):
+    _STRUCT_EPOCH[0] += 1
+    return None
+
+
+def _install_structure_hooks():
+    if getattr(_install_structure_hooks, "done", False):
+        return
+    from torch.nn.modules import module as _m
+    _m.register_module_parameter_registration_hook(_bump_structure_epoch)
+    _m.register_module_buffer_registration_hook(_bump_structure_epoch)
+    _m.register_module_module_registration_hook(_bump_structure_epoch)
+    _install_structure_hooks.done = True
+
+
+_install_structure_hooks()
+
 
 def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
     """getattr(model.deepmil, cfg['name'])(**cfg)  (model/utils_vl.py:129-138)."""
@@ -57,10 +80,10 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     calls from ``VLSAHandler.func_load_model`` (runner/vlsa_handler.py:112-120).  ``VLSA.from_modules(image_encoder_cfg, ...)``
     assembles the same model from ready-made parts (text features / provider / prompt learner + encoder objects)."""
 
-    _transient = {"_plans": dict, "_train_plans": dict, "_tower_lists": lambda: None, "_text_cache": lambda: None,
+    _transient = {"_plans": dict, "_train_plans": dict, "_provider_lists": dict, "_text_cache": lambda: None,
                   "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
                   "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None,
-                  "_pending_calls": lambda: None, "_materialising": lambda: False, "_provider_walks": dict}
+                  "_pending_calls": lambda: None, "_materialising": lambda: False}
 
     #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
     #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
@@ -166,10 +189,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             self.logit_scale = nn.Parameter(torch.ones([]) * float(logit_scale))  # CoCa init, model/conch/coca_model.py:187
         self._plans = {}
         self._train_plans = {}
-        self._tower_lists = None
+        self._provider_lists = {}                              # provider module -> (module, submodules, tensors, structure epoch)
         self._la = self._la_lists = None                      # look-ahead window + kept module / tensor lists (see _lookahead)
         self._pending_calls, self._materialising = None, False  # deferred training calls (vlsa_amd/deferred.py)
-        self._provider_walks = {}
         self._head_tickets = VF.HeadTickets()
         self._prepared_text, self._prepared_gen = None, 0     # see _fused_vlfan: what the plans' prepared T^ / queries were computed from
         self._prepared_query, self._prepared_qver = None, -1
@@ -216,29 +238,45 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         parameter and buffer of the provider modules, the train / eval flag of every submodule (dropout in the 'FC' adapter)
         and the grad mode.  None = the provider is an opaque callable with no declared modules: its output cannot be cached.
 
-        The reference's handler calls the model once per bag, so this runs per bag: the text tower (~110 modules, ~150 tensors)
-        is not re-walked every time -- its module / tensor lists are kept and only their flags and versions are read
-        (``_tower_lists``; rebuilt by an exact walk whenever the key misses, on ``_apply`` and on ``load_state_dict``); the
-        small learner / adapter modules are walked exactly on every call."""
+        The reference's handler calls the model once per bag, so this runs per bag (31 us with an exact walk of the learner and
+        adapter per call, round 4: the whole look-ahead hit path is 9 us): the module / tensor lists of every provider module are
+        kept and only their flags and versions are read.  The lists are exact for the structure epoch they were walked in (any
+        parameter / buffer / submodule registration anywhere bumps it: ``_STRUCT_EPOCH``), and are re-walked whenever the key misses,
+        on ``_apply`` and on ``load_state_dict`` besides."""
         mods = self._provider_modules()
         if not mods:
             return None
-        tower = getattr(self, "prompt_encoder", None)
+        epoch = _STRUCT_EPOCH[0]
+        kept = self._provider_lists
         key = [torch.is_grad_enabled()]
-        walks = {}
         for m in mods:
-            if m is tower:
-                tl = self._tower_lists
-                if tl is None or tl[0] is not m:
-                    sub, tensors = self._walk_module(m)
-                    tl = self._tower_lists = (m, sub, tensors)
-                key.append((id(m), len(tl[2]), tuple(map(_GET_TRAINING, tl[1])), tuple(map(_GET_VERSION, tl[2]))))
-            else:
+            tl = kept.get(id(m))
+            if tl is None or tl[0] is not m or tl[3] != epoch:
                 sub, tensors = self._walk_module(m)
-                walks[id(m)] = (sub, tensors)
-                key.append((id(m), tuple([(id(x), x.training) for x in sub]), tuple([(id(t), t._version) for t in tensors])))
-        self._provider_walks = walks          # the exact walks of this call (deferred training calls read them right after)
+                # the walk's identity goes into the key (versions alone cannot tell a re-assigned parameter from the old one); it only
+                # changes when the walk really found other objects -- a registration elsewhere in the process re-walks, nothing more
+                same = (tl is not None and tl[0] is m and len(tl[1]) == len(sub) and len(tl[2]) == len(tensors)
+                        and all(a is b for a, b in zip(tl[1], sub)) and all(a is b for a, b in zip(tl[2], tensors)))
+                if not same:
+                    _STRUCT_EPOCH[1] += 1
+                tl = kept[id(m)] = (m, sub, tensors, epoch, tl[4] if same else _STRUCT_EPOCH[1])
+            key.append((id(m), tl[4], tuple(map(_GET_TRAINING, tl[1])), tuple(map(_GET_VERSION, tl[2]))))
         return tuple(key)
+
+    @property
+    def _tower_lists(self):        # (module, submodules, tensors) of the text tower as last walked, or None
+        tower = getattr(self, "prompt_encoder", None)
+        tl = self._provider_lists.get(id(tower)) if tower is not None else None
+        return None if tl is None else tl[:3]
+
+    @_tower_lists.setter
+    def _tower_lists(self, value):   # `= None`: forget every kept provider list (the next key walks exactly)
+        assert value is None
+        self._provider_lists.clear()
+
+    @property
+    def _provider_walks(self):
+        return {k: (v[1], v[2]) for k, v in self._provider_lists.items()}
 
     @staticmethod
     def _walk_module(m):
@@ -476,6 +514,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         pc = self._pending_calls
         if pc is not None and self.defer_training_calls and not self._materialising and self.training and torch.is_grad_enabled():
             # a further call of an open batch of deferred training calls (vlsa_amd/deferred.py): nothing to evaluate here
+            if type(X) is not torch.Tensor and isinstance(X, torch.Tensor):
+                with torch._C.DisableTorchFunctionSubclass():      # a tagged resident view: every attribute read below would dispatch
+                    X = X.as_subclass(torch.Tensor)
             if pc.same_state() and pc.takes(X):
                 return pc.add(X)
         src = getattr(X, "_vlsa_src", None)          # a ResidentBags item as the handler's loader delivers it (vlsa_amd/ingest.py)
@@ -567,10 +608,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             # + the kept tower lists; the encoder: `_la_lists`) -- no second walk over the ~120 modules of the tower
             sub, tensors = list(self._la_lists[1]), list(self._la_lists[2])
             if key[0] is not None:
+                walks = self._provider_walks
                 for m in self._provider_modules():
-                    w = self._tower_lists[1:] if (self._tower_lists is not None and self._tower_lists[0] is m) else self._provider_walks.get(id(m))
-                    if w is None:
-                        w = self._walk_module(m)
+                    w = walks.get(id(m)) or self._walk_module(m)
                     sub += w[0]
                     tensors += w[1]
             if any(isinstance(m, nn.modules.dropout._DropoutNd) and m.p > 0 and m.training for m in sub):
