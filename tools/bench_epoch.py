@@ -28,6 +28,7 @@ NP = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 DT = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32       # fp32 = what patch_reference() stores
 K = P = 12
 BATCH = 32
+EMPTY_CACHE = False        # (set for the timed epochs: see train_epoch)
 c = TC.TOWERS["conch"]
 enc = CONCHPromptEncoder(width=c["width"], heads=c["heads"], layers=c["layers"], vocab_size=c["vocab"], output_dim=c["out_dim"])
 for p_ in enc.parameters():
@@ -92,6 +93,8 @@ def train_epoch():                               # runner/vlsa_handler.py:192-23
             _, p_ = update_network(xs, ys)
             preds.append(p_)
             xs, ys = [], []
+            if EMPTY_CACHE:
+                torch.cuda.empty_cache()             # runner/vlsa_handler.py:222: the reference does this after every mini-batch
     return torch.cat(preds)
 
 
@@ -118,16 +121,19 @@ def timed(fn, reps=3):
 torch.cuda.synchronize(); t0 = time.perf_counter()
 train_epoch()
 torch.cuda.synchronize(); first = time.perf_counter() - t0
+EMPTY_CACHE = True
+train_epoch()
 steps = (NP + BATCH - 1) // BATCH
 print(f"{NP} patients, {patches} patches ({patches * 512 * (2 if DT == torch.bfloat16 else 4) / 1e9:.2f} GB resident as {str(DT)[6:]}), {steps} optimizer steps of {BATCH} bags per epoch")
 print(f"epoch 1 (uploads every bag: host -> HBM): {first * 1e3:.0f} ms")
 res = {}
-for defer in (False, True):
+for defer, ec in ((False, True), (True, True), (True, False)):
     net.defer_training_calls = defer
+    EMPTY_CACHE = ec
     train_epoch()
     res[defer] = timed(train_epoch)
-    print(f"training epoch, handler loops as written, defer_training_calls = {defer}: {res[defer] * 1e3:7.1f} ms = {res[defer] / steps * 1e3:5.2f} ms per step "
-          f"({NP / res[defer]:7.0f} patients/s, {patches / res[defer] / 1e9:.2f} G patches/s trained)")
+    print(f"training epoch, handler loops as written, defer_training_calls = {defer}, torch.cuda.empty_cache() per mini-batch {'as the reference does' if ec else 'REMOVED'}: "
+          f"{res[defer] * 1e3:7.1f} ms = {res[defer] / steps * 1e3:5.2f} ms per step ({NP / res[defer]:7.0f} patients/s, {patches / res[defer] / 1e9:.2f} G patches/s trained)")
 for la in (0, 64):
     net.lookahead_bags = la
     eval_pass()
