@@ -43,7 +43,10 @@ def test_cat_of_the_rows_is_the_batched_tensor_and_gradients_flow():
     preds = torch.cat([o[0] for o in outs], dim=0)                           # runs ONE forward_bags over all five bags
     assert m.calls == 1 and m._pending_calls is None and type(preds) is torch.Tensor and tuple(preds.shape) == (5, 3)
     batch = p._vlsa_batch
-    assert preds is batch.real[0]                                            # the batched tensor itself, not five slices glued together
+    # ONE node over the batched tensor (not five slices glued together), but fresh storage as torch.cat's always is: an in-place
+    # op on the handler's `bag_preds` must not reach what the batch's other outputs read later
+    assert torch.equal(preds, batch.real[0]) and preds.data_ptr() != batch.real[0].data_ptr()
+    assert preds.grad_fn is not None and preds.grad_fn.next_functions[0][0] is batch.real[0].grad_fn
     part = torch.cat([outs[1][0], outs[2][0], outs[4][0]], dim=0)            # rows 1-2 as one slice + row 4
     assert torch.equal(part, preds[[1, 2, 4]])
     mixed = torch.cat([outs[0][0], torch.ones(2, 3), outs[1][0]], dim=0)
@@ -56,6 +59,26 @@ def test_cat_of_the_rows_is_the_batched_tensor_and_gradients_flow():
     assert type(outs[3][0] * 2) is torch.Tensor and type(outs[3][1].detach()) is torch.Tensor and m.calls == 1
     assert float(outs[0][0][0, 1]) == float(preds[0, 1]) and "tensor" in repr(outs[0][0])
     assert torch.equal(outs[0][2] + 0, m.w)
+
+
+def test_cat_result_does_not_alias_the_batch_and_out_kwarg_and_is_leaf():
+    m, bags = _Stub(), _bags(3)
+    outs = [m(x) for x in bags]
+    preds = torch.cat([o[0] for o in outs], dim=0)
+    keep = (outs[1][0] + 0).detach().clone()
+    with torch.no_grad():
+        preds.clamp_(min=100.0)                                              # in place on the handler's tensor
+    assert torch.equal((outs[1][0] + 0).detach(), keep)                      # ... the batch's rows are untouched
+    m2 = _Stub()
+    o2 = [m2(x) for x in bags]
+    buf = torch.empty(3, 3)
+    with torch.no_grad():
+        r = torch.cat([o[0] for o in o2], dim=0, out=buf)                    # an `out=` tensor with several elements: the generic route
+    assert r is buf and torch.equal(buf, m2.forward_bags(bags)[0].detach())
+    m3 = _Stub()
+    a = m3(bags[0])[0]
+    assert m3.calls == 0
+    assert a.is_leaf is False and m3.calls == 1                              # the real row is a slice of the batched result: asking materialises
 
 
 def test_any_operation_triggers_and_a_changed_model_raises():

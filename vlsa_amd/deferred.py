@@ -36,7 +36,8 @@ def _meta_funcs():
     global _META
     if _META is None:
         T = torch.Tensor
-        names = ("shape", "dtype", "device", "requires_grad", "is_cuda", "ndim", "layout", "is_leaf", "names", "is_sparse", "is_quantized",
+        # (`is_leaf` is NOT here: the placeholder is a leaf, the real row is a slice of the batched result -- asking materialises)
+        names = ("shape", "dtype", "device", "requires_grad", "is_cuda", "ndim", "layout", "names", "is_sparse", "is_quantized",
                  "is_meta")
         fs = {getattr(T, n).__get__ for n in names if hasattr(T, n)}
         fs |= {T.dim, T.size, T.numel, T.__len__, T.nelement, T.ndimension, T.element_size, T.is_floating_point, T.is_complex,
@@ -69,12 +70,14 @@ class DeferredOutput(torch.Tensor):
             # single-row slices the backward pass would be 32 slice nodes + 31 adds of zero-padded [B, K] gradients (~1 ms per step)
             seq = args[0] if args else kwargs.get("tensors")
             dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
-            if isinstance(seq, (list, tuple)) and dim in (0, -2) and not kwargs.get("out"):
+            if isinstance(seq, (list, tuple)) and dim in (0, -2) and kwargs.get("out") is None:
                 merged = _merge_rows(seq)
                 if merged is not None:
-                    if len(merged) == 1:
-                        return merged[0]
                     with torch._C.DisableTorchFunctionSubclass():
+                        if len(merged) == 1:
+                            # `torch.cat` hands out FRESH storage: an in-place op on the handler's `bag_preds` must not reach what the
+                            # other outputs of the batch will read later -- one [B, K] copy per step
+                            return merged[0].clone()
                         return torch.cat(merged, dim=0)
         args = _real(args)
         kwargs = {k: _real(v) for k, v in kwargs.items()}
@@ -179,4 +182,9 @@ class TrainingCalls:
                 self.real = m.forward_bags(self.bags)
         finally:
             m._materialising = prev
+        from . import vlsa as _v
+        if _v.ENV_PARANOID:
+            import random
+            j = random.randrange(len(self.bags))
+            m._paranoid_check(self.bags[j], self.real[0][j], f"deferred training batch of {len(self.bags)} bags, bag {j}")
         self.bags = None

@@ -165,7 +165,14 @@ class DeviceBagArena:
         ev = torch.cuda.Event()
         ev.record(self._stream)
         self._ready[key] = ev
+        self.clean_version = self.data._version     # the arena's in-place version after ITS OWN last write (see `modified_in_place`)
         return self._view(key)
+
+    def modified_in_place(self) -> bool:
+        """True when a torch in-place op wrote to the arena (through ANY view of it: they share one version counter) since the arena's
+        own last upload -- resident bags are handed out as views, not copies, so `X.mul_(2)` on one of them would silently corrupt the
+        bag for every later epoch.  (Writes by raw-pointer kernels do not count; nothing in this package issues one on resident rows.)"""
+        return self.data._version != getattr(self, "clean_version", self.data._version)
 
     def add_files(self, key, paths: Sequence[str]) -> torch.Tensor:
         return self.add(key, [read_patch_data(p) for p in paths])
@@ -293,7 +300,11 @@ class ResidentBags(torch.utils.data.Dataset):
     def __init__(self, dataset, device="cuda", dtype: torch.dtype = torch.bfloat16, segment_rows: int = 1 << 21, D: int = 512,
                  first_segment_rows: int = 1 << 17, tag_views: bool = True):
         """tag_views: resident features come back as ``ResidentBagView`` (see there): no collate copy, and the model can serve a
-        bag-by-bag evaluation loop from batched launches."""
+        bag-by-bag evaluation loop from batched launches.  NOTE the aliasing that comes with it: what the loader hands the handler IS
+        the resident rows (the reference's host loader + ``.cuda()`` hand out a private copy per step) -- an in-place op on ``X``
+        would change the bag for good.  Nothing in the reference's handlers writes to ``X``; a write through torch is detected at
+        the next access (``DeviceBagArena.modified_in_place`` -> RuntimeError).  ``tag_views=False``: plain views; the loader's
+        ``default_collate`` then copies every item (the reference's isolation, at one device copy per bag)."""
         self.dataset = dataset
         self._tag_views = bool(tag_views)
         self._device, self._dtype, self._segment_rows, self._D = torch.device(device), dtype, int(segment_rows), int(D)
@@ -366,7 +377,13 @@ class ResidentBags(torch.utils.data.Dataset):
             seg.add(i, feats)
             self._where[i], self._rest[i] = seg, (idx, tuple(data_x[1:]), label)
         idx, rest, label = self._rest[i]
-        feats = self._where[i].bag(i)
+        seg = self._where[i]
+        if seg.modified_in_place():
+            raise RuntimeError("vlsa_amd.ResidentBags: a resident bag was modified IN PLACE since it was uploaded (the handler's loader + "
+                               "`.cuda()` hand out VIEWS of the rows in HBM, not private copies as the reference's host loader does): "
+                               "every later epoch would read the modified rows.  Clone before an in-place op (`X = X.clone()`), or "
+                               "build the dataset with ResidentBags(..., tag_views=False) to get a private copy per item.")
+        feats = seg.bag(i)
         if self._tag_views:
             feats = ResidentBagView.wrap(feats, (self, i))
         return idx, (feats, *rest), label

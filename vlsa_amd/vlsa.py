@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 import operator
+import os
+import random
 from typing import Callable, Optional
 
 import torch
@@ -31,6 +33,9 @@ _GET_TRAINING, _GET_VERSION = operator.attrgetter("training"), operator.attrgett
 # Structure epoch: bumped whenever ANY nn.Module in the process registers a parameter, buffer or submodule (torch's global registration
 # hooks; `module.x = nn.Parameter(...)` goes through them).  Module / tensor lists kept for the cache keys below are valid for the epoch
 # they were walked in -- a re-assigned parameter of the prompt learner is seen at the next key, without walking the learner per call.
+# SIDE EFFECT (documented in INTEGRATION.md 5): the hooks are process-global -- one Python callback per registration in ANY model of the
+# process -- and are installed when the first ``VLSA`` is assembled, not at import.  Removals (``del m.weight``, writes to
+# ``m._parameters[...]``) are not registrations: the keys additionally re-walk on every cache miss, ``_apply`` and ``load_state_dict``.
 _STRUCT_EPOCH = [0, 0]          # [registrations seen, walks that found a changed structure]
 
 
@@ -49,7 +54,23 @@ def _install_structure_hooks():
     _install_structure_hooks.done = True
 
 
-_install_structure_hooks()
+def _env_flag(name: str) -> bool:
+    return os.environ.get(name, "").strip().lower() not in ("", "0", "false", "no", "off")
+
+
+# Environment-level switches for the stateful shortcuts of the boundary, read ONCE at import (a run is one way or the other):
+#   VLSA_AMD_NO_DEFER=1      net(X) in training mode is never deferred (vlsa_amd/deferred.py), whatever `defer_training_calls` says
+#   VLSA_AMD_NO_LOOKAHEAD=1  net(X) over ResidentBags items is never served from a look-ahead window (every call runs its own bag)
+#   VLSA_AMD_PARANOID=1      every materialised deferred batch and every look-ahead window re-computes ONE random bag of it through
+#                            the per-bag route and raises if the logits differ by more than 1e-4 (a device sync per batch / window)
+ENV_NO_DEFER = _env_flag("VLSA_AMD_NO_DEFER")
+ENV_NO_LOOKAHEAD = _env_flag("VLSA_AMD_NO_LOOKAHEAD")
+ENV_PARANOID = _env_flag("VLSA_AMD_PARANOID")
+PARANOID_TOLERANCE = 1e-4
+
+
+class ParanoidMismatch(RuntimeError):
+    """VLSA_AMD_PARANOID=1: a batched shortcut (deferred training calls / look-ahead window) disagreed with the per-bag route."""
 
 
 def build_mil_encoder(image_encoder_cfg: dict) -> nn.Module:
@@ -149,6 +170,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     def _assemble(self, image_encoder_cfg, text_provider=None, pretrained_text_features=None, query_network=None,
                   prompt_learner=None, prompt_encoder=None, logit_scale=math.log(1 / 0.07), cache_text_features=True, kwargs=None,
                   frozen_coop_features=False):
+        _install_structure_hooks()      # process-global registration hooks (see _STRUCT_EPOCH): only once a VLSA model exists
         self.kwargs = kwargs or {}
         self.image_encoder_cfg = dict(image_encoder_cfg)
         self.mil_encoder = build_mil_encoder(self.image_encoder_cfg)
@@ -512,7 +534,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if isinstance(X, (list, tuple)):
             return self.forward_bags(list(X))
         pc = self._pending_calls
-        if pc is not None and self.defer_training_calls and not self._materialising and self.training and torch.is_grad_enabled():
+        if (pc is not None and self.defer_training_calls and not ENV_NO_DEFER and not self._materialising and self.training
+                and torch.is_grad_enabled()):
             # a further call of an open batch of deferred training calls (vlsa_amd/deferred.py): nothing to evaluate here
             if type(X) is not torch.Tensor and isinstance(X, torch.Tensor):
                 with torch._C.DisableTorchFunctionSubclass():      # a tagged resident view: every attribute read below would dispatch
@@ -523,7 +546,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         text_features = self._text_features()
         needs_grad = self._needs_grad(text_features)
         if src is not None:
-            if not needs_grad and not self.training and self.lookahead_bags > 1:
+            if not needs_grad and not self.training and self.lookahead_bags > 1 and not ENV_NO_LOOKAHEAD and not self._materialising:
                 ahead = self._lookahead(src, X, text_features)
                 if ahead is not None:
                     return ahead
@@ -534,7 +557,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 return fused
         else:
             self._la = None                      # a differentiable forward: parameters are about to move
-            if self.defer_training_calls and self.training and not self._materialising:
+            if self.defer_training_calls and not ENV_NO_DEFER and self.training and not self._materialising:
                 deferred = self._defer_call(X, text_features)
                 if deferred is not None:
                     return deferred
@@ -568,17 +591,30 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         return logits, image_features, text_features
 
     # -- deferred training calls: the reference handler's bag-by-bag TRAINING loop at batched speed (vlsa_amd/deferred.py) -------
+    #: plain (non-tensor) attributes of the MIL encoder that change what a forward computes: part of the look-ahead / deferral state
+    _ENC_SCALARS = operator.attrgetter("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type")
+
     def _encoder_lists(self):
+        """(encoder, its submodules, its tensors + logit scale, structure epoch): kept between calls, re-walked when the encoder
+        object changed, when ANY module registered a parameter / buffer / submodule since (``_STRUCT_EPOCH``: a re-assigned
+        ``enc.Q = nn.Parameter(...)`` is seen at the next call), on ``_apply``, ``load_state_dict`` and before every window / batch."""
         ll = self._la_lists
-        if ll is None or ll[0] is not self._modules["mil_encoder"]:
-            enc = self._modules["mil_encoder"]
+        enc = self._modules["mil_encoder"]
+        if ll is None or ll[0] is not enc or ll[3] != _STRUCT_EPOCH[0]:
             sub, tensors = self._walk_module(enc)
             tensors = tensors + [self._parameters["logit_scale"]]
             cs = getattr(enc, "coattn_logit_scale", None)
             if isinstance(cs, torch.Tensor):
                 tensors.append(cs)
-            ll = self._la_lists = (enc, sub, tensors)
+            ll = self._la_lists = (enc, sub, tensors, _STRUCT_EPOCH[0])
         return ll
+
+    def _encoder_scalars(self, enc):
+        try:
+            sc = self._ENC_SCALARS(enc)
+        except AttributeError:        # an encoder class without one of them: read what is there
+            sc = tuple(getattr(enc, n, None) for n in ("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type"))
+        return sc + (self.image_encoder_cfg.get("pooling"),)
 
     def _defer_key(self):
         """Everything a training-mode output depends on besides the bag: the text side (fixed features: the buffer's version; a
@@ -592,12 +628,19 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 return None
         ll = self._encoder_lists()
         return (pk, None if fixed is None else (id(fixed), fixed._version), tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])),
-                self.training)
+                self.training, self._encoder_scalars(ll[0]))
 
     def _defer_call(self, X, text_features):
         from .deferred import TrainingCalls
         if not (TrainingCalls.takes(X) and text_features.dim() == 2):
             return None
+        enc = self.mil_encoder
+        if isinstance(enc, FeatMIL) and enc.pooling not in ("mean", "max"):
+            # identity FeatMIL (zero-shot logit pooling with trainable prompts): the reference returns the bag's [N, D] patch features
+            # as its second output (model/vlsa.py:188-196) -- a deferred batch hands out ONE row per bag, so these calls run as they come
+            return None
+        if not isinstance(enc, (VLFAN, FeatMIL, mil_encoders.DeepMIL)):
+            return None                                      # an encoder this package does not know: no claim about its output shape
         pc = self._pending_calls
         if pc is None or not pc.same_state():
             self._la_lists = None                           # an exact walk of the encoder for the batch's key
@@ -619,6 +662,27 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                                                      text_features.shape[1], X.device)
         return pc.add(X)
 
+    # -- VLSA_AMD_PARANOID=1: cross-check of the batched shortcuts against the per-bag route ----------------------------------------
+    def _paranoid_check(self, X, logits_row, what: str):
+        """Re-compute ONE bag of a deferred batch / look-ahead window through the per-bag route (``forward`` under ``no_grad`` with
+        deferral and look-ahead off: the single-bag kernels) and compare the logits at ``PARANOID_TOLERANCE``; raises
+        ``ParanoidMismatch``.  Syncs the device: a debug mode."""
+        prev, la, pending = self._materialising, self._la, self._pending_calls
+        self._materialising = True
+        try:
+            with torch.no_grad():
+                Xp = X.as_subclass(torch.Tensor) if type(X) is not torch.Tensor else X
+                ref = self.forward(Xp if Xp.dim() == 3 else Xp[None])[0]
+        finally:
+            self._materialising, self._la, self._pending_calls = prev, la, pending
+        err = float((ref.detach().float().reshape(-1) - logits_row.detach().float().reshape(-1)).abs().max())
+        self._paranoid_checks = getattr(self, "_paranoid_checks", 0) + 1
+        if not (err <= PARANOID_TOLERANCE):
+            raise ParanoidMismatch(f"vlsa_amd (VLSA_AMD_PARANOID): {what}: batched logits differ from the per-bag route by {err:.3e} "
+                                   f"(> {PARANOID_TOLERANCE:g}) for a bag of {tuple(X.shape)}; set VLSA_AMD_NO_DEFER=1 / "
+                                   "VLSA_AMD_NO_LOOKAHEAD=1 to run without the shortcut and report this")
+        return err
+
     # -- look-ahead: the reference handler's bag-by-bag evaluation loop at batched speed ---------------------------------------
     def _eval_state(self, text_features):
         """Everything an inference result depends on besides the bag: the text-feature tensor (object + in-place version: the text
@@ -627,11 +691,12 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         scale, the co-attention scale.  The module / tensor lists are kept between calls and rebuilt by an exact walk whenever a
         window is computed, on ``_apply`` and on ``load_state_dict``."""
         ll = self._encoder_lists()
-        return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version)
+        return (ll[2], tuple(map(_GET_VERSION, ll[2])), tuple(map(_GET_TRAINING, ll[1])), text_features, text_features._version,
+                self._encoder_scalars(ll[0]))
 
     @staticmethod
     def _same_state(a, b):
-        return (a[1] == b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4]
+        return (a[1] == b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4] and a[5] == b[5]
                 and (a[0] is b[0] or (len(a[0]) == len(b[0]) and all(x is y for x, y in zip(a[0], b[0])))))
 
     def _lookahead(self, src, X, text_features):
@@ -703,6 +768,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         with torch.no_grad():
             out = self._forward_bags_fused(bagset, text_features)
         logits, feats, That = out[0], out[1], out[2]
+        if ENV_PARANOID:
+            j = random.randrange(len(views))
+            self._paranoid_check(views[j], logits[j], f"look-ahead window of {len(views)} bags from item {lo}, bag {j}")
         per_bag = isinstance(feats, torch.Tensor) and feats.dim() == 2 and feats.shape[0] == len(views)
         # the rows are produced on the stream that is current NOW; a later hit may run under another current stream: an event per
         # window, waited for (on the consumer's stream) until the host has seen it complete
