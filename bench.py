@@ -19,8 +19,14 @@ N = 1  -> BASELINE.json configs[2]: 50k x 512 bf16 bags, P = 12 queries, K = 4 r
           this one GPU (what the N > 1 runs divide among the ranks).
 N > 1  -> BASELINE.json configs[3], STRONG scaling: 200k x 512 bf16 bags, P = 12, K = 8, every bag patch-sharded
           across the N ranks (200k / N rows per GPU: 25k at N = 8).  Per launch each rank streams its shards of the 64
-          bags, folds them into 64 compact records, ONE RCCL all-gather moves world x 64 x 24.7 KB, every rank merges
-          and runs the replicated head; the collective of step i overlaps the streaming kernel of step i+1.
+          bags and folds them into 64 compact records (24.7 KB each); bag b is OWNED by rank b % N: the records travel
+          to their owners, the owner folds the N records of its 64 / N bags and runs the head for them, and the packed
+          results (2.3 KB per bag) travel to everyone (vlsa_amd/sharded.py).  Transport, picked by a self-test at start-up
+          and named in the line (`data_plane`): "ipc" = kernels storing into peer buffers mapped through hipIpc + epoch
+          flags (no collective library on the data path), else RCCL all_to_all_single + all-gather ("owner"), else round
+          1-4's all-gather of all records ("allgather"), else the same over gloo -- the reason for every step down is in
+          the line.  The control plane (barriers, the max over ranks of the time, object exchange at set-up) is a gloo
+          group; an RCCL hang is caught in a probe subprocess with a time-out, not in this process.
           `weak_scaling` in the same line = the round-1 workload (bags of N x 50k patches, 50k rows per GPU, K = 4).
 """
 import argparse
@@ -60,7 +66,7 @@ def _self_launch():
     sys.exit(subprocess.call(cmd))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--probe-rccl" not in sys.argv:
     _self_launch()
 
 import torch  # noqa: E402
@@ -149,6 +155,68 @@ def cpu_baseline(seconds=10.0):
                       f"with {cores} threads = the better 20-bag median of the two thread counts with the best median of 7 warmed calls among {'/'.join(map(str, cands))}; {n1} bags on 1 thread"}
 
 
+def rccl_probe_main():
+    """`python bench.py --probe-rccl` (a child of every rank, same RANK / WORLD_SIZE / LOCAL_RANK, its own MASTER_PORT): bring an
+    RCCL communicator up and run the collectives the data plane uses on small tensors.  Prints one line `RCCL_PROBE_OK`.  A hang here
+    is the parent's time-out, not the bench's."""
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import datetime
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=60))
+    w, r = dist.get_world_size(), dist.get_rank()
+    x = torch.full((4096,), float(r + 1), device=dev)
+    dist.all_reduce(x)
+    assert abs(float(x[0].item()) - w * (w + 1) / 2) < 1e-3
+    src = torch.arange(w * 1024, device=dev, dtype=torch.float32) + 10000 * r
+    dst = torch.empty_like(src)
+    dist.all_to_all_single(dst, src)
+    assert float(dst[1024 * ((r + 1) % w)].item()) == 10000 * ((r + 1) % w) + 1024 * r
+    g = torch.empty(w * 512, device=dev)
+    dist.all_gather_into_tensor(g, x[:512].contiguous())
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_PROBE_OK", flush=True)
+
+
+def probe_rccl(ctrl_dist, timeout_s=120.0):
+    """(ok on EVERY rank, reason).  Each rank runs `bench.py --probe-rccl` in a subprocess with a time-out and its own rendezvous
+    port (rank 0 picks it); the verdicts are AND-ed over the gloo control group."""
+    import socket
+    import subprocess
+    port = [None]
+    if ctrl_dist.get_rank() == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    ctrl_dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    env.pop("VLSA_BENCH_BACKEND", None)
+    t0 = time.perf_counter()
+    why = ""
+    try:
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--probe-rccl"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, start_new_session=True)
+        try:
+            out, _ = pr.communicate(timeout=timeout_s)
+            ok = pr.returncode == 0 and "RCCL_PROBE_OK" in out
+            if not ok:
+                why = f"probe exited {pr.returncode}: " + " | ".join(out.strip().splitlines()[-3:])[-400:]
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(pr.pid, signal.SIGKILL)          # the exact process group this rank started
+            pr.communicate()
+            ok, why = False, f"probe still running after {timeout_s:.0f} s (killed)"
+    except Exception as exc:  # noqa: BLE001
+        ok, why = False, f"probe could not start: {exc!r}"
+    verdicts = [None] * ctrl_dist.get_world_size()
+    ctrl_dist.all_gather_object(verdicts, (bool(ok), why))
+    bad = [f"rank {i}: {w}" for i, (o, w) in enumerate(verdicts) if not o]
+    return (not bad), ("; ".join(bad) if bad else f"ok in {time.perf_counter() - t0:.1f} s")
+
+
 def load_pmc():
     names = (("r04_pmc_batch_kernel_b64.json", "r03_pmc_batch_kernel_b64.json") if BAGS_PER_LAUNCH == 64 else
              ("r04_pmc_batch_kernel.json", "r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
@@ -222,10 +290,89 @@ def main():
         import torch.distributed as dist
         if force_sharded and "RANK" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29677", RANK="0", WORLD_SIZE="1")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))      # control plane (CPU, TCP on 127.0.0.1)
+
+    # ---- data plane of the N > 1 runs: (exchange, process group) candidates in order of preference, each SELF-TESTED below on one
+    # launch against the plain all-gather over the control group; the first that passes carries the headline, the others that pass
+    # get a short leg of their own (`exchanges` in the line), the ones that fail leave their reason (`data_plane.fallbacks`)
+    data_plane = {"chosen": None, "fallbacks": [], "control_plane": "gloo"}
+    candidates = []
+    rccl_group = None
+    if dist is not None:
+        want = os.environ.get("VLSA_BENCH_EXCHANGE", "auto")            # auto | ipc | owner | allgather
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+            if world > torch.cuda.device_count():
+                data_plane["fallbacks"].append({"what": "rccl", "why": f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible"})
+            else:
+                ok, why = probe_rccl(dist, float(os.environ.get("VLSA_BENCH_PROBE_TIMEOUT", "150")))
+                data_plane["rccl_probe"] = why
+                if ok:
+                    try:
+                        import datetime
+                        rccl_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=device)
+                    except Exception as exc:  # noqa: BLE001
+                        data_plane["fallbacks"].append({"what": "rccl", "why": f"new_group failed: {exc!r}"})
+                else:
+                    data_plane["fallbacks"].append({"what": "rccl", "why": why})
+        order = ["ipc", "owner", "allgather"] if want == "auto" else [want]
+        for ex in order:
+            if ex == "ipc":
+                candidates.append(("ipc", None, "ipc"))
+            elif rccl_group is not None:
+                candidates.append((ex, rccl_group, f"{ex}/rccl"))
+        for ex in (["owner", "allgather"] if want == "auto" else [want]):
+            if ex != "ipc":
+                candidates.append((ex, None, f"{ex}/gloo"))
+        if ("allgather", None, "allgather/gloo") not in candidates:
+            candidates.append(("allgather", None, "allgather/gloo"))
+
+    def make_sharded_plan(B_, K_, exchange, group, **kw):
+        from vlsa_amd.sharded import ShardedVlfanBatchPlan
+        return ShardedVlfanBatchPlan(B_, P, K_, device, dist, group=group, exchange=exchange, **kw)
+
+    def self_test(exchange, group, name):
+        """one unpipelined launch of 2 * world + 1 small bags through `exchange` against the all-gather over the control group;
+        (ok, reason) agreed by every rank"""
+        ok, why = True, ""
+        try:
+            Bt, Kt = 2 * world + 1, 4
+            Q, T, W, b, ls = synth_params(device, Kt)
+            bags = synth_bags(device, 4000 + rank, Bt, 700 + 64 * rank)
+            ref = make_sharded_plan(Bt, Kt, "allgather", None, pipeline=False)
+            ref.set_bags(bags)
+            want_ = ref.run(Q, T, ls, W, b).clone()
+            pl = make_sharded_plan(Bt, Kt, exchange, group, pipeline=False, timeout_s=10.0)
+            pl.set_bags(bags)
+            for _ in range(3):           # three launches: both slots and the acknowledgement gates of the peer-write protocol
+                got = pl.run(Q, T, ls, W, b)
+            torch.cuda.synchronize()
+            err = float((got - want_).abs().max())
+            st = pl.status()
+            if not (err < 2e-5) or st != 0:
+                ok, why = False, f"self-test: |dlogit| {err:.2e} vs the all-gather over gloo, time-out bits {st}"
+            if hasattr(pl, "close"):
+                pl.close()
+        except Exception as exc:  # noqa: BLE001
+            ok, why = False, f"self-test raised {type(exc).__name__}: {str(exc)[:300]}"
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, (ok, why))
+        bad = [f"rank {i}: {w}" for i, (o, w) in enumerate(verdicts) if not o]
+        return (not bad), "; ".join(bad)
+
+    working = []
+    if dist is not None:
+        for ex, grp, name in candidates:
+            ok, why = self_test(ex, grp, name)
+            if ok:
+                working.append((ex, grp, name))
+            else:
+                data_plane["fallbacks"].append({"what": name, "why": why})
+        if not working:
+            sys.exit("bench.py: no exchange passed its self-test: " + json.dumps(data_plane))
+        data_plane["chosen"] = working[0][2]
+        data_plane["also_working"] = [n for _, _, n in working[1:]]
+    chosen = working[0] if working else None
 
     BPL, LPS = BAGS_PER_LAUNCH, LAUNCHES_PER_STEP
     NS = max(1, a.streams)
@@ -241,7 +388,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(rows_local, rows_global, K, steps, warmup, seed, roofline, dtype=torch.bfloat16, want_attn=False, verify_every=1):
+    def measure(rows_local, rows_global, K, steps, warmup, seed, roofline, dtype=torch.bfloat16, want_attn=False, verify_every=1,
+                plane=None):
         """K-class head, BPL bags of `rows_local` rows (bf16 or fp32) on this rank (`rows_global` over all ranks); want_attn: the
         same launches also hand out every bag's attention weights A [P, N] (N = 1 only).  Returns (seconds of `steps` steps = max
         over ranks, roofline dict or None, info dict).  roofline = True also binds the timed launches to the CPU oracle: logits of
@@ -254,8 +402,8 @@ def main():
             if dist is None:
                 pl = F.VlfanBatchPlan(BPL, P, K, device, reserved_cus=RESERVED, want_attn=want_attn)
             else:
-                from vlsa_amd.sharded import ShardedVlfanBatchPlan
-                pl = ShardedVlfanBatchPlan(BPL, P, K, device, dist, reserved_cus=RESERVED)
+                ex_, grp_, _name = plane or chosen
+                pl = make_sharded_plan(BPL, K, ex_, grp_, reserved_cus=RESERVED)
             pl.set_bags(bags)
             plans.append(pl)
 
@@ -287,7 +435,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
 
@@ -347,7 +495,7 @@ def main():
             # restatement of the reference's op sequence) on the same rows, tolerance 1e-4 (north star) -- every `verify_every`-th
             # bag (N = 1: all 64).  N > 1: the shards of each checked bag are gathered on rank 0 first.  A mismatch fails the run.
             last = plans[(n_last - 1) % NS]
-            got_all = (last.local.logits if dist is not None else last.logits).float().cpu()
+            got_all = last.logits.float().cpu()
             which = list(range(0, BPL, max(1, verify_every)))
             sizes = [shard_bounds(rows_global, world, r)[1] - shard_bounds(rows_global, world, r)[0] for r in range(world)]
             errs, t_or = [], time.perf_counter()
@@ -357,7 +505,7 @@ def main():
                     pad = torch.zeros(max(sizes), D, dtype=X0.dtype, device=device)
                     pad[:X0.shape[0]] = X0
                     parts = [torch.empty_like(pad) for _ in range(world)]
-                    dist.all_gather(parts, pad)
+                    dist.all_gather(parts, pad, group=rccl_group)         # (None = the gloo control group: through the host)
                     X0 = torch.cat([p_[:n_] for p_, n_ in zip(parts, sizes)]) if rank == 0 else None
                 if rank == 0:
                     ref, refA = oracle_check(X0, Q, T, ls, W, b, want_attn and i in (which[0], which[-1]))
@@ -384,46 +532,49 @@ def main():
                 base.run_partial_only()
             e1.record()
             torch.cuda.synchronize()
-            mine = torch.tensor([e0.elapsed_time(e1) * 100.0], device=device, dtype=torch.float64)      # us per launch
+            mine = torch.tensor([e0.elapsed_time(e1) * 100.0], dtype=torch.float64)      # us per launch
             if dist is not None:
                 allk = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allk, mine)
                 info["per_rank_kernel_us"] = [round(float(t.item()), 1) for t in allk]
+                ex_, grp_, name_ = plane or chosen
                 ones = torch.ones(1, device=device)
-                dist.all_reduce(ones)
-                info["communicator"] = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "allreduce_of_ones": int(ones.item())}
-                # ---- exchange accounting: the same steps with the all-gather left out (local work only) -> what the collective
-                # still costs on the critical path; and one all-gather of this size alone on an idle stream
-                for pl in plans:
-                    pl.skip_exchange = True
-                run_steps(max(1, warmup // 2))
-                sync()
-                t0 = time.perf_counter()
-                run_steps(steps)
-                sync()
-                dt_local = time.perf_counter() - t0
-                for pl in plans:
-                    pl.skip_exchange = False
-                tt = torch.tensor([dt_local], device=device, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt_local = float(tt.item())
-                from vlsa_amd.sharded import all_gather_records
+                dist.all_reduce(ones, group=grp_)
+                info["communicator"] = {"data_plane": name_, "collective_backend": dist.get_backend(grp_), "nranks": dist.get_world_size(),
+                                        "allreduce_of_ones": int(ones.item())}
+                # ---- exchange accounting: what this rank really moves per launch, and -- for the collective transports -- the same
+                # steps with the exchange left out (local work only) -> what the exchange still costs on the critical path
                 pl = plans[0]
-                for _ in range(5):
-                    all_gather_records(pl.rec[0], pl.gathered[0], pl.group)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(20):
-                    all_gather_records(pl.rec[0], pl.gathered[0], pl.group)
-                e1.record()
-                torch.cuda.synchronize()
-                info["exchange"] = {"ms_per_step_with": dt / steps * 1e3, "ms_per_step_without": dt_local / steps * 1e3,
-                                    "exposed_ms_per_step": (dt - dt_local) / steps * 1e3,
-                                    "allgather_alone_us": e0.elapsed_time(e1) * 50.0, "bytes_per_rank": int(pl.rec[0].numel() * 4),
-                                    "note": "exposed = step time with minus without the collective; the rest of its latency hides behind "
-                                            "the next launch's streaming kernel (side stream, 32 CUs left free)"}
+                xb = pl.exchange_bytes()
+                info["exchange"] = {"kind": ex_, "transport": name_, "bytes_sent_per_rank_per_launch": xb["sent"],
+                                    "bytes_received_per_rank_per_launch": xb["received"], "what": xb["what"],
+                                    "record_bytes": int(pl.rf * 4), "bags_per_launch": BPL, "ms_per_step_with": dt / steps * 1e3,
+                                    "timeout_bits": max(p_.status() for p_ in plans)}
+                if ex_ != "ipc":
+                    for p_ in plans:
+                        p_.skip_exchange = True
+                    run_steps(max(1, warmup // 2))
+                    sync()
+                    t0 = time.perf_counter()
+                    run_steps(steps)
+                    sync()
+                    dt_local = time.perf_counter() - t0
+                    for p_ in plans:
+                        p_.skip_exchange = False
+                    tt = torch.tensor([dt_local], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt_local = float(tt.item())
+                    info["exchange"].update({"ms_per_step_without": dt_local / steps * 1e3, "exposed_ms_per_step": (dt - dt_local) / steps * 1e3,
+                                             "note": "exposed = step time with minus without the exchange; the rest of its latency hides "
+                                                     "behind the other stream's streaming kernel (32 CUs left free)"})
+                if info["exchange"]["timeout_bits"]:
+                    info.setdefault("verified", {})["ok"] = False
+                    info["verified"]["why"] = "a flag wait of the peer-write exchange timed out"
             else:
                 info["per_rank_kernel_us"] = [round(float(mine.item()), 1)]
+        for p_ in plans:
+            if hasattr(p_, "close"):
+                p_.close()
         del plans, bags
         torch.cuda.empty_cache()
         return dt, roof, info
@@ -580,9 +731,20 @@ def main():
         dt, roof, info = measure(hi - lo, rows, K, a.steps, a.warmup, 100 + rank, True, verify_every=4)
         total = BPL * LPS * rows * a.steps
         workload = (f"{cfg}: synthetic 200k x 512 bf16 bags, P=12, K=8, patch-sharded over {world} GPUs ({rows // world} rows per "
-                    f"GPU per bag), one RCCL all-gather of compact records per launch; one step = {BPL * LPS} bags = {LPS} "
-                    f"launches of {BPL} bags")
+                    f"GPU per bag), records to their bag owners + packed results to everyone per launch ({chosen[2]}); one step = "
+                    f"{BPL * LPS} bags = {LPS} launches of {BPL} bags")
+        extra["data_plane"] = data_plane
         if not a.no_extra:
+            legs = {}
+            for pl_ in working[1:]:      # the other transports that passed their self-test: a short leg each, same workload
+                try:
+                    s_ = max(4, a.steps // 2)
+                    dtx, _, infx = measure(hi - lo, rows, K, s_, max(2, a.warmup // 2), 100 + rank, True, verify_every=16, plane=pl_)
+                    legs[pl_[2]] = {"value": BPL * LPS * rows * s_ / dtx, "unit": "patches/s", "steps": s_, "ms_per_step": dtx / s_ * 1e3,
+                                    "exchange": infx.get("exchange"), "verified": infx.get("verified")}
+                except Exception as exc:  # noqa: BLE001
+                    legs[pl_[2]] = {"error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+            extra["exchanges"] = legs
             rw, Kw = CONFIGS["configs[2]"]["rows"], CONFIGS["configs[2]"]["K"]
             dtw, _, _ = measure(rw, rw * world, Kw, a.steps, a.warmup, 500 + rank, False)
             extra["weak_scaling"] = {"workload": f"bags of {world} x 50k patches, 50k rows per GPU per bag, P=12, K=4 (round-1 --gpus workload)",
@@ -630,4 +792,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--probe-rccl" in sys.argv:
+        rccl_probe_main()
+    else:
+        main()

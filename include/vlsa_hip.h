@@ -617,6 +617,40 @@ int vlsa_vlfan_backward_dx(const void* bag_desc, const void* dx_desc, int B, int
 int vlsa_fill_one_bag_tables(void* dst, const void* X, int64_t N, int64_t ld, const void* extra, int64_t extra_ld, int tile_rows,
                              void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Peer-write exchange of the patch-sharded multi-GPU path (csrc/xchg.hip).  The reference has no multi-GPU code
+ * ("NCCL call sites: none"); the payload is the per-query partial sums of model/deepmil.py:198-200 as compact
+ * records [m2(16) | l(16) | acc(P*D)] and the owner's head outputs (model/vlsa.py:188-192).  One process per GPU; every rank
+ * exports ONE fine-grained buffer, maps its peers' buffers, and the data path is kernels writing over xGMI + epoch flags.
+ *
+ * Set-up calls (the ONLY entry points that allocate / synchronise; once per plan, never on the hot path):
+ *   vlsa_xchg_alloc   zeroed device buffer of `bytes` (uncached, else fine-grained, else plain: *kind = 2 / 1 / 0) + its 64-byte
+ *                     hipIpcMemHandle_t in handle64 (HOST memory).  VLSA_EUNSUPPORTED: the driver refuses IPC for it.
+ *   vlsa_xchg_open    map a peer's handle (another process, same or another GPU of the node) -> device address
+ *   vlsa_xchg_close / vlsa_xchg_free
+ * Data path (enqueue only; the pointer tables are HOST arrays of `world` device addresses, `status` a zeroed device uint32 that
+ * collects time-out bits 1 (put gate) | 2 (wait) | 4 (collect); timeout_ticks in 100 MHz wall-clock ticks):
+ *   vlsa_xchg_put     block d: [wait gate[d] >= gate_epoch], copy n16[d] x 16 B  src[d] -> dst[d], system fence,
+ *                     flag[d] = epoch (and ack[d] = epoch).  ack / gate nullable (table or entry).
+ *   vlsa_xchg_wait    until every flag[r] >= epoch
+ *   vlsa_xchg_collect block o: [wait flag[o] >= epoch]; owner o's result box (vlsa_xchg_result_floats layout, count[o] bags) ->
+ *                     logits [B, K], incidence [B, K] (nullable), vhat [B, D], m2 / l [B, 16] at bag j * world + o (the caller's bag
+ *                     order), m2_local / l_local (nullable pair) at start[o] + j (the owner-major order of the local bag table);
+ *                     [ack[o] = epoch].  flag / ack tables nullable: the boxes then hold the output of a collective. */
+int vlsa_xchg_max_peers(void);
+size_t vlsa_xchg_result_floats(int nmax, int K, int D, int64_t* offsets5);
+int vlsa_xchg_alloc(size_t bytes, void** ptr, void* handle64, int* kind);
+int vlsa_xchg_open(const void* handle64, void** ptr);
+int vlsa_xchg_close(void* ptr);
+int vlsa_xchg_free(void* ptr);
+int vlsa_xchg_put(int world, const void* const* src, void* const* dst, const uint32_t* n16, void* const* flag, void* const* ack,
+                  const void* const* gate, uint32_t epoch, uint32_t gate_epoch, int64_t timeout_ticks, void* status, void* stream);
+int vlsa_xchg_wait(int world, const void* const* flag, uint32_t epoch, int64_t timeout_ticks, void* status, void* stream);
+int vlsa_xchg_collect(int world, const void* const* box, const void* const* flag, void* const* ack, const int* count,
+                      const int* start, int nmax, int K, int D, uint32_t epoch, int64_t timeout_ticks, float* logits,
+                      float* incidence, float* vhat, float* m2, float* l, float* m2_local, float* l_local, void* status,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,79 @@ def test_two_rank_zeroshot_topk_and_attention_pool_exchange():
     assert len(ret) == world
     for r in range(world):
         assert ret[r][0] < 1e-4 and ret[r][1] < 1e-5, ret[r]
+
+
+# ---- bag-owner exchange (round 5): records to their owners (all_to_all_single with split sizes), owner-side fold, packed results to
+# everyone, assembly in the caller's bag order -- the partition / split / ordering logic of ShardedVlfanBatchPlan(exchange="owner")
+def test_owner_partition_covers_every_bag_once():
+    from vlsa_amd.sharded import owner_partition
+    for B in (1, 3, 5, 8, 64, 65):
+        for world in (1, 2, 3, 4, 8):
+            perm, counts, starts = owner_partition(B, world)
+            assert sorted(perm) == list(range(B)) and sum(counts) == B and len(counts) == world
+            for o in range(world):
+                mine = perm[starts[o]:starts[o] + counts[o]]
+                assert mine == list(range(o, B, world))                     # bag b is owned by rank b % world, in rising order
+            assert max(counts) - min(counts) <= 1 and max(counts) == counts[0]
+
+
+def _worker_owner(rank, world, port, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vlsa_amd import sharded
+        P, K = 4, 3
+        LOG2E = 1.4426950408889634
+        rf = sharded.record_floats(P, 512)
+        params = cases.make_params(P, K, 31)
+        Q = 0.5 * params["resid"] + params["prompt"]
+        Qh = O.l2_normalize(Q)
+        sizes = [40 + 37 * i for i in range(B)]
+        bags = [cases.make_bag(n, 700 + i) for i, n in enumerate(sizes)]
+        perm, counts, starts = sharded.owner_partition(B, world)
+        n_me = counts[rank]
+        # local records in owner-major order (what the streaming kernel + local fold leave in `rec`)
+        rec = torch.zeros(B, rf)
+        for t, bidx in enumerate(perm):
+            a, b = sharded.shard_bounds(sizes[bidx], world, rank)
+            if b > a:
+                m, l, acc, _ = O.vlfan_partial(bags[bidx][a:b], Qh)
+                rec[t, :P], rec[t, 16:16 + P], rec[t, 32:] = m * LOG2E, l, acc.reshape(-1)
+            else:
+                rec[t, :P] = float("-inf")                                   # an empty shard: the neutral record
+        recv = torch.empty(world, max(n_me, 1), rf)
+        dist.all_to_all_single(recv.view(-1)[:world * n_me * rf], rec.view(-1), output_split_sizes=[n_me * rf] * world,
+                               input_split_sizes=[c * rf for c in counts])
+        # owner-side fold + "head" (here: the pooled mean row's first K entries stand in for the logits)
+        nmax = max(counts)
+        res = torch.zeros(nmax, K + 16)
+        for j in range(n_me):
+            ms = [recv[r, j, :P] / LOG2E for r in range(world)]
+            ls = [recv[r, j, 16:16 + P] for r in range(world)]
+            accs = [recv[r, j, 32:].reshape(P, 512) for r in range(world)]
+            mg, lg, out = O.merge_partials(ms, ls, accs)
+            res[j, :K] = out.mean(dim=0)[:K]
+            res[j, K:K + P] = lg
+        resg = torch.empty(world, nmax, K + 16)
+        dist.all_gather_into_tensor(resg.view(-1), res.view(-1))
+        # assembly in the caller's order: bag b = j * world + o  (what vlsa_xchg_collect does on the device)
+        got = torch.stack([resg[b % world, b // world] for b in range(B)])
+        err = 0.0
+        for bidx in range(B):
+            ref = O.vlfan_forward(bags[bidx], Q)["out"].mean(dim=0)[:K]
+            err = max(err, (got[bidx, :K] - ref).abs().max().item())
+        ret[rank] = (err, got[:, :K].clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (3, 4), (3, 2)])
+def test_owner_exchange_over_gloo_matches_the_unsharded_result(world, B):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29100 + (os.getpid() % 300) + 7 * world + B
+    mp.spawn(_worker_owner, args=(world, port, B, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert ret[r][0] < 1e-4, (r, ret[r][0])
+        assert torch.equal(ret[r][1], ret[0][1])                              # identical on every rank

@@ -152,6 +152,17 @@ _SIGNATURES = {
     "vlsa_vlfan_backward_dx": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_debug_probe": (c_int, [c_int, c_void_p, c_size_t, c_void_p]),
+    "vlsa_xchg_max_peers": (c_int, []),
+    "vlsa_xchg_result_floats": (c_size_t, [c_int, c_int, c_int, c_void_p]),
+    "vlsa_xchg_alloc": (c_int, [c_size_t, c_void_p, c_void_p, c_void_p]),
+    "vlsa_xchg_open": (c_int, [c_void_p, c_void_p]),
+    "vlsa_xchg_close": (c_int, [c_void_p]),
+    "vlsa_xchg_free": (c_int, [c_void_p]),
+    "vlsa_xchg_put": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_int64, c_void_p,
+                              c_void_p]),
+    "vlsa_xchg_wait": (c_int, [c_int, c_void_p, c_uint32, c_int64, c_void_p, c_void_p]),
+    "vlsa_xchg_collect": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_uint32, c_int64]
+                          + [c_void_p] * 9),
 }
 
 _lib = None
