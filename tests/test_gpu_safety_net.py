@@ -32,6 +32,16 @@ def _item(rb, i):
     return torch.utils.data.default_collate([rb[i]])[1][0].cuda()
 
 
+def _resident(sizes, **kw):
+    from vlsa_amd.ingest import ResidentBags
+    ds = _Items(sizes, **kw)
+    rb = ResidentBags(ds, dtype=torch.float32)
+    for i in range(len(sizes)):
+        rb[i]                               # upload: look-ahead windows only span items that are resident already
+    torch.cuda.synchronize()
+    return ds, rb
+
+
 def test_no_defer_switch_wins_over_the_model_flag(monkeypatch):
     from vlsa_amd import vlsa as V
     from vlsa_amd.deferred import DeferredOutput
@@ -51,7 +61,7 @@ def test_no_lookahead_switch(monkeypatch):
     from vlsa_amd.ingest import ResidentBags
     net, _ = _vlfan_net()
     net.eval()
-    rb = ResidentBags(_Items([500, 300, 700, 64]), dtype=torch.float32)
+    _, rb = _resident([500, 300, 700, 64])
     with torch.no_grad():
         a = [net(_item(rb, i))[0].clone() for i in range(4)]
         assert net._la is not None and len(net._la["rows"]) == 4
@@ -79,7 +89,7 @@ def test_paranoid_checks_run_and_catch_a_wrong_batch(monkeypatch):
     assert net.mil_encoder.Q.grad is not None
     # look-ahead windows
     net.eval()
-    rb = ResidentBags(_Items([500, 300, 700, 64, 900, 129]), dtype=torch.float32)
+    _, rb = _resident([500, 300, 700, 64, 900, 129])
     with torch.no_grad():
         for i in range(6):
             net(_item(rb, i))
@@ -154,8 +164,7 @@ def test_lookahead_sees_a_reassigned_encoder_parameter_and_a_changed_scalar():
     from vlsa_amd.ingest import ResidentBags
     net, _ = _vlfan_net()
     net.eval()
-    ds = _Items([500, 300, 700, 64, 900, 129])
-    rb = ResidentBags(ds, dtype=torch.float32)
+    ds, rb = _resident([500, 300, 700, 64, 900, 129])
     enc = net.mil_encoder
 
     def check(i, what):
