@@ -427,7 +427,8 @@ def main():
 
         # Untimed, before the W warm-up steps: ~15 ms of the same launches so that the GPU clocks have ramped (an MI355X
         # drops its clocks within a few hundred us of idling and needs ~5 ms to come back; profiles/README.md).
-        run_steps(max(4, int(RAMP * 50_000 * 2 / max(rows_local * esz, 1)) // LPS))
+        # (the count must be the SAME on every rank -- the ranks' shards differ by up to 16 rows: computed from the global size)
+        run_steps(max(4, int(RAMP * 50_000 * 2 / max((rows_global // world) * esz, 1)) // LPS))
         run_steps(warmup)
         sync()
         t0 = time.perf_counter()
