@@ -126,7 +126,15 @@ int vlsa_attn_normalise(const float* scores, int P, int64_t N, const float* m2, 
 /* out[r, :] = in[r, :] / max(||in[r, :]||, 1e-12); norms[r] (nullable) = that denominator. (F.normalize) */
 int vlsa_normalize_rows(const float* in, int rows, int D, float* out, float* norms, void* stream);
 
-/* Bytes of scratch vlsa_head_forward needs (a ticket counter).  The caller zeroes it ONCE after allocation; every
+/* Partial merge + head of ONE bag in one call (the tail of vlsa_vlfan_forward_bag; model/deepmil.py:198-204 + model/vlsa.py:188-192):
+ * vlsa_vlfan_merge(normalise = 1) + vlsa_head_forward with the same arguments and results.  D == 512, mean / weight pooling and a
+ * Linear adapter run as two ticket-free launches (the merge workgroups multiply their merged columns with their slice of W). */
+int vlsa_vlfan_merge_head(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int pool_mode,
+                          const float* pool_w, const float* W, const float* b, const float* That, int K,
+                          const float* logit_scale, void* head_ws, float* m2, float* l, float* out, float* pooled, float* v,
+                          float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
+
+/* Bytes of scratch vlsa_head_forward / vlsa_vlfan_merge_head need (a ticket counter + partial adapter vectors).  The caller zeroes it ONCE after allocation; every
  * call leaves it zeroed again, so no per-call memset is needed (one workspace per stream in flight). */
 size_t vlsa_head_workspace_bytes(int D);
 

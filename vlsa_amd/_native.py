@@ -49,6 +49,8 @@ _SIGNATURES = {
     "vlsa_attn_normalise": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "vlsa_head_workspace_bytes": (c_size_t, [c_int]),
+    "vlsa_vlfan_merge_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int]
+                              + [c_void_p] * 12),
     "vlsa_head_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),

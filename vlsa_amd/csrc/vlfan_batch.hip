@@ -639,6 +639,81 @@ __global__ __launch_bounds__(512, 4) void k_vlfan_merge_pool_batch(const float* 
     }
 }
 
+// Merge + query pooling for FEW partials per bag (G <= 8: wide launches of slide-sized bags run one workgroup per bag, G = 1;
+// 64 x 50k bags 8): ONE workgroup per bag, thread = column.  The (m, l) of all G x P partial records go through 1 KB of LDS,
+// then every accumulator piece a thread needs (<= 16 queries x 2 partials per round) is in flight at once.  At B = 256, G = 1
+// k_vlfan_merge_pool_batch took 13.6 us (2 048 workgroups of 512 threads, a serial pooling loop each); this one 256 workgroups.
+// <= 8 KiB LDS, <= 96 VGPRs: may co-reside with a persistent streaming kernel of another stream.
+__global__ __launch_bounds__(512, 3) void k_vlfan_merge_pool_small(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                                    const float* __restrict__ pacc, int G, int P, int D,
+                                                                    float* __restrict__ m2, float* __restrict__ l,
+                                                                    float* __restrict__ out, MergeStrides st, int pool_mode,
+                                                                    const float* __restrict__ pool_w, float* __restrict__ pooled) {
+    __shared__ float sm_[8][VLSA_MAX_P], sl_[8][VLSA_MAX_P];   // per partial: exp2(m_g - m) and l_g
+    __shared__ float sinv[VLSA_MAX_P], spw[VLSA_MAX_P];
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
+    const int tid = threadIdx.x, bag = blockIdx.x;
+    pm += (size_t)bag * st.bm;
+    pl += (size_t)bag * st.bl;
+    pacc += (size_t)bag * st.ba;
+    if (tid < 8 * VLSA_MAX_P) {
+        const int g = tid >> 4, p = tid & 15;
+        const bool ok = g < G && p < P;
+        sm_[g][p] = ok ? pm[(size_t)g * st.sm + p] : -INFINITY;
+        sl_[g][p] = ok ? pl[(size_t)g * st.sl + p] : 0.f;
+    }
+    if (pool_mode == VLSA_POOL_WEIGHT && tid == 256) {
+        float mx = -INFINITY, sum = 0.f;
+        for (int q = 0; q < P; ++q) mx = fmaxf(mx, pool_w[q]);
+        for (int q = 0; q < P; ++q) { spw[q] = expf(pool_w[q] - mx); sum += spw[q]; }
+        for (int q = 0; q < P; ++q) spw[q] /= sum;
+    }
+    __syncthreads();
+    if (tid < VLSA_MAX_P) {
+        const int p = tid;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) mx = fmaxf(mx, sm_[g][p]);
+        float ls = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float f = sm_[g][p] == -INFINITY ? 0.f : fast_exp2(sm_[g][p] - mx);
+            ls += sl_[g][p] * f;
+            sm_[g][p] = f;
+        }
+        sinv[p] = 1.f / ls;
+        if (p < P) {
+            m2[(size_t)bag * st.om + p] = mx;
+            l[(size_t)bag * st.ol + p] = ls;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < D; c += 512) {
+        float acc[VLSA_MAX_P];
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p) acc[p] = 0.f;
+        for (int g = 0; g < G; ++g) {       // one partial record per round: its <= 16 pieces in flight together
+            float x[VLSA_MAX_P];
+#pragma unroll
+            for (int p = 0; p < VLSA_MAX_P; ++p) x[p] = p < P ? pacc[(size_t)g * st.sa + (size_t)p * D + c] : 0.f;
+#pragma unroll
+            for (int p = 0; p < VLSA_MAX_P; ++p) acc[p] += x[p] * sm_[g][p];
+        }
+        float r = pool_mode == VLSA_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+        for (int p = 0; p < VLSA_MAX_P; ++p)
+            if (p < P) {
+                const float o = acc[p] * sinv[p];
+                out[(size_t)bag * st.oo + (size_t)p * D + c] = o;
+                if (pool_mode == VLSA_POOL_MAX) r = fmaxf(r, o);
+                else if (pool_mode == VLSA_POOL_WEIGHT) r += spw[p] * o;
+                else r += o;
+            }
+        if (pool_mode == VLSA_POOL_MEAN) r /= (float)P;
+        if (pooled != nullptr) pooled[(size_t)bag * D + c] = r;
+    }
+}
+
 // A[p, n] = exp2(t[p, n] - m2[bag, p]) / l[bag, p] for every bag of a batch (softmax over the patches, model/deepmil.py:198),
 // from the scores the streaming kernel stored and the bag-global (m2, l) of the merge.  grid (chunks of 1024 patches, P, B);
 // float4 per thread; may run in place (A == scores).  Columns N .. ld-1 of a row hold -inf scores -> 0.
@@ -672,6 +747,18 @@ int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float
 int vlsa_launch_head_rows_batch(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
                                 const float* b, const float* That, int K, const float* logit_scale, float* pooled, float* v,
                                 float* vhat, float* vnorm, float* logits, float* incidence, hipStream_t s);  // vlfan_tail.hip
+
+// merge + pooling of B bags: few partials per bag -> one workgroup per bag, else the (64 columns, bag) workgroups
+static int launch_merge_pool(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D, float* m2, float* l,
+                             float* out, const MergeStrides& st, int pool_mode, const float* pool_w, float* pooled, hipStream_t s) {
+    if (G <= 8)
+        hipLaunchKernelGGL(k_vlfan_merge_pool_small, dim3(B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st, pool_mode, pool_w,
+                           pooled);
+    else
+        hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
+                           pool_mode, pool_w, pooled);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
 
 #ifdef VLSA_TIMING
 extern "C" int vlsa_debug_read_batch_cycles(long long* host_out) {
@@ -835,9 +922,7 @@ extern "C" int vlsa_vlfan_forward_batch_attn(const void* bag_desc, int B, int x_
     const MergeStrides st{kPStride, kPStride, (int64_t)P * D, (int64_t)G * kPStride, (int64_t)G * kPStride,
                           (int64_t)G * P * D, kPStride, kPStride, (int64_t)P * D};
     // merge + pooling in one kernel; the head then starts from the pooled vectors (2 KB instead of P x 2 KB per workgroup)
-    hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
-                       pool_mode, pool_w, pooled);
-    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    if (launch_merge_pool(pm, pl, pacc, B, G, P, D, m2, l, out, st, pool_mode, pool_w, pooled, s) != VLSA_OK) return VLSA_ELAUNCH;
     (void)counters;
     const int rh = vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
     if (rh != VLSA_OK || !scores_desc) return rh;
@@ -880,9 +965,7 @@ extern "C" int vlsa_vlfan_merge_head_batch_strided(const float* pm, const float*
     if ((st.sa % 4) || (st.ba % 4) || (st.oo % 4) || (reinterpret_cast<uintptr_t>(pacc) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return VLSA_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
-                       pool_mode, pool_w, pooled);
-    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    if (launch_merge_pool(pm, pl, pacc, B, G, P, D, m2, l, out, st, pool_mode, pool_w, pooled, s) != VLSA_OK) return VLSA_ELAUNCH;
     return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
 }
 

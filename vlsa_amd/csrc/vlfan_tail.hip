@@ -309,6 +309,72 @@ __global__ __launch_bounds__(256) void k_head_linear(const float* __restrict__ p
         }
 }
 
+// v = pooled W^T + b for MANY bags on the f32 matrix pipe (round 5; D == 512): workgroup (bag tile of 16, output tile of 32),
+// 8 waves, wave w contracts columns [64 w, 64 w + 64) with v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: no split, no
+// rounding beyond fp32) -- A = pooled (M = bag), B = W rows (N = output), one float4 per lane and fragment feeds four k-steps
+// (k-slot g of step t <-> column 16 it + 4 g + t, the same map on both sides).  All 12 float4 loads of a wave are in flight
+// at once; the eight partial tiles are summed through 8 KiB of LDS in a fixed order.  k_head_linear (VALU, 2 048 workgroups at
+// B = 256) took 26.7 us of a 168 us step of 256 slide-sized bags.  <= 8 KiB LDS, <= 96 VGPRs: co-resides with a persistent kernel.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void k_head_linear_mfma(const float* __restrict__ pooled, int B, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ v) {
+    constexpr int D = 512;
+    __shared__ __attribute__((aligned(16))) float sred[4][64][8];   // 8 KiB
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int bag0 = blockIdx.x * 16, j0 = blockIdx.y * 32;
+    const int bag = min(bag0 + i16, B - 1);
+    const float* pa = pooled + (size_t)bag * D + wv * 64 + 4 * g;
+    const float* pb0 = W + (size_t)(j0 + i16) * D + wv * 64 + 4 * g;
+    const float* pb1 = pb0 + (size_t)16 * D;
+    float4 a[4], b0[4], b1[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        a[it] = *reinterpret_cast<const float4*>(pa + 16 * it);
+        b0[it] = *reinterpret_cast<const float4*>(pb0 + 16 * it);
+        b1[it] = *reinterpret_cast<const float4*>(pb1 + 16 * it);
+    }
+    f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b0[it].x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].x, b1[it].x, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b0[it].y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].y, b1[it].y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b0[it].z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].z, b1[it].z, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b0[it].w, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[it].w, b1[it].w, c1, 0, 0, 0);
+    }
+    // fixed-order tree over the 8 column slices: (w, w + 4), then (w, w + 2), then (0, 1)
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float* dst = sred[wv - half][lane];
+            *reinterpret_cast<f32x4_t*>(dst) = c0;
+            *reinterpret_cast<f32x4_t*>(dst + 4) = c1;
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float* src = sred[wv][lane];
+            c0 += *reinterpret_cast<const f32x4_t*>(src);
+            c1 += *reinterpret_cast<const f32x4_t*>(src + 4);
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    const float bj0 = bias != nullptr ? bias[j0 + i16] : 0.f, bj1 = bias != nullptr ? bias[j0 + 16 + i16] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bg = bag0 + 4 * g + r;      // D fragment: lane (i16, g) holds rows 4 g + r, column i16
+        if (bg < B) {
+            v[(size_t)bg * D + j0 + i16] = c0[r] + bj0;
+            v[(size_t)bg * D + j0 + 16 + i16] = c1[r] + bj1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v, int D, const float* __restrict__ That, int K,
                                                       const float* __restrict__ logit_scale, float* __restrict__ vhat,
                                                       float* __restrict__ vnorm, float* __restrict__ logits,
@@ -354,6 +420,196 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v
         for (int k = 0; k < K; ++k) mx = fmaxf(mx, slog[k]);
         for (int k = 0; k < K; ++k) s += expf(slog[k] - mx);
         for (int k = 0; k < K; ++k) incidence[(size_t)bag * K + k] = expf(slog[k] - mx) / s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One slide per call (round 5): the tail as TWO ticket-free launches.  Until round 4 it was k_vlfan_merge (5 us) and
+// the ticketed k_head (15.5 us at 50k: W rows -> pooled -> write-through v -> drain -> ticket -> last arriver re-reads
+// v -> logits, every step a dependent cross-XCD round trip).  The adapter is linear, so
+//     v = W mean_p(out_p) + b = b + sum_p wgt_p sum_cc W[:, cols(cc)] out_p[cols(cc)]
+// and the merge workgroup (cc, p), which holds the 64 merged columns of query p anyway, can multiply them with its
+// 512 x 64 slice of W (128 KB of coalesced L2 reads, in flight WHILE the partials are being merged).
+//   k_vlfan_merge_wpart   grid (8, P) x 256: k_vlfan_merge + vpart[cc][p][j] = W[j, cols] . out_p[cols]   (D == 512)
+//   k_head_finish_parts   ONE workgroup x 512: v = b + sum_p wgt_p sum_cc vpart (fixed order), pooled, normalise, K cosine
+//                         logits, incidence.
+// mean / softmax(weight) query pooling with a Linear adapter; everything else keeps the old route.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                            const float* __restrict__ pacc, int G, int P, float* __restrict__ m2,
+                                                            float* __restrict__ l, float* __restrict__ out, int64_t sm, int64_t sl_,
+                                                            int64_t sa, const float* __restrict__ W, float* __restrict__ vpart) {
+    constexpr int D = 512;
+    __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
+    __shared__ float sl[16];
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = blockIdx.y, c0 = blockIdx.x * 64;
+    const int c4 = tid & 15, gs = tid >> 4;
+    const int col = c0 + c4 * 4;
+
+    // this thread's slice of W: rows gs * 32 .. + 31, its four columns -- 16 lanes cover 256 contiguous bytes of a row
+    float4 wr[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wr[r] = *reinterpret_cast<const float4*>(W + (size_t)(gs * 32 + r) * D + col);
+
+    constexpr int U = 16;
+    float mx = -INFINITY;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lt = 0.f;
+    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * sm + p]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int g0 = gs; g0 < G; g0 += 16 * U) {
+        float mg[U], lg[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int gI = g0 + 16 * u;
+            const bool ok = gI < G;
+            mg[u] = ok ? pm[(size_t)gI * sm + p] : -INFINITY;
+            lg[u] = ok ? pl[(size_t)gI * sl_ + p] : 0.f;
+            v[u] = ok ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * sa + (size_t)p * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float f = (mg[u] == -INFINITY) ? 0.f : fast_exp2(mg[u] - mx);
+            lt += lg[u] * f;
+            a.x += v[u].x * f; a.y += v[u].y * f; a.z += v[u].z * f; a.w += v[u].w * f;
+        }
+    }
+    sacc[gs][c4] = a;
+    if (c4 == 0) sl[gs] = lt;
+    __syncthreads();
+    if (tid < 16) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ls = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = sacc[k][tid];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            ls += sl[k];
+        }
+        const float inv = 1.f / ls;
+        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+        *reinterpret_cast<float4*>(out + (size_t)p * D + c0 + tid * 4) = s;
+        if (tid == 0 && blockIdx.x == 0) {
+            m2[p] = mx;
+            l[p] = ls;
+        }
+        sacc[0][tid] = s;   // (row 0 was read by this very thread only: no hazard)
+    }
+    __syncthreads();
+    const float4 o = sacc[0][c4];
+    // 32 dot-product pieces per lane, summed over the 16 lanes of a row group by a halving butterfly (30 shuffles instead of
+    // 128): after the four stages lane c4 holds the complete sums of rows gs * 32 + 2 c4 + {0, 1}
+    float d[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) d[r] = wr[r].x * o.x + wr[r].y * o.y + wr[r].z * o.z + wr[r].w * o.w;
+#pragma unroll
+    for (int h = 8, n = 32; h >= 1; h >>= 1, n >>= 1) {
+        const bool up = (c4 & h) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            const float keep = up ? d[i + n / 2] : d[i];
+            const float send = up ? d[i] : d[i + n / 2];
+            d[i] = keep + __shfl_xor(send, h);
+        }
+    }
+    float2 r2 = make_float2(d[0], d[1]);
+    *reinterpret_cast<float2*>(vpart + ((size_t)blockIdx.x * P + p) * D + gs * 32 + 2 * c4) = r2;
+}
+
+__global__ __launch_bounds__(512) void k_head_finish_parts(const float* __restrict__ vpart, const float* __restrict__ rows, int P,
+                                                            int ncc, int pool_mode, const float* __restrict__ pool_w,
+                                                            const float* __restrict__ bias, const float* __restrict__ That, int K,
+                                                            const float* __restrict__ logit_scale, float* __restrict__ pooled,
+                                                            float* __restrict__ v, float* __restrict__ vhat,
+                                                            float* __restrict__ vnorm, float* __restrict__ logits,
+                                                            float* __restrict__ incidence) {
+    constexpr int D = 512;
+    __shared__ float sp[D];
+    __shared__ float swg[VLSA_MAX_P];
+    __shared__ float slog[VLSA_MAX_K];
+    __shared__ float red[8];
+    __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // everything this thread needs is in flight at once: its column of the <= 16 x 8 partial vectors and of the P rows
+    float part[VLSA_MAX_P];
+#pragma unroll
+    for (int p = 0; p < VLSA_MAX_P; ++p) {
+        float s = 0.f;
+        if (p < P) {
+            float q[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) q[cc] = cc < ncc ? vpart[((size_t)cc * P + p) * D + tid] : 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) s += q[cc];
+        }
+        part[p] = s;
+    }
+    float x[VLSA_MAX_P];
+#pragma unroll
+    for (int p = 0; p < VLSA_MAX_P; ++p) x[p] = p < P ? rows[(size_t)p * D + tid] : 0.f;
+    const float bj = bias != nullptr ? bias[tid] : 0.f;
+    if (tid == 0) {
+        if (pool_mode == VLSA_POOL_WEIGHT) {   // softmax over the raw 'weight' parameter (model/deepmil.py:148)
+            float mx = -INFINITY, s = 0.f;
+            for (int p = 0; p < P; ++p) mx = fmaxf(mx, pool_w[p]);
+            for (int p = 0; p < P; ++p) { swg[p] = expf(pool_w[p] - mx); s += swg[p]; }
+            for (int p = 0; p < P; ++p) swg[p] /= s;
+        } else {
+            for (int p = 0; p < P; ++p) swg[p] = 1.f;
+        }
+    }
+    __syncthreads();
+    float vs = 0.f, ps = 0.f;
+#pragma unroll
+    for (int p = 0; p < VLSA_MAX_P; ++p)
+        if (p < P) {
+            vs += swg[p] * part[p];
+            ps += swg[p] * x[p];
+        }
+    if (pool_mode == VLSA_POOL_MEAN) {   // left-to-right sum, then / P (pooled_col's order)
+        vs /= (float)P;
+        ps /= (float)P;
+    }
+    const float vj = vs + bj;
+    pooled[tid] = ps;
+    v[tid] = vj;
+    float ss = wave_sum(vj * vj);
+    if (lane == 0) red[wv] = ss;
+    __syncthreads();
+    ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    const float nrm = fmaxf(sqrtf(ss), kNormEps);
+    const float u = vj / nrm;
+    sp[tid] = u;
+    vhat[tid] = u;
+    if (tid == 0) vnorm[0] = nrm;
+    __syncthreads();
+    const float ls = expf(logit_scale[0]);
+    for (int k = wv; k < K; k += 8) {
+        const float* tk = That + (size_t)k * D;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < D / 64; ++c) s += sp[lane + 64 * c] * tk[lane + 64 * c];
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float lg = ls * s;
+            logits[k] = lg;
+            slog[k] = lg;
+        }
+    }
+    if (incidence == nullptr) return;
+    __syncthreads();
+    if (tid == 0) {
+        float mx = -INFINITY, s = 0.f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, slog[k]);
+        for (int k = 0; k < K; ++k) s += expf(slog[k] - mx);
+        for (int k = 0; k < K; ++k) incidence[k] = expf(slog[k] - mx) / s;
     }
 }
 
@@ -449,7 +705,39 @@ extern "C" int vlsa_normalize_rows(const float* in, int rows, int D, float* out,
     return launch_status();
 }
 
-extern "C" size_t vlsa_head_workspace_bytes(int D) { (void)D; return 256; }
+// 256 bytes of ticket counter (k_head) + the [8][VLSA_MAX_P][512] partial adapter vectors of the single-slide tail
+constexpr size_t kHeadTicketBytes = 256;
+extern "C" size_t vlsa_head_workspace_bytes(int D) { (void)D; return kHeadTicketBytes + (size_t)8 * VLSA_MAX_P * 512 * sizeof(float); }
+
+// Partial merge + query pooling + adapter + cosine logits of ONE bag: the tail of vlsa_vlfan_forward_bag as an entry point of its
+// own.  D == 512 with mean / weight pooling and a Linear adapter: k_vlfan_merge_wpart + k_head_finish_parts (two ticket-free
+// launches); anything else: vlsa_vlfan_merge + vlsa_head_forward.
+extern "C" int vlsa_vlfan_merge_head(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int pool_mode,
+                                     const float* pool_w, const float* W, const float* b, const float* That, int K,
+                                     const float* logit_scale, void* head_ws, float* m2, float* l, float* out, float* pooled,
+                                     float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream) {
+    if (!pm || !pl || !pacc || !m2 || !l || !out || !That || !logit_scale || !head_ws || !pooled || !v || !vhat || !vnorm || !logits)
+        return VLSA_EINVAL;
+    if (G < 1 || P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D <= 0 || D > VLSA_MAX_D || (D % 8) != 0) return VLSA_EINVAL;
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_GIVEN) return VLSA_EINVAL;
+    if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
+    const bool fused = D == 512 && W != nullptr && (pool_mode == VLSA_POOL_MEAN || pool_mode == VLSA_POOL_WEIGHT) &&
+                       (reinterpret_cast<uintptr_t>(pacc) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    if (!fused) {
+        const int rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 1, m2, l, out, stream);
+        if (rc != VLSA_OK) return rc;
+        return vlsa_head_forward(out, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, pooled, v, vhat, vnorm, logits,
+                                 incidence, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* vpart = reinterpret_cast<float*>(static_cast<unsigned char*>(head_ws) + kHeadTicketBytes);
+    hipLaunchKernelGGL(k_vlfan_merge_wpart, dim3(8, P), dim3(256), 0, s, pm, pl, pacc, G, P, m2, l, out, (int64_t)kPStride,
+                       (int64_t)kPStride, (int64_t)P * D, W, vpart);
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    hipLaunchKernelGGL(k_head_finish_parts, dim3(1), dim3(512), 0, s, vpart, out, P, 8, pool_mode, pool_w, b, That, K, logit_scale,
+                       pooled, v, vhat, vnorm, logits, incidence);
+    return launch_status();
+}
 
 extern "C" int vlsa_head_forward(const float* rows, int P, int D, int pool_mode, const float* pool_w, const float* W,
                                  const float* b, const float* That, int K, const float* logit_scale, void* workspace,
@@ -486,8 +774,11 @@ int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float
                                   float* incidence, hipStream_t s) {
     const float* vin = pooled;
     if (W != nullptr) {
-        hipLaunchKernelGGL(k_head_linear, dim3((D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock, (B + kHeadBagsPerBlock - 1) / kHeadBagsPerBlock),
-                           dim3(256), 0, s, pooled, B, D, W, b, v);
+        if (D == 512 && B >= 16 && (reinterpret_cast<uintptr_t>(pooled) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0)
+            hipLaunchKernelGGL(k_head_linear_mfma, dim3((B + 15) / 16, 16), dim3(512), 0, s, pooled, B, W, b, v);   // f32 matrix pipe
+        else
+            hipLaunchKernelGGL(k_head_linear, dim3((D + kHeadRowsPerBlock - 1) / kHeadRowsPerBlock, (B + kHeadBagsPerBlock - 1) / kHeadBagsPerBlock),
+                               dim3(256), 0, s, pooled, B, D, W, b, v);
         vin = v;
     } else {
         if (hipMemcpyAsync(v, pooled, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return VLSA_ELAUNCH;
@@ -554,15 +845,16 @@ extern "C" int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int
     }
     rc = vlsa_vlfan_partial(X, x_dtype, N, ldx, D, qprep, P, kernel, pm, pl, pacc, scores, stream);
     if (rc != VLSA_OK) return rc;
-    rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 1, m2, l, out, stream);
-    if (rc != VLSA_OK) return rc;
-    if (scores && A) {
-        rc = vlsa_attn_normalise(scores, P, N, m2, l, A, stream);
+    if (pool_mode < 0) {   // aggregation only: the caller pools the P rows itself (attention poolings) and calls the head
+        rc = vlsa_vlfan_merge(pm, pl, pacc, G, P, D, 1, m2, l, out, stream);
+        if (rc != VLSA_OK) return rc;
+    } else {
+        rc = vlsa_vlfan_merge_head(pm, pl, pacc, G, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, m2, l, out, pooled, v,
+                                   vhat, vnorm, logits, incidence, stream);
         if (rc != VLSA_OK) return rc;
     }
-    if (pool_mode < 0) return VLSA_OK;   // aggregation only: the caller pools the P rows itself (attention poolings) and calls the head
-    return vlsa_head_forward(out, P, D, pool_mode, pool_w, W, b, That, K, logit_scale, head_ws, pooled, v, vhat, vnorm, logits,
-                             incidence, stream);
+    if (scores && A) return vlsa_attn_normalise(scores, P, N, m2, l, A, stream);
+    return VLSA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

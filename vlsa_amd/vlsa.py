@@ -104,7 +104,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
     _transient = {"_plans": dict, "_train_plans": dict, "_provider_lists": dict, "_text_cache": lambda: None,
                   "_text_cache_key": lambda: None, "_prepared_text": lambda: None, "_prepared_query": lambda: None,
                   "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None,
-                  "_pending_calls": lambda: None, "_materialising": lambda: False}
+                  "_pending_calls": lambda: None, "_materialising": lambda: False, "_side_streams": None}
 
     #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
     #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
@@ -463,21 +463,26 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         # which this module keeps alive (`_prepared_text`), the queries likewise (`_prepared_query`: the tensor `step_query` hands
         # out, whose own cache follows the query network's parameters).  A query source that is a plain callable gives no key:
         # prepare every call.
-        if not isinstance(enc.Q, (nn.Module, torch.Tensor)):
-            pkey = None                                  # an opaque callable: a fresh tensor per call, nothing to key on
-        else:
-            # `step_query` hands out the SAME tensor object as long as the query source's parameters / buffers, flags and the grad
-            # mode are unchanged (a Parameter query: the parameter itself), so identity + in-place version of that object -- kept
-            # alive here -- is the query part of the key
-            if self._prepared_text is not text_features or self._prepared_query is not Qsrc or self._prepared_qver != Qsrc._version:
-                self._prepared_text, self._prepared_query, self._prepared_qver = text_features, Qsrc, Qsrc._version
-                self._prepared_gen += 1
-            pkey = (self._prepared_gen, text_features._version)
+        pkey = self._params_key(enc, Qsrc, text_features)
         plan.run(X2, Q, text_features.detach().float().contiguous(), self.logit_scale.detach().float(),
                  None if W is None else W.detach().float().contiguous(), None if b is None else b.detach().float().contiguous(),
                  None if pw is None else pw.detach().float().reshape(-1).contiguous(), outs=outs, params_key=pkey,
                  query_pool_module=qmod)
         return outs["logits"], outs["vhat"], outs["That"]
+
+    def _params_key(self, enc, Qsrc, text_features):
+        """Key of the (queries, text features) a plan's prepared block was computed from, or None = prepare every call (a query source
+        that is a plain callable gives a fresh tensor per call: nothing to key on).  ``step_query`` hands out the SAME tensor object as
+        long as the query source's parameters / buffers, flags and the grad mode are unchanged (a Parameter query: the parameter
+        itself), so identity + in-place version of that object -- kept alive here -- is the query part of the key; the text side
+        contributes the identity of the exact tensor object the last preparation read (``_prepared_text``) + its version.  Never the
+        ADDRESS of a transient tensor: a freed block is handed out again by the caching allocator with ``_version == 0``."""
+        if not isinstance(enc.Q, (nn.Module, torch.Tensor)):
+            return None
+        if self._prepared_text is not text_features or self._prepared_query is not Qsrc or self._prepared_qver != Qsrc._version:
+            self._prepared_text, self._prepared_query, self._prepared_qver = text_features, Qsrc, Qsrc._version
+            self._prepared_gen += 1
+        return (self._prepared_gen, text_features._version)
 
     def _slide_train(self, X, text_features):
         """One bag with a gradient needed, VLFAN encoder with mean query pooling and a Linear / identity adapter (the shipped
@@ -904,7 +909,11 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             outs = [self.forward(x if x.dim() == 3 else x[None]) for x in bags]
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), outs[0][2]
         mode, pw, W, b = spec
-        Q = enc.get_query().detach().float().contiguous()
+        Qsrc = enc.step_query()
+        Q = Qsrc.detach()
+        if Q.dtype != torch.float32 or not Q.is_contiguous():
+            Q = Q.float().contiguous()
+        pkey = self._params_key(enc, Qsrc, text_features) if isinstance(Qsrc, torch.Tensor) else None
         P = Q.shape[0] - (1 if enc.gated_query else 0)
         K = text_features.shape[0]
         T = text_features.detach().float().contiguous()
@@ -921,9 +930,22 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             rows = sum(bagset.sizes if bagset is not None else [x.shape[0] for x in flat]) / len(flat)
             while step < VF.forward_max_bags() and step < len(flat) and 2 * step * rows <= 64 * 50_000:
                 step *= 2
-        for i in range(0, len(flat), step):
+        # several launches: they alternate between two side streams (a plan per parity: its own workspace and outputs), so that the
+        # merge / head launches of chunk i run under the streaming kernel of chunk i + 1 -- the tail kernels fit next to a persistent
+        # workgroup (<= 96 VGPRs, <= 8 KiB LDS) -- the way bench.py issues its launches
+        n_chunks = (len(flat) + step - 1) // step
+        side = None
+        if n_chunks > 1 and not want_attn:
+            dev0 = flat[0].device
+            side = self.__dict__.get("_side_streams")
+            if side is None or side[0].device != dev0:
+                side = self.__dict__["_side_streams"] = (torch.cuda.Stream(device=dev0), torch.cuda.Stream(device=dev0))
+            cur = torch.cuda.current_stream(dev0)
+            for st_ in side:
+                st_.wait_stream(cur)
+        for ci, i in enumerate(range(0, len(flat), step)):
             chunk = bagset.chunk(i, step) if (bagset is not None and not projected) else flat[i:i + step]
-            key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else 0)
+            key = ("batch", len(chunk), P, K, chunk[0].device, enc.gated_query, mode, W is None, want_attn, i if want_attn else (ci & 1))
             plan = self._plans.get(key)
             if plan is None:
                 plan = VF.VlfanBatchPlan(len(chunk), P, K, chunk[0].device, gated=enc.gated_query, pool=mode,
@@ -931,14 +953,22 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                                          reserved_cus=0, want_attn=want_attn)
                 self._plans[key] = plan
             used.append(plan)
-            plan.set_bags(chunk, validated=True)
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=chunk[0].device)  # noqa: E731
             outs = {"logits": f(len(chunk), K), "vhat": f(len(chunk), 512)}
             if That is None:
                 outs["That"] = That = f(K, 512)
-            plan.run(Q, T, ls, Wc, bc, pwc, outs=outs)
+            if side is not None:
+                with torch.cuda.stream(side[ci & 1]):
+                    plan.set_bags(chunk, validated=True)
+                    plan.run(Q, T, ls, Wc, bc, pwc, outs=outs, params_key=pkey)
+            else:
+                plan.set_bags(chunk, validated=True)
+                plan.run(Q, T, ls, Wc, bc, pwc, outs=outs, params_key=pkey)
             logits.append(outs["logits"])
             feats.append(outs["vhat"])
+        if side is not None:
+            for st_ in side:
+                cur.wait_stream(st_)
         res = (logits[0], feats[0], That) if len(logits) == 1 else (torch.cat(logits), torch.cat(feats), That)
         return res + (used,) if want_attn else res
 
