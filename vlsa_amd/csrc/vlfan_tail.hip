@@ -437,9 +437,14 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restrict__ pm, const float* __restrict__ pl,
                                                             const float* __restrict__ pacc, int G, int P, float* __restrict__ m2,
-                                                            float* __restrict__ l, float* __restrict__ out, int64_t sm, int64_t sl_,
-                                                            int64_t sa, const float* __restrict__ W, float* __restrict__ vpart) {
+                                                            float* __restrict__ l, float* __restrict__ out,
+                                                            const float* __restrict__ W, float* __restrict__ vpart) {
+    // contiguous partials (pm / pl [G, 16], pacc [G, P, 512]); blockIdx.z = quarter of W's rows: every quarter repeats the (cheap,
+    // L2-resident) merge of its (cc, p) piece and multiplies it with 128 rows of W -- 8 float4 of W per thread instead of 32
     constexpr int D = 512;
+    constexpr unsigned sm = kPStride, sl_ = kPStride;
+    const unsigned sa = (unsigned)P * D;
+    const int jq = blockIdx.z;
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) float4 sacc[16][16];
     __shared__ float sl[16];
@@ -449,16 +454,17 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restri
     const int c4 = tid & 15, gs = tid >> 4;
     const int col = c0 + c4 * 4;
 
-    // this thread's slice of W: rows gs * 32 .. + 31, its four columns -- 16 lanes cover 256 contiguous bytes of a row
-    float4 wr[32];
+    // this thread's slice of W: rows jq * 128 + gs * 8 .. + 7, its four columns -- 16 lanes cover 256 contiguous bytes of a row
+    float4 wr[8];
+    const float* wbase = W + (unsigned)((jq * 128 + gs * 8) * D + col);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) wr[r] = *reinterpret_cast<const float4*>(W + (size_t)(gs * 32 + r) * D + col);
+    for (int r = 0; r < 8; ++r) wr[r] = *reinterpret_cast<const float4*>(wbase + r * D);
 
     constexpr int U = 16;
     float mx = -INFINITY;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     float lt = 0.f;
-    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(size_t)gI * sm + p]);
+    for (int gI = tid; gI < G; gI += 256) mx = fmaxf(mx, pm[(unsigned)gI * sm + p]);
     mx = wave_max(mx);
     if (lane == 0) red[wv] = mx;
     __syncthreads();
@@ -467,12 +473,12 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restri
         float mg[U], lg[U];
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int gI = g0 + 16 * u;
-            const bool ok = gI < G;
-            mg[u] = ok ? pm[(size_t)gI * sm + p] : -INFINITY;
-            lg[u] = ok ? pl[(size_t)gI * sl_ + p] : 0.f;
-            v[u] = ok ? *reinterpret_cast<const float4*>(pacc + (size_t)gI * sa + (size_t)p * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) {   // out-of-range partials: the last one again, with weight 0 (no branch between the loads)
+            const unsigned gI = (unsigned)min(g0 + 16 * u, G - 1);
+            mg[u] = pm[gI * sm + p];
+            lg[u] = pl[gI * sl_ + p];
+            v[u] = *reinterpret_cast<const float4*>(pacc + gI * sa + (unsigned)(p * D + col));
+            if (g0 + 16 * u >= G) mg[u] = -INFINITY;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -495,22 +501,24 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restri
         }
         const float inv = 1.f / ls;
         s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-        *reinterpret_cast<float4*>(out + (size_t)p * D + c0 + tid * 4) = s;
-        if (tid == 0 && blockIdx.x == 0) {
-            m2[p] = mx;
-            l[p] = ls;
+        if (jq == 0) {
+            *reinterpret_cast<float4*>(out + (unsigned)(p * D + c0 + tid * 4)) = s;
+            if (tid == 0 && blockIdx.x == 0) {
+                m2[p] = mx;
+                l[p] = ls;
+            }
         }
         sacc[0][tid] = s;   // (row 0 was read by this very thread only: no hazard)
     }
     __syncthreads();
     const float4 o = sacc[0][c4];
-    // 32 dot-product pieces per lane, summed over the 16 lanes of a row group by a halving butterfly (30 shuffles instead of
-    // 128): after the four stages lane c4 holds the complete sums of rows gs * 32 + 2 c4 + {0, 1}
-    float d[32];
+    // 8 dot-product pieces per lane, summed over the 16 lanes of a row group by a halving butterfly (4 + 2 + 1 shuffles, then one
+    // more): lane c4 ends with the complete sum of row gs * 8 + (c4 >> 1) (both lanes of a pair hold it; the even one stores)
+    float d[8];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) d[r] = wr[r].x * o.x + wr[r].y * o.y + wr[r].z * o.z + wr[r].w * o.w;
+    for (int r = 0; r < 8; ++r) d[r] = wr[r].x * o.x + wr[r].y * o.y + wr[r].z * o.z + wr[r].w * o.w;
 #pragma unroll
-    for (int h = 8, n = 32; h >= 1; h >>= 1, n >>= 1) {
+    for (int h = 8, n = 8; h >= 2; h >>= 1, n >>= 1) {
         const bool up = (c4 & h) != 0;
 #pragma unroll
         for (int i = 0; i < n / 2; ++i) {
@@ -519,8 +527,8 @@ __global__ __launch_bounds__(256) void k_vlfan_merge_wpart(const float* __restri
             d[i] = keep + __shfl_xor(send, h);
         }
     }
-    float2 r2 = make_float2(d[0], d[1]);
-    *reinterpret_cast<float2*>(vpart + ((size_t)blockIdx.x * P + p) * D + gs * 32 + 2 * c4) = r2;
+    const float tot = d[0] + __shfl_xor(d[0], 1);   // row index: bit3 -> 4, bit2 -> 2, bit1 -> 1
+    if ((c4 & 1) == 0) vpart[(unsigned)((blockIdx.x * P + p) * D + jq * 128 + gs * 8 + (c4 >> 1))] = tot;
 }
 
 __global__ __launch_bounds__(512) void k_head_finish_parts(const float* __restrict__ vpart, const float* __restrict__ rows, int P,
@@ -538,22 +546,17 @@ __global__ __launch_bounds__(512) void k_head_finish_parts(const float* __restri
     __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // everything this thread needs is in flight at once: its column of the <= 16 x 8 partial vectors and of the P rows
-    float part[VLSA_MAX_P];
+    // (rows p >= P: row P - 1 again, weighted 0 below -- no branch between the loads, so all of them are in flight together)
+    float part[VLSA_MAX_P], x[VLSA_MAX_P];
 #pragma unroll
     for (int p = 0; p < VLSA_MAX_P; ++p) {
-        float s = 0.f;
-        if (p < P) {
-            float q[8];
+        const unsigned pc = (unsigned)min(p, P - 1);
+        float q[8];
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) q[cc] = cc < ncc ? vpart[((size_t)cc * P + p) * D + tid] : 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) s += q[cc];
-        }
-        part[p] = s;
+        for (int cc = 0; cc < 8; ++cc) q[cc] = vpart[((unsigned)cc * P + pc) * D + tid];
+        part[p] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        x[p] = rows[pc * D + tid];
     }
-    float x[VLSA_MAX_P];
-#pragma unroll
-    for (int p = 0; p < VLSA_MAX_P; ++p) x[p] = p < P ? rows[(size_t)p * D + tid] : 0.f;
     const float bj = bias != nullptr ? bias[tid] : 0.f;
     if (tid == 0) {
         if (pool_mode == VLSA_POOL_WEIGHT) {   // softmax over the raw 'weight' parameter (model/deepmil.py:148)
@@ -564,15 +567,15 @@ __global__ __launch_bounds__(512) void k_head_finish_parts(const float* __restri
         } else {
             for (int p = 0; p < P; ++p) swg[p] = 1.f;
         }
+        for (int p = P; p < VLSA_MAX_P; ++p) swg[p] = 0.f;
     }
     __syncthreads();
     float vs = 0.f, ps = 0.f;
 #pragma unroll
-    for (int p = 0; p < VLSA_MAX_P; ++p)
-        if (p < P) {
-            vs += swg[p] * part[p];
-            ps += swg[p] * x[p];
-        }
+    for (int p = 0; p < VLSA_MAX_P; ++p) {
+        vs += swg[p] * part[p];
+        ps += swg[p] * x[p];
+    }
     if (pool_mode == VLSA_POOL_MEAN) {   // left-to-right sum, then / P (pooled_col's order)
         vs /= (float)P;
         ps /= (float)P;
@@ -731,8 +734,7 @@ extern "C" int vlsa_vlfan_merge_head(const float* pm, const float* pl, const flo
     }
     hipStream_t s = (hipStream_t)stream;
     float* vpart = reinterpret_cast<float*>(static_cast<unsigned char*>(head_ws) + kHeadTicketBytes);
-    hipLaunchKernelGGL(k_vlfan_merge_wpart, dim3(8, P), dim3(256), 0, s, pm, pl, pacc, G, P, m2, l, out, (int64_t)kPStride,
-                       (int64_t)kPStride, (int64_t)P * D, W, vpart);
+    hipLaunchKernelGGL(k_vlfan_merge_wpart, dim3(8, P, 4), dim3(256), 0, s, pm, pl, pacc, G, P, m2, l, out, W, vpart);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     hipLaunchKernelGGL(k_head_finish_parts, dim3(1), dim3(512), 0, s, vpart, out, P, 8, pool_mode, pool_w, b, That, K, logit_scale,
                        pooled, v, vhat, vnorm, logits, incidence);

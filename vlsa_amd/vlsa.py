@@ -29,6 +29,7 @@ from .deepmil import FeatMIL, VLFAN, logit_pooling
 
 
 _GET_TRAINING, _GET_VERSION = operator.attrgetter("training"), operator.attrgetter("_version")    # C-level loops in _provider_key
+_PLAIN = frozenset((str, int, float, bool, type(None)))
 
 # Structure epoch: bumped whenever ANY nn.Module in the process registers a parameter, buffer or submodule (torch's global registration
 # hooks; `module.x = nn.Parameter(...)` goes through them).  Module / tensor lists kept for the cache keys below are valid for the epoch
@@ -106,9 +107,11 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                   "_head_tickets": lambda: VF.HeadTickets(), "_la": lambda: None, "_la_lists": lambda: None,
                   "_pending_calls": lambda: None, "_materialising": lambda: False, "_side_streams": None}
 
-    #: bags per look-ahead window (<= 64 = one persistent launch): an evaluation loop that calls ``net(X)`` once per bag of a
-    #: ``vlsa_amd.ingest.ResidentBags`` dataset is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off
+    #: bags per look-ahead window: an evaluation loop that calls ``net(X)`` once per bag of a ``vlsa_amd.ingest.ResidentBags`` dataset
+    #: is served from ONE batched launch over the next bags of the dataset; 0 / 1 = off.  Windows of slide-sized bags grow beyond this
+    #: -- up to 256 bags (one forward launch takes that many) as long as a window stays under ``lookahead_rows`` patch rows
     lookahead_bags = 64
+    lookahead_rows = 3_200_000
     #: True: a grad-enabled ``net(X)`` in training mode is recorded, not run; the first torch operation on any of its outputs runs ONE
     #: ``forward_bags`` over all recorded bags (vlsa_amd/deferred.py) -- the reference handler's bag-by-bag training loop
     #: (runner/vlsa_handler.py:260-289) at the batched step's speed.  ``patch_reference()`` switches it on; off by default.
@@ -596,8 +599,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         return logits, image_features, text_features
 
     # -- deferred training calls: the reference handler's bag-by-bag TRAINING loop at batched speed (vlsa_amd/deferred.py) -------
-    #: plain (non-tensor) attributes of the MIL encoder that change what a forward computes: part of the look-ahead / deferral state
-    _ENC_SCALARS = operator.attrgetter("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type")
+    #: plain (non-tensor) attributes of the MIL encoder that change what a forward computes (``_ENC_SCALAR_NAMES``) are part of the
+    #: look-ahead / deferral state
 
     def _encoder_lists(self):
         """(encoder, its submodules, its tensors + logit scale, structure epoch): kept between calls, re-walked when the encoder
@@ -614,12 +617,24 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             ll = self._la_lists = (enc, sub, tensors, _STRUCT_EPOCH[0])
         return ll
 
+    _ENC_SCALAR_NAMES = ("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type")
+    _ENC_SCALAR_GETTERS: dict = {}
+
     def _encoder_scalars(self, enc):
+        get = self._ENC_SCALAR_GETTERS.get(type(enc))
+        if get is None:               # which of the names this encoder CLASS'S instances carry: decided once per class (a miss on an
+            names = tuple(n for n in self._ENC_SCALAR_NAMES if n in enc.__dict__)   # nn.Module goes through __getattr__: ~1 us each)
+            get = self._ENC_SCALAR_GETTERS[type(enc)] = (names, operator.attrgetter(*names) if len(names) > 1 else
+                                                         (lambda e, _n=names: tuple(getattr(e, x) for x in _n)))
         try:
-            sc = self._ENC_SCALARS(enc)
-        except AttributeError:        # an encoder class without one of them: read what is there
-            sc = tuple(getattr(enc, n, None) for n in ("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type"))
-        return sc + (self.image_encoder_cfg.get("pooling"),)
+            sc = get[1](enc)
+        except AttributeError:        # an instance that lost an attribute its class-mates have: read what is there
+            sc = tuple(getattr(enc, n, None) for n in get[0])
+        for v in sc:
+            if v.__class__ not in _PLAIN:      # a Parameter / module in place of a plain value (query_pooling): its identity
+                sc = tuple(v if v.__class__ in _PLAIN else id(v) for v in sc)
+                break
+        return (sc, self.image_encoder_cfg.get("pooling"))
 
     def _defer_key(self):
         """Everything a training-mode output depends on besides the bag: the text side (fixed features: the buffer's version; a
@@ -709,8 +724,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         runner/vlsa_handler.py:322-330, calls the model once per bag): the first call of a window runs ``forward_bags`` over items
         i, i+1, ... (as many as are resident, <= ``lookahead_bags``: the loaders of base_handler.py:246-259 do not shuffle) -- ONE
         persistent launch instead of one latency-bound launch chain per bag -- and the following calls return their rows of that
-        result; half way through a window the next one is launched, so that the GPU does not idle while the host walks through the
-        rows.  A row is only ever handed out for the exact item it was computed from (the tag travels on the tensor object:
+        result; the first hit inside the newest window launches the window behind it, so the GPU is always one window ahead of
+        the host walking through the rows (until round 4 the next window went out at the half-way hit: the GPU idled for half a
+        window's host time per window).  Windows of slide-sized bags grow to 256 bags (``_lookahead_cap``).  A row is only ever handed out for the exact item it was computed from (the tag travels on the tensor object:
         ``ResidentBagView``) and while the model state it was computed under (``_eval_state``) still holds; any differentiable
         forward, ``_apply`` or ``load_state_dict`` drops the windows.  An access pattern that does not use its windows shrinks
         them (random access degenerates to the per-bag route)."""
@@ -731,7 +747,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             width, seq = la["width"], la["seq"]
             if la["rows"]:                            # a miss behind a window: was that window used?
                 if la["used"] >= la["computed"]:
-                    width = min(int(self.lookahead_bags), 2 * width)
+                    width = min(self._lookahead_cap(la.get("mean_rows", 0)), 2 * width)
                 elif la["used"] <= 1:
                     width = max(1, width // 4)
             seq = seq + 1 if i == la["last"] + 1 else 0
@@ -751,6 +767,13 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             return None
         la["used"] = 1
         return self._lookahead_row(la["rows"][i], X) if i in la["rows"] else None
+
+    def _lookahead_cap(self, mean_rows) -> int:
+        """bags a window may hold: ``lookahead_bags``, more for slide-sized bags (<= 256, <= ``lookahead_rows`` rows per window)"""
+        base = int(self.lookahead_bags)
+        if mean_rows <= 0 or base <= 1:
+            return base
+        return max(base, min(VF.forward_max_bags(), int(self.lookahead_rows // max(1, int(mean_rows)))))
 
     def _lookahead_window(self, la, text_features, width) -> int:
         """run ``forward_bags`` over the resident items hi+1 .. hi+width of la's dataset and add their rows; -> number of bags"""
@@ -786,11 +809,13 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             rows[lo + b] = (logits[b:b + 1], feats[b:b + 1] if per_bag else None, That, per_bag, win)
         la["hi"] = lo + len(views) - 1
         la["computed"] += len(views)
-        la["trigger"] = lo + len(views) // 2          # ... at which the window behind this one is launched
+        la["mean_rows"] = sum(v.shape[0] for v in views) / len(views)
+        la["trigger"] = lo                            # the first hit in THIS window launches the one behind it (one window ahead)
         return len(views)
 
     def _lookahead_extend(self, la, text_features):
-        """half of the newest window has been handed out in order: launch the next one now (and forget the rows behind us)"""
+        """the newest window has been reached in order: launch the next one now -- the GPU is then always one window ahead of the
+        host -- and forget the rows behind us"""
         la["trigger"] = 1 << 62
         if la["hi"] + 1 >= len(la["rb"]):
             return
@@ -802,7 +827,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         if not self._same_state(la["state"], state):
             return
         la["state"] = state
-        la["width"] = min(int(self.lookahead_bags), 2 * max(la["width"], 1))     # used in order: the next window may be wider
+        la["width"] = min(self._lookahead_cap(la.get("mean_rows", 0)), 2 * max(la["width"], 1))     # used in order: the next window may be wider
         self._lookahead_window(la, text_features, la["width"])
 
     def _lookahead_row(self, row, X):
