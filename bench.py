@@ -349,6 +349,8 @@ def main():
             torch.cuda.synchronize()
             err = float((got - want_).abs().max())
             st = pl.status()
+            if exchange == "ipc":
+                data_plane["ipc_memory"] = {2: "uncached", 1: "fine-grained", 0: "coarse-grained (kernel-boundary coherence only)"}.get(pl.peers.kind)
             if not (err < 2e-5) or st != 0:
                 ok, why = False, f"self-test: |dlogit| {err:.2e} vs the all-gather over gloo, time-out bits {st}"
             if hasattr(pl, "close"):

@@ -540,7 +540,14 @@ class ShardedVlfanBatchPlan:
         return self.logits
 
     def close(self):
+        """release the peer mappings and this rank's exchange buffer ("ipc"); COLLECTIVE when there is something to release: every
+        rank's kernels must have finished writing into the others' buffers before any of them goes away"""
         if getattr(self, "peers", None) is not None:
+            torch.cuda.synchronize()
+            try:
+                self.dist.barrier(group=self.group)
+            except Exception:  # noqa: BLE001  (a torn-down group: nothing left to wait for)
+                pass
             self.peers.close()
             self.peers = None
 
