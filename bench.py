@@ -218,8 +218,8 @@ def probe_rccl(ctrl_dist, timeout_s=120.0):
 
 
 def load_pmc():
-    names = (("r04_pmc_batch_kernel_b64.json", "r03_pmc_batch_kernel_b64.json") if BAGS_PER_LAUNCH == 64 else
-             ("r04_pmc_batch_kernel.json", "r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
+    names = (("r05_pmc_batch_kernel_b64.json", "r04_pmc_batch_kernel_b64.json", "r03_pmc_batch_kernel_b64.json") if BAGS_PER_LAUNCH == 64 else
+             ("r05_pmc_batch_kernel.json", "r04_pmc_batch_kernel.json", "r03_pmc_batch_kernel.json", "r02_pmc_batch_kernel.json", "r01_pmc_batch_kernel.json") if BAGS_PER_LAUNCH == 32 else ())
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):

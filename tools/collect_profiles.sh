@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): full GPU test suite, bench lines, rocprofv3 kernel stats of the bench command, separate PMC
-# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r04/ (copied into profiles/ afterwards).
+# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r05/ (copied into profiles/ afterwards).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04; mkdir -p $O
+O=gpurun_out/r05; mkdir -p $O
 (VLSA_GRAD_ERRORS_OUT=$O/grad_errors.txt timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench.err
@@ -98,7 +98,6 @@ python tools/bench_attn.py 50000 fp32 2>&1 | grep want_attn >> $O/bench_attn.txt
 python tools/bench_step.py > $O/bench_step.txt 2>&1
 python tools/bench_epoch.py 2>&1 | grep -v amdgpu > $O/bench_epoch.txt
 python tools/bench_train.py > $O/bench_train.txt 2>&1
-python tools/sweep_groups.py > $O/sweep_groups.txt 2>&1
 python tools/kbench_batch_f32.py 2>&1 | grep "N=" > $O/kbench_batch_f32.txt
 python tools/kbench_wide.py 2>&1 | grep "N=" > $O/kbench_wide.txt
 python tools/kbench_wide.py 50000 20000 2>&1 | grep "bfloat" > $O/kbench_wide_50k.txt
@@ -110,12 +109,12 @@ python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
 VLSA_BENCH_FORCE_SHARDED=1 python bench.py --no-cpu-baseline > $O/bench_sharded_1rank.json 2> $O/bench_sh1.err
 # the N > 1 code path started the way the driver starts it (python bench.py --gpus 2: self-launch), two ranks sharing this GPU over gloo
-VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-extra > $O/bench_2ranks_gloo_one_gpu.json 2> $O/bench_2ranks.err
+VLSA_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks.err
+VLSA_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 10 --warmup 3 > $O/bench_4ranks_one_gpu.json 2> $O/bench_4ranks.err
 # ... and with 8 ranks sharing the GPU (short clock ramp: every gloo exchange of 8 processes on one device takes ~0.1-1 s): world = 8
 # shard bounds, the 8-record fold and the gathered verification walk through; timings meaningless
-VLSA_BENCH_RAMP=1 VLSA_BENCH_WATCHDOG=300 VLSA_BENCH_BACKEND=gloo timeout 500 python bench.py --gpus 8 --steps 2 --warmup 1 --no-extra > $O/bench_8ranks_gloo_one_gpu.json 2> $O/bench_8ranks.err
+VLSA_BENCH_RAMP=1 VLSA_BENCH_WATCHDOG=300 VLSA_BENCH_BACKEND=gloo timeout 500 python bench.py --gpus 8 --steps 2 --warmup 1 > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks.err
 # round 4: persistent text-tower forward vs launch-per-stage (+ its in-kernel stamps), the whole-row score kernel vs the default
-for m in 1 0; do VLSA_TT_PERSIST=$m python tools/bench_text.py 2>&1 | grep "GPU forward" | sed "s/^/VLSA_TT_PERSIST=$m: /"; done > $O/bench_text_persist.txt
 python tools/bench_text_trainable.py 2>&1 | tail -1 > $O/bench_text_trainable.txt
 pmc tt_fetch FETCH_SIZE -- python tools/run_text.py
 pmc tt_write WRITE_SIZE -- python tools/run_text.py
@@ -123,7 +122,6 @@ mkdir -p $O/pmc_tt && cp -r $O/pmc_tt_fetch $O/pmc_tt_write $O/pmc_tt/ 2>/dev/nu
 python tools/run_text.py summarise $O/pmc_tt > $O/pmc_text_tower.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/text_train -- python tools/bench_text_trainable.py > /dev/null 2>&1
 cp $(find $O/text_train -name "*kernel_stats.csv" | head -1) $O/text_train_kernel_stats.csv 2>/dev/null
-VLSA_TT_PERSIST=1 python tools/tt_persist_stamps.py 2>&1 | grep -v amdgpu > $O/tt_persist_stamps.txt
 # ---- round 3: backward kernels of the N-sized layers, attention-weights traffic, text tower with the shared prefix
 python tools/kbench_mlp_bwd.py > $O/kbench_mlp_bwd.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mb -- python tools/run_mlp_bwd.py 50000 > /dev/null 2>&1
@@ -152,11 +150,10 @@ def collect(tags, pats):
                 out.setdefault(p, {})[k] = sum(v) / len(v)
     return out
 json.dump(collect(("mb_a", "mb_b", "mb_c", "mb_d"), ["k_mlp_backward"]), open("$O/pmc_mlp_backward_gated.json", "w"), indent=1)
-json.dump(collect(("at_f", "at_w"), ["k_vlfan_partial_dma_batch<true>", "k_attn_normalise_batch", "k_vlfan_merge_pool_batch"]),
+json.dump(collect(("at_f", "at_w"), ["k_vlfan_partial_dma_batch<true>", "k_attn_normalise_batch", "k_vlfan_merge_pool_batch", "k_vlfan_merge_pool_small"]),
           open("$O/pmc_batch_attn_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/mb $O/pmc_mb_a $O/pmc_mb_b $O/pmc_mb_c $O/pmc_mb_d $O/pmc_at_f $O/pmc_at_w
-python tools/bench_text.py --no-prefix 2>&1 | tail -2 > $O/bench_text_noprefix.txt
 # what the machine gives next to the product: read-ceiling probe (built here), the product on cache-resident rows
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/hbm_read_probe.hip -o tools/probes/libhbm_read_probe.so 2>/dev/null
 python tools/hbm_read_probe.py 2>&1 | grep -v amdgpu > $O/hbm_read_probe.txt
@@ -164,7 +161,16 @@ python tools/kbench_resident.py 2>&1 | grep -v amdgpu > $O/kbench_resident.txt
 # the score kernel: both modules' counters at 393 216 patches (steady state), the ungated module's shapes side by side
 bash tools/pmc_gated.sh 393216 > /dev/null 2>&1
 rm -rf $O/pmc_gs_gated_sq $O/pmc_gs_gated_lds $O/pmc_gs_gated_mem $O/pmc_gs_gated_wait $O/pmc_gs_ungated_sq $O/pmc_gs_ungated_lds $O/pmc_gs_ungated_mem $O/pmc_gs_ungated_wait
-(echo '# attention-score kernel: default shapes vs the 8-wave shapes of round 2 (VLSA_GS_HG2=0: ungated module, VLSA_GS_G4=0: gated module), same box, alternating processes, us per bag'; python tools/kbench_gated_ab.py - VLSA_GS_HG2=0,VLSA_GS_G4=0 2>&1 | grep 'gated=') > $O/kbench_gated_ab.txt
-for n in 40000 50000 70000 100000; do for sp in 0 1; do VLSA_GS_SPLIT=$sp python tools/gs_rows.py $n 2>/dev/null | sed "s/$/ split=$sp/"; done; done > $O/gs_split.txt
 rm -rf $O/train $O/stats $O/text $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_fetch64 $O/pmc_write64 $O/pmc_lds64 $O/pmc_gs_sq $O/pmc_gs_lds $O/pmc_gs_mem
+# ---- round 5: the launch chains behind the streaming kernels (one slide per call, 256 slide-sized bags per launch), the single-slide tail
+# alone, the machine's price of the score-line write stream, the GPU timeline of the handler's evaluation loop
+python tools/prof_tails.py 2>&1 | grep -v amdgpu > $O/bench_tails.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tails -- python tools/prof_tails.py single wide > /dev/null 2>&1
+cp $(find $O/tails -name "*kernel_stats.csv" | head -1) $O/tails_kernel_stats.csv; rm -rf $O/tails
+python tools/kbench_tail.py 2>&1 | grep -v amdgpu > $O/kbench_tail.txt
+python tools/hbm_rw_probe.py 2>&1 | grep -v amdgpu > $O/hbm_rw_probe.txt
+python tools/prof_eval_loop.py 2>&1 | grep "us per" > $O/eval_loop_timeline.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/evl -- python tools/prof_eval_loop.py > /dev/null 2>&1
+python tools/prof_eval_loop.py gaps $(find $O/evl -name "*kernel_trace.csv" | head -1) >> $O/eval_loop_timeline.txt; rm -rf $O/evl
+python tools/prof_hit.py 2798 2>&1 | grep -v amdgpu | head -24 > $O/prof_hit.txt
 cat $O/pytest_gpu.txt; cut -c1-400 $O/bench.json; cut -c1-200 $O/bench_driver_args.json; cat $O/pmc_gated_scores.json | head -30

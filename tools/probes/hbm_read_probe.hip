@@ -11,7 +11,11 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-__global__ __launch_bounds__(512, 2) void k_read_dma(const unsigned char* __restrict__ base, long long rows, int mode, int bar, int hold, int* __restrict__ sink) {
+// wout != nullptr (round 5): waves cw = 0 / 1 of every row group also STORE the production kernel's score lines -- a [12, rows] fp32
+// matrix, per 32-row tile one 128-byte line per query (48 B per 1 KiB row = 4.7 % of the read stream), whole lines per instruction --
+// so that the machine's own price of that write stream next to the read stream can be read off without any arithmetic.
+__global__ __launch_bounds__(512, 2) void k_read_dma(const unsigned char* __restrict__ base, long long rows, int mode, int bar, int hold, int* __restrict__ sink,
+                                                      float* __restrict__ wout = nullptr, int wmode = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,6 +61,16 @@ __global__ __launch_bounds__(512, 2) void k_read_dma(const unsigned char* __rest
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         acc ^= *reinterpret_cast<const int*>(ring + slot * 8192 + lane * 4);
+        if (wout != nullptr && cw < 2) {
+            const int q = 8 * cw + (lane >> 3);                       // query row of this lane (cw = 1: queries 8 .. 11 only)
+            if (q < 12) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 v = {(float)acc, 1.f, 2.f, 3.f};
+                float* dst = wout + (size_t)q * rows + (size_t)(r0 + it * 64 + rg * 32 + 4 * (lane & 7));
+                if (wmode == 1) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                else *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
         for (int h = 0; h < (hold & 15); ++h) __builtin_amdgcn_s_sleep(4);   // the slot stays busy for ~256 cycles per unit ("arithmetic")
         if (hold & 16) {      // the product's LDS read volume: the tile twice (row-major fragments + transposed fragments) = 32 x ds_read_b128
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -182,5 +196,18 @@ extern "C" int hbm_read_probe_launch(const void* base, long long bytes, int mode
     } else {
         hipLaunchKernelGGL(k_read_plain, dim3(256 * 4), dim3(512), 0, s, static_cast<const i32x4*>(base), bytes / 16, static_cast<int*>(sink));
     }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// read stream of mode (see hbm_read_probe_launch) + the score-line write stream into wout [12, bytes / 1024] fp32; wmode 1 = nontemporal stores
+extern "C" int hbm_rw_probe_launch(const void* base, long long bytes, int mode, void* sink, void* wout, int wmode, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)k_read_dma, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384 + 8 * 2048);
+        once = true;
+    }
+    hipLaunchKernelGGL(k_read_dma, dim3(256), dim3(512), 8 * 16384 + 8 * 2048, s, static_cast<const unsigned char*>(base), bytes / 1024, mode & 1,
+                       (mode >> 2) & 3, mode >> 4, static_cast<int*>(sink), static_cast<float*>(wout), wmode);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

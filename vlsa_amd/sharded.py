@@ -214,6 +214,12 @@ class PeerBuffers:
             self.close()
             raise
         self.kinds = [k for _h, k, _p in infos]
+        if min(self.kinds) == 0 and os.environ.get("VLSA_XCHG_ALLOW_COARSE") != "1":
+            # plain device memory is coherent at kernel boundaries only: a peer's stores need not be visible to a kernel that is
+            # already spinning on the flag -- refuse (the caller falls back to a collective) rather than risk stale records
+            self.close()
+            raise VlsaNativeError("peer-write exchange: the driver gave no uncached / fine-grained device memory to rank(s) "
+                                  f"{[i for i, k in enumerate(self.kinds) if k == 0]}")
 
     def inbox_floats(self, o: int) -> int:
         return self.world * self.counts[o] * self.rf
