@@ -1,6 +1,14 @@
 """Timing-only ablations of k_gated_scores, one library per bit set (vlsa_amd/_lib/variants/libvlsa_abl<bits>.so, built with
 -DVLSA_GS_ABL=<bits>; results of those libraries are WRONG by construction): 400k- and 50k-patch bf16 bags, gated and ungated.
-`python tools/gs_ablate.py` runs every variant in its own process (VLSA_HIP_LIB) on the same box."""
+`python tools/gs_ablate.py` runs every variant in its own process (VLSA_HIP_LIB) on the same box.
+
+Building the variants (in the CPU container, after `python -m vlsa_amd.build`):
+    cd vlsa_amd/csrc; mkdir -p ../_lib/variants
+    for a in 2 4 6 32 1 8; do
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DVLSA_GS_ABL=$a -c gated_scores.hip -o /tmp/gs_abl$a.o
+      hipcc --offload-arch=gfx950 -shared -fPIC $(ls ../_lib/obj/*.o | grep -v gated_scores) /tmp/gs_abl$a.o -o ../_lib/variants/libvlsa_abl$a.so
+    done
+(the variant libraries are not kept in the tree: 2.3 MB each)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "child":

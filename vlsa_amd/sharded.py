@@ -194,32 +194,49 @@ class PeerBuffers:
             raise VlsaNativeError(f"peer-write exchange: at most {lib.vlsa_xchg_max_peers()} ranks")
         self.lib, self.rank, self.world, self.counts, self.rf, self.F = lib, rank, world, list(counts), rf, F
         self.bytes = self.layout_bytes(rank)
+        self.own, self.kind, self.base, self._opened = 0, -1, [0] * world, []
+        # Every rank walks the SAME sequence of control-plane collectives whatever fails locally (a rank that raised on its own would
+        # leave the others inside a collective it never joins): export, gather (handle or the error), map, gather the verdicts, and
+        # only then raise -- on every rank together.
         ptr, kind = ctypes.c_void_p(), ctypes.c_int(-1)
         handle = ctypes.create_string_buffer(64)
-        nat.check(lib.vlsa_xchg_alloc(self.bytes, ctypes.byref(ptr), handle, ctypes.byref(kind)), "vlsa_xchg_alloc")
-        self.own, self.kind = int(ptr.value), int(kind.value)
+        rc = lib.vlsa_xchg_alloc(self.bytes, ctypes.byref(ptr), handle, ctypes.byref(kind))
+        if rc == 0:
+            self.own, self.kind = int(ptr.value), int(kind.value)
+            mine = (bytes(handle.raw), self.kind, os.getpid())
+        else:
+            mine = (None, -1, f"vlsa_xchg_alloc: {lib.vlsa_error_string(rc).decode()} ({rc})")
         infos = [None] * world
-        dist_module.all_gather_object(infos, (bytes(handle.raw), self.kind, os.getpid()), group=group)
-        self.base, self._opened = [0] * world, []
-        try:
+        dist_module.all_gather_object(infos, mine, group=group)
+        err = None
+        bad = [f"rank {o}: {p_}" for o, (h, _k, p_) in enumerate(infos) if h is None]
+        if bad:
+            err = "peer-write exchange: no exportable device buffer on " + "; ".join(bad)
+        else:
+            self.kinds = [k for _h, k, _p in infos]
+            if min(self.kinds) == 0 and os.environ.get("VLSA_XCHG_ALLOW_COARSE") != "1":
+                # plain device memory is coherent at kernel boundaries only: a peer's stores need not be visible to a kernel that is
+                # already spinning on the flag -- refuse (the caller falls back to a collective) rather than risk stale records
+                err = ("peer-write exchange: the driver gave no uncached / fine-grained device memory to rank(s) "
+                       f"{[i for i, k in enumerate(self.kinds) if k == 0]}")
+        if err is None:
             for o, (h, _k, _pid) in enumerate(infos):
                 if o == rank:
                     self.base[o] = self.own
                     continue
                 q = ctypes.c_void_p()
-                nat.check(lib.vlsa_xchg_open(ctypes.create_string_buffer(h, 64), ctypes.byref(q)), f"vlsa_xchg_open(rank {o})")
+                rc = lib.vlsa_xchg_open(ctypes.create_string_buffer(h, 64), ctypes.byref(q))
+                if rc != 0:
+                    err = f"vlsa_xchg_open(rank {o}'s buffer) on rank {rank}: {lib.vlsa_error_string(rc).decode()} ({rc})"
+                    break
                 self.base[o] = int(q.value)
                 self._opened.append(int(q.value))
-        except Exception:
+        verdicts = [None] * world
+        dist_module.all_gather_object(verdicts, err, group=group)
+        errs = [e for e in verdicts if e]
+        if errs:
             self.close()
-            raise
-        self.kinds = [k for _h, k, _p in infos]
-        if min(self.kinds) == 0 and os.environ.get("VLSA_XCHG_ALLOW_COARSE") != "1":
-            # plain device memory is coherent at kernel boundaries only: a peer's stores need not be visible to a kernel that is
-            # already spinning on the flag -- refuse (the caller falls back to a collective) rather than risk stale records
-            self.close()
-            raise VlsaNativeError("peer-write exchange: the driver gave no uncached / fine-grained device memory to rank(s) "
-                                  f"{[i for i, k in enumerate(self.kinds) if k == 0]}")
+            raise VlsaNativeError(errs[0] if len(set(errs)) == 1 else "; ".join(sorted(set(errs))))
 
     def inbox_floats(self, o: int) -> int:
         return self.world * self.counts[o] * self.rf
