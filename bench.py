@@ -176,6 +176,25 @@ def rccl_probe_main():
     g = torch.empty(w * 512, device=dev)
     dist.all_gather_into_tensor(g, x[:512].contiguous())
     torch.cuda.synchronize()
+    # ... and the data plane itself, pipelined, as the timed launches use it: the owner exchange and the all-gather exchange over RCCL
+    # against the all-gather over a gloo group, three launches of 2 w + 1 small bags each
+    from vlsa_amd.sharded import ShardedVlfanBatchPlan
+    ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+    Bt, Kt = 2 * w + 1, 4
+    Q, T, W, b, ls = synth_params(dev, Kt)
+    bags = synth_bags(dev, 4000 + r, Bt, 700 + 64 * r)
+    ref = ShardedVlfanBatchPlan(Bt, P, Kt, dev, dist, group=ctrl, exchange="allgather", pipeline=False)
+    ref.set_bags(bags)
+    want = ref.run(Q, T, ls, W, b).clone()
+    for ex in ("owner", "allgather"):
+        pl = ShardedVlfanBatchPlan(Bt, P, Kt, dev, dist, group=None, exchange=ex, pipeline=True)
+        pl.set_bags(bags)
+        for _ in range(3):
+            pl.run(Q, T, ls, W, b)
+        got = pl.finish()
+        torch.cuda.synchronize()
+        err = float((got - want).abs().max())
+        assert err < 2e-5, (ex, err)
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_PROBE_OK", flush=True)
