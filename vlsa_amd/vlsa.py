@@ -634,19 +634,12 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         return ll
 
     _ENC_SCALAR_NAMES = ("keep_ratio", "pooling", "query_pooling", "gated_query", "pred_head", "query_type")
-    _ENC_SCALAR_GETTERS: dict = {}
 
     def _encoder_scalars(self, enc):
-        get = self._ENC_SCALAR_GETTERS.get(type(enc))
-        if get is None:               # which of the names this encoder CLASS'S instances carry: decided once per class (a miss on an
-            names = tuple(n for n in self._ENC_SCALAR_NAMES if n in enc.__dict__)   # nn.Module goes through __getattr__: ~1 us each)
-            get = self._ENC_SCALAR_GETTERS[type(enc)] = (names, operator.attrgetter(*names) if len(names) > 1 else
-                                                         (lambda e, _n=names: tuple(getattr(e, x) for x in _n)))
-        try:
-            sc = get[1](enc)
-        except AttributeError:        # an instance that lost an attribute its class-mates have: read what is there
-            sc = tuple(getattr(enc, n, None) for n in get[0])
-        return (sc, self.image_encoder_cfg.get("pooling"))
+        """the plain attributes of ``_ENC_SCALAR_NAMES`` as this INSTANCE carries them (read from its ``__dict__``: a name held as a
+        Parameter / submodule -- ``query_pooling`` -- is not there; it is in the tensor / module lists, compared by identity)"""
+        d = enc.__dict__
+        return (tuple([d.get(n) for n in self._ENC_SCALAR_NAMES]), self.image_encoder_cfg.get("pooling"))
 
     def _defer_key(self):
         """Everything a training-mode output depends on besides the bag: the text side (fixed features: the buffer's version; a
