@@ -36,6 +36,7 @@
 #include <cstdlib>
 
 #include "vlsa_common.h"
+#include "gated_scores.h"
 
 // Timing-only ablations of k_gated_scores (results are WRONG with any bit set; tools/attic/gs_ablate.sh builds one library per bit):
 // 1 = no A-fragment reads from LDS, 2 = no weight loads, 4 = no X loads / publication, 8 = no per-step barrier,
@@ -55,10 +56,6 @@ typedef int i32x4g __attribute__((ext_vector_type(4)));
 
 namespace gs {
 constexpr int kRows = 256;                        // patch rows per workgroup tile
-constexpr int kHid = 256;
-constexpr int kD = 512;
-constexpr int kSteps = 16;                        // K steps of 32
-constexpr int kHalves = 2;                        // a workgroup covers kHid / kHalves hidden units (of both branches)
 constexpr int kXBuf = kRows * 64;                 // one K step of the tile: 256 rows x 32 bf16 = 16 KiB
 constexpr int kXOff = 0;
 constexpr int kScrOff = kXOff + 2 * kXBuf;        // 32 KiB
@@ -67,18 +64,6 @@ constexpr int kLds = kScrOff + 8 * kRows * 4;     // + 8 KiB
 constexpr int kScrOff32 = kXOff + 4 * kXBuf;      // 64 KiB
 constexpr int kLds32 = kScrOff32 + 8 * kRows * 4;
 }  // namespace gs
-
-struct GatedPrepLayout {
-    size_t wpack, ba, bg, w2, c, total;
-    __host__ __device__ explicit GatedPrepLayout(int gated) {
-        wpack = 0;
-        ba = wpack + (size_t)gs::kHalves * 8 * gs::kSteps * (gated ? 4 : 2) * 1024;
-        bg = ba + gs::kHid * 4;
-        w2 = bg + gs::kHid * 4;
-        c = w2 + gs::kHid * 4;
-        total = c + 16;
-    }
-};
 
 // packed[(((half * 8 + w) * 16 + ks) * NF + f) * 1024 + lane * 16 + 2 e] =
 //     term(f & 1) of W_br[128 half + 16 w + (lane & 15)][32 ks + 8 (lane >> 4) + e],   f = br * 2 + term,  NF = 4 (gated) / 2.
@@ -117,19 +102,6 @@ __global__ __launch_bounds__(64) void k_prepare_gated_weights(const float* __res
     }
 }
 
-// tanh(x) * sigmoid(y) = (1 - u) / ((1 + u)(1 + v)),  u = e^{-2x}, v = e^{-y}: two v_exp_f32 and ONE v_rcp_f32 (1 ulp) per
-// value.  The activations are a real cost here (N x 512 of them per bag at quarter rate; an IEEE division would add ~10
-// VALU instructions each).  The arguments au = -2 log2(e) x and av = -log2(e) y come straight out of the accumulators (weights
-// and biases are pre-scaled); they are clamped from above only: 2^43 * 2^57 keeps (1 + u)(1 + v) finite, where the result
-// is saturated in fp32 anyway, and exp2 of a very negative argument is simply 0.
-__device__ __forceinline__ float gate_act(float au, float av) {
-    const float u = fast_exp2(fminf(au, 43.f)), v = fast_exp2(fminf(av, 57.f));
-    return (1.f - u) * __builtin_amdgcn_rcpf((1.f + u) * (1.f + v));
-}
-__device__ __forceinline__ float tanh_act(float au) {
-    const float u = fast_exp2(fminf(au, 43.f));
-    return (1.f - u) * __builtin_amdgcn_rcpf(1.f + u);
-}
 __device__ __forceinline__ f32x4 gs_mfma(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {
 #if VLSA_GS_ABL & 32
     asm volatile("" ::"v"(a), "v"(b));     // operands still have to arrive in registers
@@ -138,15 +110,6 @@ __device__ __forceinline__ f32x4 gs_mfma(bf16x8 a, bf16x8 b, f32x4 c, int, int, 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
-// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane: four full-rate VALU adds
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
-    return v;
-}
-
 // XF32: fp32 bags (the reference's own feature format, dataset/PatchWSI.py:205-215).  The thread splits its 16 fp32 values of a
 // step into bf16 hi + lo on the fly and publishes both images; per accumulator the step then issues X_hi W_hi + X_hi W_lo +
 // X_lo W_hi (the lo x lo term is 2^-16 relative and dropped): 1.5x the MFMA work of a bf16 bag, no [N, 256] activations in
@@ -156,22 +119,6 @@ __device__ __forceinline__ float row16_sum(float v) {
 // waves (HG = 2, RT = 8: the four-wave shape of the ungated module).
 // Several bags per launch (the DeepMIL encoder over a batch of slides, runner/vlsa_handler.py:315-345): bags != null, row tile
 // t of the launch belongs to the bag b with tile_start[b] <= t < tile_start[b + 1]; its scores go to a_out + a_off[b].
-struct GsBag {
-    const void* X;
-    long long N, ldx;
-};
-struct GsBatch {
-    const GsBag* bags;
-    const int* tile_start;      // [B + 1], tile_start[0] = 0
-    const long long* a_off;     // [B] offset (floats) of bag b's scores in a_out
-    int B;                      // <= 64
-    // training-mode dropout of Gated_Attention_Pooling (nn.Dropout behind tanh and behind sigmoid, model/layers.py:94,99):
-    // drop_thr = p * 2^32 (0: off), drop_scale = 1 / (1 - p); see dropout_bits()
-    unsigned int drop_thr, drop_seed;
-    float drop_scale;
-    unsigned int row_base;      // first row of this launch inside the bag's score array (a bag may be covered by two launches)
-};
-
 template <bool GATED, bool FULL, bool XF32, int RT = 16, int HG = 1, int NW = 8 / HG>
 __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restrict__ Xv, long long N, long long ldx,
                                                        const unsigned char* __restrict__ prep, float* __restrict__ a_out,
@@ -661,7 +608,17 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
     const int NF = gated ? 4 : 2;
     hipLaunchKernelGGL(k_prepare_gated_weights, dim3(gs::kHalves * 8 * gs::kSteps * NF), dim3(64), 0, (hipStream_t)stream, Wa, ba, Wg, bg, w2, c,
                        gated ? 1 : 0, static_cast<unsigned char*>(prep));
-    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    return gs_tile_prepare(Wa, Wg, gated, static_cast<unsigned char*>(prep), (hipStream_t)stream);
+}
+
+// bf16 bags of at least this many rows take k_scores_tile (gated_scores_tile.hip); VLSA_GS_TILE = <rows> moves the threshold
+// (0: never)
+static long long gs_tile_min_rows(bool gated) {
+    static const long long env = [] { const char* e = getenv("VLSA_GS_TILE"); return e ? atoll(e) : -1ll; }();
+    if (env == 0) return (1ll << 62);
+    if (env > 0) return env;
+    return gated ? 16384 : 16384;
 }
 
 static bool gs_round64() {
@@ -750,7 +707,6 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     const GsTiling tl = gs_tiling(f32, gated != 0, N);
     const int max_rows = tl.max_rows, round_tiles = tl.round_tiles;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const unsigned char* pp = static_cast<const unsigned char*>(prep);
     GsBatch dropb{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f, 0u};
     if (gated && drop_p > 0.f) {
@@ -775,6 +731,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
                 (void)hipFuncSetAttribute((const void*)k_gated_scores_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gr::kLds);
                 (void)hipFuncSetAttribute((const void*)k_gated_scores_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gr::kLds);
             }
+            if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
             const int n_row_tiles = (int)(((N + gr::kR - 1) / gr::kR + 7) / 8 * 8);      // whole groups of 8 row tiles x 2 halves
             const int nv = 2 * n_row_tiles;
             const unsigned int grid = (unsigned int)(nv < 256 ? nv : 256);
@@ -783,6 +740,13 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
             return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
         }
     }
+    // round 5: large bf16 bags take the LDS-DMA tile kernel (gated_scores_tile.hip)
+    if (!f32 && N >= gs_tile_min_rows(gated != 0) && 256ll * ldx * 2 < (1ll << 31)) {
+        // the ungated module's tiles are whole (one workgroup per row tile stores its scores): nothing to zero
+        if (gated && hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
+        return gs_tile_launch(X, (long long)N, (long long)ldx, pp, gated, a, 0, 0, dropb, st);
+    }
+    if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const int64_t round_rows = round_tiles * (int64_t)max_rows;
     static const bool split = [] { const char* e = getenv("VLSA_GS_SPLIT"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     int64_t seg_rows[2] = {N, 0};
