@@ -355,8 +355,13 @@ int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const 
  * vlsa_gated_scores_tiling: the tile geometry of the score kernel for a (bag dtype, module) pair -- max_rows = rows of its largest
  *   tile, round_tiles = row tiles that fill the 256 CUs once; a batch smaller than one round is best served by the smallest
  *   rows_per_tile that still fits round_tiles.
+ * vlsa_gated_scores_big_tile: large bf16 batches of the gated module are better served by the persistent LDS-DMA kernel (both
+ *   operands staged through LDS, 256-row x 256-column tiles): *rows = its tile height (0: not for this dtype / module) and
+ *   *min_total_rows = the batch size in rows from which to use it; a caller that does builds tile_start for rows_per_tile = *rows
+ *   (any multiple of 32 above max_rows and up to 256 selects that kernel in vlsa_gated_scores_batch).
  */
 int vlsa_gated_scores_tiling(int x_dtype, int gated, int* max_rows, int* round_tiles);
+int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_total_rows);
 int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
                             int n_tiles, int rows_per_tile, float* a, const int64_t* a_off, int64_t a_floats, void* stream);
 int vlsa_scored_pool_partial_batch(const void* bag_desc, int B, int x_dtype, int D, const float* scores, const int64_t* a_off,

@@ -164,12 +164,13 @@ def _dropout_keep(seed, rows, units, p):
     return h >= thr
 
 
+@pytest.mark.parametrize("N", [3000, 17001])       # (17 001 bf16 rows: the persistent LDS-DMA score kernel, gated_scores_tile.hip)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_gated_scores_training_dropout_forward_and_backward(dtype):
+def test_gated_scores_training_dropout_forward_and_backward(dtype, N):
     """Gated_Attention_Pooling in train mode (nn.Dropout behind tanh and sigmoid, model/layers.py:94,99): the fused kernels with
     their own counter-based masks against torch autograd through the same arithmetic with the SAME masks."""
     from vlsa_amd import functional as VF
-    N, p, seed = 3000, 0.25, 123457
+    p, seed = 0.25, 123457
     X = cases.make_bag(N, 8100, "clustered", dtype=dtype)
     pp = {k: v.clone().requires_grad_(True) for k, v in cases.make_pool_params("gated_attention", 8101).items()}
     G = torch.randn(N, generator=cases.gen(8102))

@@ -5,9 +5,7 @@
 import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBD = os.path.join(ROOT, "vlsa_amd", "_lib")
-NAMES = {0: "the product", 2: "no weight DMA after step 1", 4: "no X DMA after step 1", 6: "neither", 32: "no MFMAs (operands still arrive)",
-         8: "no per-step barrier", 16: "no activations", 38: "no DMA, no MFMAs", 64: "X rows of tile 0 for everybody (L2 hits)", 128: "no s_setprio",
-         22: "no DMA, no activations"}
+NAMES = {0: "the product", 16: "no activations", 32: "no MFMAs (operands still arrive)", 48: "neither"}
 if os.environ.get("GT_ONLY"):
     NAMES = {int(b): NAMES.get(int(b), "?") for b in os.environ["GT_ONLY"].split(",")}
 EXTRA = os.environ.get("GT_EXTRA", "").split()

@@ -617,8 +617,10 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
 static long long gs_tile_min_rows(bool gated) {
     static const long long env = [] { const char* e = getenv("VLSA_GS_TILE"); return e ? atoll(e) : -1ll; }();
     if (env == 0) return (1ll << 62);
-    if (env > 0) return env;
-    return gated ? 16384 : 16384;
+    if (env > 0) return env;       // (both modules)
+    // gated: 393 216 patches 336 vs 376 us, 50 000: 50-52 vs 53-55, 20 000: 26.3 vs 28.9 (same box each); ungated: within +-2 % of the
+    // four-wave fragment-order kernel at every size (184 vs 186 us at 393 216): it keeps that kernel unless VLSA_GS_TILE asks
+    return gated ? 16384 : (1ll << 62);
 }
 
 static bool gs_round64() {
@@ -669,6 +671,16 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
     if (f32 && !gated && f4) return {128, 256, true, 2};
     if (f32 && gated && f4) return {64, 64, true, 2};
     return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
+}
+
+// Rows per tile of the persistent LDS-DMA kernel (gated_scores_tile.hip) and the total number of rows from which a batched launch
+// should use it -- 0 / 0 where it does not apply (fp32 bags, the ungated module: measured no faster there).
+extern "C" int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_total_rows) {
+    if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !rows || !min_total_rows) return VLSA_EINVAL;
+    const bool on = x_dtype == VLSA_DT_BF16 && gs_tile_min_rows(gated != 0) < (1ll << 61);
+    *rows = on ? 256 : 0;
+    *min_total_rows = on ? gs_tile_min_rows(gated != 0) : 0;
+    return VLSA_OK;
 }
 
 // vlsa_gated_scores_batch's caller sizes its tile table with this: rows of the largest tile and row tiles per round.
@@ -834,6 +846,13 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     const bool f32 = x_dtype == VLSA_DT_F32;
     const GsTiling tl = gs_tiling(f32, gated != 0, 0);
     const int max_rows = tl.max_rows;
+    if (!f32 && rows_per_tile > max_rows && rows_per_tile <= 256 && (rows_per_tile % 32) == 0) {
+        // tiles higher than the fragment-order kernel's: the persistent LDS-DMA kernel (vlsa_gated_scores_big_tile)
+        hipStream_t st = (hipStream_t)stream;
+        if (gated && hipMemsetAsync(a, 0, (size_t)a_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
+        const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
+        return gs_tile_launch(nullptr, 0ll, 0ll, static_cast<const unsigned char*>(prep), gated, a, n_tiles, rows_per_tile, bt, st);
+    }
     if (rows_per_tile < 16 || rows_per_tile > max_rows || (rows_per_tile % 16)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
     if (attr_once.first()) {

@@ -1029,6 +1029,22 @@ def _score_tiling(f32: bool, gated: bool):
     return t
 
 
+_SCORE_BIG_TILE = {}
+
+
+def _score_big_tile(f32: bool, gated: bool):
+    """(tile height of the persistent LDS-DMA score kernel, rows in a batch from which to use it) -- vlsa_gated_scores_big_tile;
+    (0, 0): not for this dtype / module."""
+    key = (f32, gated)
+    t = _SCORE_BIG_TILE.get(key)
+    if t is None:
+        rows, mn = ctypes.c_int(0), ctypes.c_int64(0)
+        nat.check(nat.load().vlsa_gated_scores_big_tile(nat.DT_F32 if f32 else nat.DT_BF16, int(gated), ctypes.addressof(rows),
+                                                       ctypes.addressof(mn)), "vlsa_gated_scores_big_tile")
+        t = _SCORE_BIG_TILE[key] = (rows.value, mn.value)
+    return t
+
+
 class FusedAttnScores:
     """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 or fp32 bag in ONE MFMA kernel
     (vlsa_gated_scores; model/layers.py:85-153): the [N, 256] hidden activations never reach memory.  Holds the weights
@@ -1083,7 +1099,10 @@ class FusedAttnScores:
         f32 = bags[0].dtype == torch.float32
         max_rows, round_tiles = _score_tiling(f32, bool(gated))
         rpt = max_rows
-        if sum((n + max_rows - 1) // max_rows for n in rows) < round_tiles:      # less than one round of the 256 CUs: smaller tiles
+        big_rows, big_min = _score_big_tile(f32, bool(gated))
+        if big_rows and sum(rows) >= big_min:                                    # a large batch: the persistent LDS-DMA kernel's tiles
+            rpt = big_rows
+        elif sum((n + max_rows - 1) // max_rows for n in rows) < round_tiles:    # less than one round of the 256 CUs: smaller tiles
             rpt = 16
             while rpt < max_rows and sum((n + rpt - 1) // rpt for n in rows) > round_tiles:
                 rpt += 16
