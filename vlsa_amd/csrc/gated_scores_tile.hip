@@ -123,8 +123,8 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() {
 //   * the DMA ring runs across tile boundaries: the last three half-steps of a tile stage steps 1, 2, 0 of the NEXT tile (the
 //     buffers those half-steps release; 16 steps over a ring of three leave every tile starting in buffer 0), so the next tile's
 //     operands arrive under the activations of this one;
-//   * tiles are h = 32 nrt <= 256 rows, one height per launch, chosen by the host so that the tiles spread evenly over the
-//     workgroups (a 50 000-patch bag: 2 x 224 tiles of 224 rows on 256 workgroups instead of 1.53 rounds of 256-row tiles paid as 2):
+//   * tiles are h = 32 nrt <= 256 rows, chosen by the host so that the rows spread evenly over the workgroups (a 50 000-patch
+//     bag: per column half 128 tiles of 224 rows, then 112 of 192, instead of 1.53 rounds of 256-row tiles paid as 2):
 //     row half wm owns tile rows [16 nrt wm, 16 nrt (wm + 1)) at LDS rows 128 wm + ...; row tiles >= nrt are skipped under
 //     wave-uniform branches, their DMA instructions are still issued -- with an offset behind the
 //     descriptor's range, which reads zeros without a memory request -- so that every wave counts the same vmcnt;
@@ -132,7 +132,7 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() {
 template <bool GATED>
 __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict__ Xv0, long long N0, long long ldx0,
                                                           const unsigned char* __restrict__ prep, float* __restrict__ a_out0,
-                                                          int n_tiles, int nrt_arg, const GsBatch bt) {
+                                                          int n_tiles, int nrt_arg, int tall_rounds, const GsBatch bt) {
     using namespace gt;
     constexpr int NW = 8, NDMA = VLSA_GT_ISSUE4 ? 12 : 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -142,15 +142,16 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     const int g = lane >> 4, i16 = lane & 15;
     const GatedPrepLayout L(GATED ? 1 : 0);
     // 16-row tiles per row half: tile height 32 nrt.  (A static nrt = 8 instantiation spilled 33-40 registers where this one fits: the
-    // uniform branches around the row tiles keep the scheduler from hoisting across them.)
-    const int nrt = nrt_arg;
-    const int rows_pt = 32 * nrt;
+    // uniform branches around the row tiles keep the scheduler from hoisting across them.)  One bag: the tiles of the first
+    // `tall_rounds` rounds (a round = one tile per walker) are 32 (nrt_arg + 1) rows high, the others 32 nrt_arg: the walkers' row
+    // counts differ by at most one 32-row unit (a 50 000-patch bag: 128 tiles of 224 rows, then 112 of 192 -- 13 units per walker, not
+    // 2 x 7).  A batch (tile table): every tile 32 nrt_arg rows.
     // gated: the column halves of a row tile on blocks b and b + 8 (same XCD under the round-robin dispatch; gridDim.x is a
     // multiple of 16): workgroup (hv, k) walks row tiles k, k + G / 2, ...
     const int bid = blockIdx.x;
     const int hv = GATED ? (bid >> 3) & 1 : 0;
     const int first = GATED ? ((bid >> 4) << 3) + (bid & 7) : bid;
-    const int stride = GATED ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int stride = GATED ? (int)(gridDim.x >> 1) : (int)gridDim.x;     // walkers
 
     i32x4t wrs;
     const unsigned long long waddr = reinterpret_cast<unsigned long long>(prep + L.wtile) + (unsigned long long)hv * gs::kSteps * kB;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     const unsigned int lds0 = (unsigned int)(uintptr_t)(lds_void_ptr_t)smem;
 
     // a tile's X source, all of it wave-uniform (SGPRs): the descriptor over its rows, the row pitch, where its scores go
-    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows; };
+    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, nrt; };
     const int xr = lane >> 2;
     const int xchunk = ((lane & 3) ^ ((0 - (xr >> 2)) & 3)) << 4;
     constexpr bool ISSUE4 = VLSA_GT_ISSUE4 != 0;
@@ -189,14 +190,24 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
             tile -= bt.tile_start[b];
         }
         Src r;
-        r.row0 = (long long)tile * rows_pt;
+        if (bt.bags != nullptr || tall_rounds == 0) {
+            r.nrt = nrt_arg;
+            r.row0 = (long long)tile * (32 * nrt_arg);
+        } else {            // round = tile / walkers (one bag: every walker is present in every full round)
+            const int rnd = __builtin_amdgcn_readfirstlane(tile / stride), tall = rnd < tall_rounds ? rnd : tall_rounds;
+            r.nrt = nrt_arg + (rnd < tall_rounds ? 1 : 0);
+            r.row0 = 32ll * stride * ((long long)rnd * nrt_arg + tall) + 32ll * (tile - rnd * stride) * r.nrt;
+        }
+        const int rows_pt = 32 * r.nrt;
         r.nrows = (int)((N - r.row0) < rows_pt ? (N - r.row0) : rows_pt);
+        if (r.nrows < 0) r.nrows = 0;
         r.a = a;
         r.ldb = __builtin_amdgcn_readfirstlane((int)(ldx * 2));
         const unsigned long long xaddr = reinterpret_cast<unsigned long long>(Xv) + (unsigned long long)r.row0 * ldx * 2ull;
         r.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)xaddr);
         r.rs[1] = __builtin_amdgcn_readfirstlane((int)((xaddr >> 32) & 0xffffu));
-        r.rs[2] = __builtin_amdgcn_readfirstlane((int)(((long long)(r.nrows - 1) * ldx + gs::kD) * 2));
+        r.rs[2] = __builtin_amdgcn_readfirstlane(r.nrows > 0 ? (int)(((long long)(r.nrows - 1) * ldx + gs::kD) * 2) : 0);
+        r.nrt = __builtin_amdgcn_readfirstlane(r.nrt);
         r.rs[3] = 0x00020000;
         return r;
     };
@@ -207,9 +218,9 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         const unsigned int sa = lds0 + buf * kStage, sb = sa + kA;
         if (j < NJA) {
             const int b = wi + JW * j, hb = b & 7;                   // (uniform)
-            const int tb = b < 8 ? b : nrt + hb;
+            const int tb = b < 8 ? b : sc.nrt + hb;
             i32x4t d = sc.rs;
-            d[2] = hb < nrt ? sc.rs[2] : 0;
+            d[2] = __builtin_amdgcn_readfirstlane(hb < sc.nrt ? sc.rs[2] : 0);
             VLSA_GT_DMA(sa + b * 1024, (16 * tb + xr) * sc.ldb + xchunk, d, ks * 64);
         } else {
             VLSA_GT_DMA(sb + (wi + JW * (j - NJA)) * 1024, wi * 1024 + lane * 16, wrs, ks * kB + (j - NJA) * JW * 1024);
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
 #pragma unroll 1
     for (; t < n_tiles; t += stride) {
         const bool has_next = t + stride < n_tiles;     // uniform
+        const int nrt = cur.nrt;
         Src nxt = cur;
         if (has_next) nxt = src_of(t + stride);
         // steps 0, 1, 2 of this tile have been issued (by the prologue or by the previous tile's last half-steps, step 0 last)
@@ -406,17 +418,19 @@ int gs_tile_prepare(const float* Wa, const float* Wg, int gated, unsigned char* 
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
-// Tile height of a single-bag launch of the persistent kernel: 32 k rows, k <= 8, such that the most loaded workgroup has the
-// fewest rows (+ ~24 rows' worth of epilogue per tile): wg row-tile walkers (128 per column half for the gated module, 256 else).
-static int gs_tile_pick_rows(long long N, int walkers) {
-    long long best = -1;
-    int pick = 256;
-    for (int k = 8; k >= 1; --k) {
-        const long long rpt = 32 * k, tiles = (N + rpt - 1) / rpt, per = (tiles + walkers - 1) / walkers;
-        const long long cost = per * (rpt + 24);
-        if (best < 0 || cost < best) { best = cost; pick = (int)rpt; }
-    }
-    return pick;
+// Tiling of a single-bag launch: U = ceil(N / (32 walkers)) 32-row units per walker in R = ceil(U / 8) rounds (a round = one tile per
+// walker, at most 256 rows): the first U % R rounds one unit taller than the others.
+struct GtPlan { int n_tiles, nrt, tall_rounds; };
+static GtPlan gs_tile_plan(long long N, int walkers) {
+    const long long U = (N + 32ll * walkers - 1) / (32ll * walkers), R = (U + 7) / 8;
+    const long long base = U / R, rem = U % R;
+    GtPlan p;
+    p.nrt = (int)base;
+    p.tall_rounds = (int)rem;
+    const long long tall_rows = rem * walkers * 32 * (base + 1);
+    if (N <= tall_rows) p.n_tiles = (int)((N + 32 * (base + 1) - 1) / (32 * (base + 1)));
+    else p.n_tiles = (int)(rem * walkers + (N - tall_rows + 32 * base - 1) / (32 * base));
+    return p;
 }
 
 // One bag (bt.bags == nullptr: rows_per_tile is chosen here) or the tile table of a batched launch (rows_per_tile: a multiple of 32,
@@ -429,16 +443,20 @@ int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned cha
         (void)hipFuncSetAttribute((const void*)k_scores_tile_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
     }
     const int walkers = gated ? 128 : 256;
+    int nrt, tall_rounds = 0;
     if (bt.bags == nullptr) {
-        rows_per_tile = gs_tile_pick_rows(N, walkers);
-        n_tiles = (int)((N + rows_per_tile - 1) / rows_per_tile);
+        const GtPlan pl = gs_tile_plan(N, walkers);
+        n_tiles = pl.n_tiles;
+        nrt = pl.nrt;
+        tall_rounds = pl.tall_rounds;
+    } else {
+        if (rows_per_tile < 32 || rows_per_tile > 256 || (rows_per_tile % 32) || n_tiles < 1) return VLSA_EINVAL;
+        nrt = rows_per_tile / 32;
     }
-    if (rows_per_tile < 32 || rows_per_tile > 256 || (rows_per_tile % 32) || n_tiles < 1) return VLSA_EINVAL;
     const int wg = n_tiles < walkers ? n_tiles : walkers;
     const unsigned int grid = gated ? 2u * (unsigned)((wg + 7) / 8 * 8) : (unsigned)wg;
-    const int nrt = rows_per_tile / 32;
-    if (gated) hipLaunchKernelGGL((k_scores_tile_p<true>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, bt);
-    else hipLaunchKernelGGL((k_scores_tile_p<false>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, bt);
+    if (gated) hipLaunchKernelGGL((k_scores_tile_p<true>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, tall_rounds, bt);
+    else hipLaunchKernelGGL((k_scores_tile_p<false>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, tall_rounds, bt);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
