@@ -40,7 +40,7 @@ def collect(tags, pat):
     return out
 json.dump(collect(("fetch", "write", "sq", "lds"), "partial_dma_batch"), open("$O/pmc_batch_kernel.json", "w"), indent=1)
 json.dump(collect(("fetch64", "write64", "lds64"), "partial_dma_batch"), open("$O/pmc_batch_kernel_b64.json", "w"), indent=1)
-json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "k_gated_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)
+json.dump(collect(("gs_sq", "gs_lds", "gs_mem"), "_scores"), open("$O/pmc_gated_scores.json", "w"), indent=1)   # (k_scores_tile_p at this size)
 PY
 # PMC passes for the fp32 streaming kernel
 pmc f32_fetch FETCH_SIZE -- python tools/run_batch.py 32 50000 0 f32
@@ -102,6 +102,12 @@ python tools/kbench_batch_f32.py 2>&1 | grep "N=" > $O/kbench_batch_f32.txt
 python tools/kbench_wide.py 2>&1 | grep "N=" > $O/kbench_wide.txt
 python tools/kbench_wide.py 50000 20000 2>&1 | grep "bfloat" > $O/kbench_wide_50k.txt
 python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
+# round 5: the persistent LDS-DMA score kernel next to k_gated_scores on this box, its timing-only ablations and cycle stamps (variant
+# libraries: `python tools/gt_ablate.py build; python tools/gt_stamps.py build` in the CPU container), its counters
+(echo "default (k_scores_tile_p for gated bf16 bags >= 16 384 rows):"; python tools/gt_ablate.py child; echo "VLSA_GS_TILE=0 (k_gated_scores everywhere):"; VLSA_GS_TILE=0 python tools/gt_ablate.py child; echo "VLSA_GS_TILE=1 (k_scores_tile_p for both modules):"; VLSA_GS_TILE=1 python tools/gt_ablate.py child; echo "timing-only ablations of k_scores_tile_p:"; VLSA_GS_TILE=1 python tools/gt_ablate.py) 2>&1 | grep -v amdgpu > $O/gt_ab.txt
+[ -f vlsa_amd/_lib/variants/libvlsa_gtstamp.so ] && python tools/gt_stamps.py 393216 gated 2>&1 | grep -v amdgpu > $O/gt_stamps.txt
+bash tools/pmc_tile.sh 393216 gated > /dev/null 2>&1
+[ -f tools/probes/libmfma_issue.so ] && python tools/probes/mfma_issue.py 2>&1 | grep -v amdgpu > $O/mfma_issue.txt
 python tools/kbench_featproj.py 2>&1 | grep "N=" > $O/kbench_featproj.txt
 python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1
 python tools/bench_module.py > $O/bench_module.txt 2>&1

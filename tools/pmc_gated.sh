@@ -1,6 +1,8 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): PMC passes of the attention-score kernel alone (gated and ungated module, N patches per bag):
+# Run ON THE GPU BOX (via gpurun): PMC passes of the fragment-order attention-score kernel k_gated_scores alone (gated and ungated
+# module, N patches per bag; VLSA_GS_TILE=0: the persistent LDS-DMA kernel has its own script, tools/pmc_tile.sh):
 # gpurun_out/r05/pmc_scores_<gated|ungated>_<N>.json
+export VLSA_GS_TILE=0
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05; mkdir -p $O
