@@ -756,7 +756,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     if (!f32 && N >= gs_tile_min_rows(gated != 0) && 256ll * ldx * 2 < (1ll << 31)) {
         // the ungated module's tiles are whole (one workgroup per row tile stores its scores): nothing to zero
         if (gated && hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
-        return gs_tile_launch(X, (long long)N, (long long)ldx, pp, gated, a, 0, 0, dropb, st);
+        return gs_tile_launch(X, (long long)N, (long long)ldx, pp, gated, a, 0, 0, dropb, nullptr, nullptr, st);
     }
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const int64_t round_rows = round_tiles * (int64_t)max_rows;
@@ -851,7 +851,7 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
         hipStream_t st = (hipStream_t)stream;
         if (gated && hipMemsetAsync(a, 0, (size_t)a_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
         const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
-        return gs_tile_launch(nullptr, 0ll, 0ll, static_cast<const unsigned char*>(prep), gated, a, n_tiles, rows_per_tile, bt, st);
+        return gs_tile_launch(nullptr, 0ll, 0ll, static_cast<const unsigned char*>(prep), gated, a, n_tiles, rows_per_tile, bt, nullptr, nullptr, st);
     }
     if (rows_per_tile < 16 || rows_per_tile > max_rows || (rows_per_tile % 16)) return VLSA_EINVAL;
     static DeviceOnce attr_once;
@@ -895,4 +895,18 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
     }
 #undef VLSA_GSB
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// Scores AND attention pooling of a batch of bf16 bags in ONE launch of the persistent LDS-DMA kernel (+ the per-bag fold of its
+// per-tile partials): X leaves HBM once.  Arguments as vlsa_gated_scores_batch with rows_per_tile a multiple of 32 in (max_rows of
+// vlsa_gated_scores_tiling, 256]; ws: n_tiles x 514 floats; pooled [B, 512] fp32 = sum_n softmax(a)_n x_n per bag.  a is written
+// whole (no zeroing needed).
+extern "C" int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated,
+                                            const int* tile_start, int n_tiles, int rows_per_tile, float* a, const int64_t* a_off,
+                                            float* ws, float* pooled, void* stream) {
+    if (!bag_desc || !prep || !a || !tile_start || !a_off || !ws || !pooled || B < 1 || B > 64 || n_tiles < 1) return VLSA_EINVAL;
+    if (D != gs::kD || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
+    const GsBatch bt{static_cast<const GsBag*>(bag_desc), tile_start, reinterpret_cast<const long long*>(a_off), B, 0u, 0u, 1.f, 0u};
+    return gs_tile_launch(nullptr, 0ll, 0ll, static_cast<const unsigned char*>(prep), gated, a, n_tiles, rows_per_tile, bt, ws, pooled,
+                          (hipStream_t)stream);
 }

@@ -67,7 +67,7 @@ constexpr int kB = 2 * kCols * 64;      // weight block of a K step: hi image + 
 constexpr int kA = 256 * 64;            // X chunk of a K step: 256 rows x 64 B
 constexpr int kStage = kA + kB;         // 48 KiB
 constexpr int kRing = 3 * kStage;       // 147 456 B
-constexpr int kLdsP = kRing + 4 * 256 * 4 + 3 * 1024;   // + cross-wave scratch + constants
+constexpr int kLdsP = kRing + 4 * 256 * 4 + 1040 * 4 + 256 * 4 + 64;   // + cross-wave scratch + constants + tile scores
 }  // namespace gt
 
 // wtile[((hv * 16 + ks) * 2 + term) * 16384 + col * 64 + slot * 16 + 2 e] = term of s_br W_br[h(col)][32 ks + 8 (slot ^ f(col)) + e],
@@ -129,12 +129,22 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() {
 //     wave-uniform branches, their DMA instructions are still issued -- with an offset behind the
 //     descriptor's range, which reads zeros without a memory request -- so that every wave counts the same vmcnt;
 //   * the cross-wave scratch has its own 4 KB behind the ring (buffer 0 is being refilled during the epilogue).
-template <bool GATED>
+//
+// POOL: scores AND the softmax-weighted row sum of the attention pooling (model/layers.py:117-121,148-152) in the same launch -- X
+// leaves HBM once.  A workgroup then needs its rows' COMPLETE scores: for the gated module it walks both column halves of its row tile
+// one after the other (two passes of 16 steps over the same rows, the second read of X out of the L2 / MALL; the pass's partial scores
+// meet in LDS: no atomics, no zeroed output), then takes max, exp and sum over the tile's scores and accumulates w_n x_n over its rows
+// (16-byte row loads: the rows just went through this CU's L2) into ONE partial (m, l, acc[512]) per tile, folded per bag by
+// k_pool_fold_tiles.
+struct GtPool { float* m; float* l; float* acc; };
+
+template <bool GATED, bool POOL>
 __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict__ Xv0, long long N0, long long ldx0,
                                                           const unsigned char* __restrict__ prep, float* __restrict__ a_out0,
-                                                          int n_tiles, int nrt_arg, int tall_rounds, const GsBatch bt) {
+                                                          int n_tiles, int nrt_arg, int tall_rounds, const GsBatch bt, const GtPool pool) {
     using namespace gt;
     constexpr int NW = 8, NDMA = VLSA_GT_ISSUE4 ? 12 : 6;
+    constexpr bool SEQ = GATED && POOL;         // both column halves in this workgroup, one pass each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,20 +159,20 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     // gated: the column halves of a row tile on blocks b and b + 8 (same XCD under the round-robin dispatch; gridDim.x is a
     // multiple of 16): workgroup (hv, k) walks row tiles k, k + G / 2, ...
     const int bid = blockIdx.x;
-    const int hv = GATED ? (bid >> 3) & 1 : 0;
-    const int first = GATED ? ((bid >> 4) << 3) + (bid & 7) : bid;
-    const int stride = GATED ? (int)(gridDim.x >> 1) : (int)gridDim.x;     // walkers
+    const int hv0 = (GATED && !SEQ) ? (bid >> 3) & 1 : 0;                  // the column half of this workgroup (SEQ: of its first pass)
+    const int first = (GATED && !SEQ) ? ((bid >> 4) << 3) + (bid & 7) : bid;
+    const int stride = (GATED && !SEQ) ? (int)(gridDim.x >> 1) : (int)gridDim.x;     // walkers
 
-    i32x4t wrs;
-    const unsigned long long waddr = reinterpret_cast<unsigned long long>(prep + L.wtile) + (unsigned long long)hv * gs::kSteps * kB;
+    i32x4t wrs;             // both column halves' weight blocks: half hv at hv * 16 * kB
+    const unsigned long long waddr = reinterpret_cast<unsigned long long>(prep + L.wtile);
     wrs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)waddr);
     wrs[1] = __builtin_amdgcn_readfirstlane((int)((waddr >> 32) & 0xffffu));
-    wrs[2] = gs::kSteps * kB;
+    wrs[2] = (GATED ? 2 : 1) * gs::kSteps * kB;
     wrs[3] = 0x00020000;
     const unsigned int lds0 = (unsigned int)(uintptr_t)(lds_void_ptr_t)smem;
 
     // a tile's X source, all of it wave-uniform (SGPRs): the descriptor over its rows, the row pitch, where its scores go
-    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, nrt; };
+    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, nrt; const unsigned char* x0; };
     const int xr = lane >> 2;
     const int xchunk = ((lane & 3) ^ ((0 - (xr >> 2)) & 3)) << 4;
     constexpr bool ISSUE4 = VLSA_GT_ISSUE4 != 0;
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         r.a = a;
         r.ldb = __builtin_amdgcn_readfirstlane((int)(ldx * 2));
         const unsigned long long xaddr = reinterpret_cast<unsigned long long>(Xv) + (unsigned long long)r.row0 * ldx * 2ull;
+        r.x0 = reinterpret_cast<const unsigned char*>(xaddr);
         r.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)xaddr);
         r.rs[1] = __builtin_amdgcn_readfirstlane((int)((xaddr >> 32) & 0xffffu));
         r.rs[2] = __builtin_amdgcn_readfirstlane(r.nrows > 0 ? (int)(((long long)(r.nrows - 1) * ldx + gs::kD) * 2) : 0);
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     // DMA instruction j of step ks into ring buffer buf: j < NJA: LDS row block b = wi + JW j (= tile rows 16 b ..., or 16 (nrt + b - 8) ...
     // for the second row half; a block behind the tile's height: an EMPTY descriptor -- the instruction is still issued and counted, and
     // reads zeros without a memory request); else piece wi + JW (j - NJA) of the step's weight block
-    auto issue_one = [&](const Src& sc, int ks, int buf, int j) {
+    auto issue_one = [&](const Src& sc, int hvx, int ks, int buf, int j) {
         const unsigned int sa = lds0 + buf * kStage, sb = sa + kA;
         if (j < NJA) {
             const int b = wi + JW * j, hb = b & 7;                   // (uniform)
@@ -223,13 +234,13 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
             d[2] = __builtin_amdgcn_readfirstlane(hb < sc.nrt ? sc.rs[2] : 0);
             VLSA_GT_DMA(sa + b * 1024, (16 * tb + xr) * sc.ldb + xchunk, d, ks * 64);
         } else {
-            VLSA_GT_DMA(sb + (wi + JW * (j - NJA)) * 1024, wi * 1024 + lane * 16, wrs, ks * kB + (j - NJA) * JW * 1024);
+            VLSA_GT_DMA(sb + (wi + JW * (j - NJA)) * 1024, wi * 1024 + lane * 16, wrs, (hvx * gs::kSteps + ks) * kB + (j - NJA) * JW * 1024);
         }
     };
-    auto issue = [&](const Src& sc, int ks, int buf) {
+    auto issue = [&](const Src& sc, int hvx, int ks, int buf) {
         if (ISSUE4 && wm != 0) return;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) issue_one(sc, ks, buf, j);
+        for (int j = 0; j < NJ; ++j) issue_one(sc, hvx, ks, buf, j);
     };
 
     int t = first;
@@ -237,20 +248,25 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     [[maybe_unused]] int stk = 0;               // (stamp index; dead code without VLSA_GT_STAMP)
     VLSA_GT_ST(stk++);
     Src cur = src_of(t);
-    issue(cur, 0, 0);
-    issue(cur, 1, 1);
-    issue(cur, 2, 2);
+    int hv = hv0;                               // the column half of the current pass
+    issue(cur, hv, 0, 0);
+    issue(cur, hv, 1, 1);
+    issue(cur, hv, 2, 2);
 
-    // the workgroup's constants live in LDS (registers are what this kernel is short of): [256] bias of the tile's columns, [256]
-    // w2 of the columns' hidden units, c
+    // the workgroup's constants live in LDS (registers are what this kernel is short of): per column half [256] bias of the tile's
+    // columns and [256] w2 of the columns' hidden units; c; behind them the tile's scores [256 LDS rows] (SEQ / POOL)
     constexpr int NH = GATED ? 2 : 4;
     float_mat* cst = reinterpret_cast<float_mat*>(smem + kRing + 4096);
-    if (tid < 256) {
-        const int cn = tid >> 6, ct = (tid >> 4) & 3, ci = tid & 15;
-        const int h = GATED ? 128 * hv + 32 * cn + 16 * (ct & 1) + ci : tid;
-        cst[tid] = reinterpret_cast<const float*>(prep + ((GATED && ct >= 2) ? L.bg : L.ba))[h];
-        cst[256 + tid] = reinterpret_cast<const float*>(prep + L.w2)[h];
-        if (tid == 0) cst[512] = reinterpret_cast<const float*>(prep + L.c)[0];
+    float_mat* tsc = cst + 1040;
+    {
+        const int hh = tid >> 8, ct256 = tid & 255;            // 512 threads: column half, column
+        const int cn = ct256 >> 6, ct = (ct256 >> 4) & 3, ci = ct256 & 15;
+        if (GATED || hh == 0) {
+            const int h = GATED ? 128 * hh + 32 * cn + 16 * (ct & 1) + ci : ct256;
+            cst[512 * hh + ct256] = reinterpret_cast<const float*>(prep + ((GATED && ct >= 2) ? L.bg : L.ba))[h];
+            cst[512 * hh + 256 + ct256] = reinterpret_cast<const float*>(prep + L.w2)[h];
+        }
+        if (tid == 0) cst[1024] = reinterpret_cast<const float*>(prep + L.c)[0];
     }
     // (the wait for these loads, which hipcc places in front of the LDS stores, and the first tile's wait for its operands are one)
 
@@ -259,12 +275,15 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     auto rd = [&](const unsigned char* p) { return *reinterpret_cast<const bf16x8_mat*>(p); };
     float_mat* scr = reinterpret_cast<float_mat*>(smem + kRing);    // [4 column quarters][256 LDS rows]
 
+    // one iteration = one PASS: 16 K steps of one column half over one row tile (SEQ: two passes per tile)
 #pragma unroll 1
-    for (; t < n_tiles; t += stride) {
-        const bool has_next = t + stride < n_tiles;     // uniform
+    for (; t < n_tiles;) {
+        const bool last_pass = !SEQ || hv == 1;         // of this tile (uniform)
+        const int t_next = last_pass ? t + stride : t, hv_next = SEQ ? (hv ^ 1) : hv;
+        const bool has_next = t_next < n_tiles;         // uniform
         const int nrt = cur.nrt;
         Src nxt = cur;
-        if (has_next) nxt = src_of(t + stride);
+        if (has_next && last_pass) nxt = src_of(t_next);
         // steps 0, 1, 2 of this tile have been issued (by the prologue or by the previous tile's last half-steps, step 0 last)
         VLSA_GT_ST(stk++);
         gt_wait_vm<0>();
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         f32x4 acc[8][4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const float bv = cst[64 * wn + 16 * ct + i16];
+            const float bv = cst[512 * hv + 64 * wn + 16 * ct + i16];
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) acc[rt][ct] = f32x4{bv, bv, bv, bv};
         }
@@ -328,8 +347,8 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
                     const int j0 = ISSUE4 ? (3 * slot + 1) / 2 : slot, j1 = ISSUE4 ? (3 * slot + 4) / 2 : (slot < 6 ? slot + 1 : slot);
 #pragma unroll
                     for (int j = j0; j < j1; ++j) {
-                        if (s + 3 < gs::kSteps) issue_one(cur, s + 3, s % 3, j);
-                        else if (has_next) issue_one(nxt, s % 3, s % 3, j);
+                        if (s + 3 < gs::kSteps) issue_one(cur, hv, s + 3, s % 3, j);
+                        else if (has_next) issue_one(nxt, hv_next, s % 3, s % 3, j);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         const unsigned int rid0 = bt.row_base + (unsigned int)cur.row0 + (unsigned int)(16 * nrt * wm);
         float w2v[NH];
 #pragma unroll
-        for (int j = 0; j < NH; ++j) w2v[j] = cst[256 + 64 * wn + 16 * j + i16];
+        for (int j = 0; j < NH; ++j) w2v[j] = cst[512 * hv + 256 + 64 * wn + 16 * j + i16];
         auto tail = [&](auto with_dropout) {
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt)
@@ -397,18 +416,114 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const int half_rows = 16 * nrt;
         if (tid < 256) {
-            const int half_rows = 16 * nrt, lr = tid & 127;
+            const int lr = tid & 127;
             const int tr = (tid >> 7) * half_rows + lr;         // LDS row -> row of the tile
-            if (lr < half_rows && tr < cur.nrows) {
-                const float sum = (hv == 0 ? cst[512] : 0.f) + scr[tid] + scr[256 + tid] + scr[512 + tid] + scr[768 + tid];
+            const bool valid = lr < half_rows && tr < cur.nrows;
+            const float part = scr[tid] + scr[256 + tid] + scr[512 + tid] + scr[768 + tid];
+            if constexpr (SEQ) {            // the halves meet in LDS; the second pass stores the finished score
+                const float v = hv == 0 ? cst[1024] + part : tsc[tid] + part;
+                tsc[tid] = valid ? v : -INFINITY;
+                if (hv == 1 && valid) cur.a[cur.row0 + tr] = v;
+            } else if (valid) {
+                const float sum = (hv == 0 ? cst[1024] : 0.f) + part;
+                if (POOL) tsc[tid] = sum;
                 if (GATED) atomicAdd(cur.a + cur.row0 + tr, sum);       // two addends per element on a zeroed array: order-independent
                 else cur.a[cur.row0 + tr] = sum;
+            } else if (POOL) {
+                tsc[tid] = -INFINITY;
+            }
+        }
+        if constexpr (POOL) {
+            if (last_pass) {
+                // ---- pooling partial of the tile: m = max a_n, w_n = e^(a_n - m), l = sum w_n, acc = sum w_n x_n -------------------
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                float mx = tsc[lane];
+                mx = fmaxf(fmaxf(mx, tsc[64 + lane]), fmaxf(tsc[128 + lane], tsc[192 + lane]));
+                mx = wave_max(mx);                                      // (every wave: the same 256 values)
+                // wave w accumulates LDS rows 32 w .. 32 w + 31 (one row half holds 128: rows of a wave are consecutive tile rows),
+                // lane = columns 8 lane .. 8 lane + 7; eight 16-byte row loads in flight
+                float accp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float lsum = 0.f;
+                const int lr0 = 32 * (w & 3), trb = (w >> 2) * half_rows;   // first LDS row inside the half, tile row of the half's row 0
+                const unsigned char* xw = cur.x0 + lane * 16;
+#pragma unroll 1
+                for (int r8 = 0; r8 < 32; r8 += 8) {
+                    bf16x8 xv[8];
+                    float wv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int lr = lr0 + r8 + i, tr = trb + lr;
+                        const bool ok = lr < half_rows && tr < cur.nrows;       // (uniform)
+                        wv[i] = ok ? fast_exp2((tsc[128 * (w >> 2) + lr] - mx) * kLog2e) : 0.f;
+                        xv[i] = bf16x8{};
+                        if (ok) xv[i] = *reinterpret_cast<const bf16x8*>(xw + (long long)tr * cur.ldb);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        lsum += wv[i];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) accp[e] += wv[i] * (float)xv[i][e];
+                    }
+                }
+                // the eight waves' partial sums: four rounds of 128 columns through the 4 KB scratch, fixed order
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                           // everybody has read tsc / scr
+                asm volatile("" ::: "memory");
+                if (lane == 0) tsc[w] = lsum;                           // (tsc is dead: reused for the eight l sums)
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    if ((lane >> 4) == q) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) scr[w * 128 + (lane & 15) * 8 + e] = accp[e];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (tid < 128) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int ww = 0; ww < 8; ++ww) sum += scr[ww * 128 + tid];
+                        pool.acc[(long long)t * 512 + 128 * q + tid] = sum;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                if (tid == 0) {
+                    float l = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < 8; ++ww) l += tsc[ww];
+                    pool.m[t] = mx;
+                    pool.l[t] = l;
+                }
             }
         }
         VLSA_GT_ST(stk++);
         cur = nxt;
+        t = t_next;
+        hv = hv_next;
     }
+}
+
+// Fold of the tiles' pooling partials per bag: pooled[b] = sum_t e^(m_t - m) acc_t / sum_t e^(m_t - m) l_t.  grid (B, 4), 128 threads.
+__global__ __launch_bounds__(128) void k_pool_fold_tiles(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                         const float* __restrict__ pacc, const int* __restrict__ tile_start,
+                                                         int n_tiles_single, float* __restrict__ pooled) {
+    const int b = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
+    const int t0 = tile_start ? tile_start[b] : 0, t1 = tile_start ? tile_start[b + 1] : n_tiles_single;
+    float m = -INFINITY;
+    for (int t = t0; t < t1; ++t) m = fmaxf(m, pm[t]);
+    float l = 0.f, acc = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const float f = __expf(pm[t] - m);
+        l += f * pl[t];
+        acc += f * pacc[(long long)t * 512 + c];
+    }
+    pooled[(long long)b * 512 + c] = acc / l;
 }
 
 // Called by vlsa_prepare_gated_weights (gated_scores.hip) on the same stream: the LDS image behind the fragment-order pack.
@@ -433,16 +548,22 @@ static GtPlan gs_tile_plan(long long N, int walkers) {
     return p;
 }
 
-// One bag (bt.bags == nullptr: rows_per_tile is chosen here) or the tile table of a batched launch (rows_per_tile: a multiple of 32,
-// <= 256; n_tiles = bt.tile_start[B]).  a is zeroed by the caller for the gated module.
+// One bag (bt.bags == nullptr: the tiling is chosen here) or the tile table of a batched launch (rows_per_tile: a multiple of 32,
+// <= 256; n_tiles = bt.tile_start[B]).  a is zeroed by the caller for the gated module unless `ws` is given.
+// ws != nullptr (batched launches only): scores AND attention pooling in this launch -- ws = n_tiles x 514 floats of per-tile
+// partials (m, l, acc[512]), pooled [B, 512] = the softmax-weighted row sums per bag (k_pool_fold_tiles).
 int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned char* prep, int gated, float* a, int n_tiles,
-                   int rows_per_tile, const GsBatch& bt, hipStream_t st) {
+                   int rows_per_tile, const GsBatch& bt, float* ws, float* pooled, hipStream_t st) {
     static DeviceOnce once;
     if (once.first()) {
-        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
-        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
+        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
+        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
+        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
+        (void)hipFuncSetAttribute((const void*)k_scores_tile_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
     }
-    const int walkers = gated ? 128 : 256;
+    const bool pool = ws != nullptr;
+    if (pool && (bt.bags == nullptr || pooled == nullptr)) return VLSA_EINVAL;
+    const int walkers = (gated && !pool) ? 128 : 256;       // (pooling: a workgroup walks both column halves of its row tiles)
     int nrt, tall_rounds = 0;
     if (bt.bags == nullptr) {
         const GtPlan pl = gs_tile_plan(N, walkers);
@@ -454,10 +575,18 @@ int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned cha
         nrt = rows_per_tile / 32;
     }
     const int wg = n_tiles < walkers ? n_tiles : walkers;
-    const unsigned int grid = gated ? 2u * (unsigned)((wg + 7) / 8 * 8) : (unsigned)wg;
-    if (gated) hipLaunchKernelGGL((k_scores_tile_p<true>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, tall_rounds, bt);
-    else hipLaunchKernelGGL((k_scores_tile_p<false>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, tall_rounds, bt);
-    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+    const unsigned int grid = (gated && !pool) ? 2u * (unsigned)((wg + 7) / 8 * 8) : (unsigned)wg;
+    const GtPool gp{ws, ws ? ws + n_tiles : nullptr, ws ? ws + 2ll * n_tiles : nullptr};
+#define VLSA_GTP(G, P) hipLaunchKernelGGL((k_scores_tile_p<G, P>), dim3(grid), dim3(512), gt::kLdsP, st, X, N, ldx, prep, a, n_tiles, nrt, tall_rounds, bt, gp)
+    if (gated) { if (pool) VLSA_GTP(true, true); else VLSA_GTP(true, false); }
+    else       { if (pool) VLSA_GTP(false, true); else VLSA_GTP(false, false); }
+#undef VLSA_GTP
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    if (pool) {
+        hipLaunchKernelGGL(k_pool_fold_tiles, dim3(bt.B, 4), dim3(128), 0, st, gp.m, gp.l, gp.acc, bt.tile_start, n_tiles, pooled);
+        if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    }
+    return VLSA_OK;
 }
 
 }  // namespace vlsa

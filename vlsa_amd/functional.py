@@ -7,6 +7,7 @@ Reference ops replaced (paths relative to the upstream repo): model/deepmil.py:1
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -1030,6 +1031,7 @@ def _score_tiling(f32: bool, gated: bool):
 
 
 _SCORE_BIG_TILE = {}
+_NO_FUSED_POOL = os.environ.get("VLSA_GS_NO_FUSED_POOL", "") == "1"      # (A/B hook: scores and pooling as two launches)
 
 
 def _score_big_tile(f32: bool, gated: bool):
@@ -1100,8 +1102,13 @@ class FusedAttnScores:
         max_rows, round_tiles = _score_tiling(f32, bool(gated))
         rpt = max_rows
         big_rows, big_min = _score_big_tile(f32, bool(gated))
-        if big_rows and sum(rows) >= big_min:                                    # a large batch: the persistent LDS-DMA kernel's tiles
+        fused = bool(big_rows) and sum(rows) >= big_min and not _NO_FUSED_POOL
+        if fused:            # a large batch: the persistent LDS-DMA kernel, scores and pooling in ONE launch (a workgroup per row tile)
             rpt = big_rows
+            if sum((n + rpt - 1) // rpt for n in rows) < 256:                    # less than one round: the lowest tiles that still fit it
+                rpt = max_rows + 32
+                while rpt < big_rows and sum((n + rpt - 1) // rpt for n in rows) > 256:
+                    rpt += 32
         elif sum((n + max_rows - 1) // max_rows for n in rows) < round_tiles:    # less than one round of the 256 CUs: smaller tiles
             rpt = 16
             while rpt < max_rows and sum((n + rpt - 1) // rpt for n in rows) > round_tiles:
@@ -1127,15 +1134,22 @@ class FusedAttnScores:
         stage[2] = torch.cuda.Event()
         stage[2].record()
         base = meta_d.data_ptr()
-        G = max(1, min(64, 512 // B))
         a = torch.empty(total, dtype=torch.float32, device=dev)
+        dt = nat.DT_F32 if f32 else nat.DT_BF16
+        if fused:
+            ws = torch.empty(n_tiles * 514, dtype=torch.float32, device=dev)
+            pooled = torch.empty(B, 512, dtype=torch.float32, device=dev)
+            nat.check(lib.vlsa_gated_scores_pool_batch(base, B, dt, 512, _p(prep), int(gated), base + 32 * B, n_tiles, rpt, _p(a),
+                                                       base + 24 * B, _p(ws), _p(pooled), s), "vlsa_gated_scores_pool_batch")
+            self._keep = (meta_d, bags, ws)            # the kernels read these
+            return pooled, a, offs
+        G = max(1, min(64, 512 // B))
         pm = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
         pl = torch.empty(B * G, nat.P_STRIDE, dtype=torch.float32, device=dev)
         pacc = torch.empty(B * G, 512, dtype=torch.float32, device=dev)
         m2 = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
         l = torch.empty(B, nat.P_STRIDE, dtype=torch.float32, device=dev)
         pooled = torch.empty(B, 512, dtype=torch.float32, device=dev)
-        dt = nat.DT_F32 if f32 else nat.DT_BF16
         nat.check(lib.vlsa_gated_scores_batch(base, B, dt, 512, _p(prep), int(gated), base + 32 * B, n_tiles, rpt, _p(a),
                                               base + 24 * B, total, s), "vlsa_gated_scores_batch")
         nat.check(lib.vlsa_scored_pool_partial_batch(base, B, dt, 512, _p(a), base + 24 * B, G, _p(pm), _p(pl), _p(pacc), s),
