@@ -77,6 +77,7 @@ struct GsBatch {
 
 // gated_scores_tile.hip (round 5): 128-row x 256-column tiles, both operands through LDS-DMA; bf16 bags
 int gs_tile_prepare(const float* Wa, const float* Wg, int gated, unsigned char* prep, hipStream_t st);
+int gs_tile_pool_tiles(long long N);
 int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned char* prep, int gated, float* a, int n_tiles,
                    int rows_per_tile, const GsBatch& bt, float* ws, float* pooled, hipStream_t st);
 }  // namespace vlsa

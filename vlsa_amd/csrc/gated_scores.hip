@@ -910,3 +910,15 @@ extern "C" int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_d
     return gs_tile_launch(nullptr, 0ll, 0ll, static_cast<const unsigned char*>(prep), gated, a, n_tiles, rows_per_tile, bt, ws, pooled,
                           (hipStream_t)stream);
 }
+
+// The same for ONE bag given by pointer (no bag table): ws = vlsa_gated_scores_pool_ws_floats(N) floats, pooled [512].
+extern "C" int64_t vlsa_gated_scores_pool_ws_floats(int64_t N) { return N < 1 ? 0 : 514ll * gs_tile_pool_tiles((long long)N); }
+extern "C" int vlsa_gated_scores_pool(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                                      float* ws, float* pooled, void* stream) {
+    if (!X || !prep || !a || !ws || !pooled || N < 1 || ldx < D) return VLSA_EINVAL;
+    if (D != gs::kD || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * 2) % 16) || 256ll * ldx * 2 >= (1ll << 31)) return VLSA_EINVAL;
+    const GsBatch none{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f, 0u};
+    return gs_tile_launch(X, (long long)N, (long long)ldx, static_cast<const unsigned char*>(prep), gated, a, 0, 0, none, ws, pooled,
+                          (hipStream_t)stream);
+}

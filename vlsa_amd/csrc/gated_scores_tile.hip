@@ -509,21 +509,55 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     }
 }
 
-// Fold of the tiles' pooling partials per bag: pooled[b] = sum_t e^(m_t - m) acc_t / sum_t e^(m_t - m) l_t.  grid (B, 4), 128 threads.
-__global__ __launch_bounds__(128) void k_pool_fold_tiles(const float* __restrict__ pm, const float* __restrict__ pl,
+// Fold of the tiles' pooling partials per bag: pooled[b] = sum_t e^(m_t - m) acc_t / sum_t e^(m_t - m) l_t.  grid (B, 16), 512 threads =
+// 16 tile groups x 32 columns: group g folds tiles t0 + g, t0 + g + 16, ... with a running maximum (four tiles in flight), then the 16
+// groups are combined through LDS in a fixed order.  (One thread per column walking a bag's ~200 tiles one after the other took longer
+// than the score kernel of a single 50 000-patch bag.)
+__global__ __launch_bounds__(512) void k_pool_fold_tiles(const float* __restrict__ pm, const float* __restrict__ pl,
                                                          const float* __restrict__ pacc, const int* __restrict__ tile_start,
                                                          int n_tiles_single, float* __restrict__ pooled) {
-    const int b = blockIdx.x, c = blockIdx.y * 128 + threadIdx.x;
+    __shared__ float sm[16], sl[16], sa[16][32];
+    const int b = blockIdx.x, g = threadIdx.x >> 5, ci = threadIdx.x & 31, c = blockIdx.y * 32 + ci;
     const int t0 = tile_start ? tile_start[b] : 0, t1 = tile_start ? tile_start[b + 1] : n_tiles_single;
-    float m = -INFINITY;
-    for (int t = t0; t < t1; ++t) m = fmaxf(m, pm[t]);
-    float l = 0.f, acc = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const float f = __expf(pm[t] - m);
-        l += f * pl[t];
-        acc += f * pacc[(long long)t * 512 + c];
+    float m = -INFINITY, l = 0.f, acc = 0.f;
+    for (int t = t0 + g; t < t1; t += 64) {
+        float mt[4], lt[4], at[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tt = t + 16 * i;
+            const bool ok = tt < t1;
+            mt[i] = ok ? pm[tt] : -INFINITY;
+            lt[i] = ok ? pl[tt] : 0.f;
+            at[i] = ok ? pacc[(long long)tt * 512 + c] : 0.f;
+        }
+        const float mn = fmaxf(fmaxf(m, fmaxf(mt[0], mt[1])), fmaxf(mt[2], mt[3]));
+        const float f = m == -INFINITY ? 0.f : __expf(m - mn);
+        l *= f;
+        acc *= f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float fi = mt[i] == -INFINITY ? 0.f : __expf(mt[i] - mn);
+            l += fi * lt[i];
+            acc += fi * at[i];
+        }
+        m = mn;
     }
-    pooled[(long long)b * 512 + c] = acc / l;
+    if (ci == 0) { sm[g] = m; sl[g] = l; }
+    sa[g][ci] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M = fmaxf(M, sm[k]);
+        float L = 0.f, A = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float f = sm[k] == -INFINITY ? 0.f : __expf(sm[k] - M);
+            L += f * sl[k];
+            A += f * sa[k][threadIdx.x];
+        }
+        pooled[(long long)b * 512 + c] = A / L;
+    }
 }
 
 // Called by vlsa_prepare_gated_weights (gated_scores.hip) on the same stream: the LDS image behind the fragment-order pack.
@@ -550,8 +584,10 @@ static GtPlan gs_tile_plan(long long N, int walkers) {
 
 // One bag (bt.bags == nullptr: the tiling is chosen here) or the tile table of a batched launch (rows_per_tile: a multiple of 32,
 // <= 256; n_tiles = bt.tile_start[B]).  a is zeroed by the caller for the gated module unless `ws` is given.
-// ws != nullptr (batched launches only): scores AND attention pooling in this launch -- ws = n_tiles x 514 floats of per-tile
-// partials (m, l, acc[512]), pooled [B, 512] = the softmax-weighted row sums per bag (k_pool_fold_tiles).
+// ws != nullptr: scores AND attention pooling in this launch -- ws = n_tiles x 514 floats of per-tile partials (m, l, acc[512];
+// one bag: gs_tile_pool_tiles(N) tiles), pooled [B, 512] = the softmax-weighted row sums per bag (k_pool_fold_tiles).
+int gs_tile_pool_tiles(long long N) { return gs_tile_plan(N, 256).n_tiles; }
+
 int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned char* prep, int gated, float* a, int n_tiles,
                    int rows_per_tile, const GsBatch& bt, float* ws, float* pooled, hipStream_t st) {
     static DeviceOnce once;
@@ -562,7 +598,7 @@ int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned cha
         (void)hipFuncSetAttribute((const void*)k_scores_tile_p<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gt::kLdsP);
     }
     const bool pool = ws != nullptr;
-    if (pool && (bt.bags == nullptr || pooled == nullptr)) return VLSA_EINVAL;
+    if (pool && pooled == nullptr) return VLSA_EINVAL;
     const int walkers = (gated && !pool) ? 128 : 256;       // (pooling: a workgroup walks both column halves of its row tiles)
     int nrt, tall_rounds = 0;
     if (bt.bags == nullptr) {
@@ -583,7 +619,8 @@ int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned cha
 #undef VLSA_GTP
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     if (pool) {
-        hipLaunchKernelGGL(k_pool_fold_tiles, dim3(bt.B, 4), dim3(128), 0, st, gp.m, gp.l, gp.acc, bt.tile_start, n_tiles, pooled);
+        hipLaunchKernelGGL(k_pool_fold_tiles, dim3(bt.bags ? bt.B : 1, 16), dim3(512), 0, st, gp.m, gp.l, gp.acc,
+                           bt.bags ? bt.tile_start : (const int*)nullptr, n_tiles, pooled);
         if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     }
     return VLSA_OK;

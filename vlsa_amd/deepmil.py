@@ -432,11 +432,23 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
                 pooled, a = VF.attn_pool_autograd(X2, self._fused_scores, *w, drop_p=drop_p)
                 out_feat = pooled[None, :]
             else:
-                a = self._attention_scores(X2)
-                if x_grad:         # other layer widths than 512 -> 256: library GEMMs (see _attention_scores) + torch pooling
-                    out_feat = torch.softmax(a, dim=0)[None, :] @ X2.float()
+                fused = None
+                if (not torch.is_grad_enabled() and not (gated and sg.training and sg.fc1[2].p > 0)
+                        and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
+                    # inference on a large bf16 bag: scores and pooling in ONE launch (vlsa_gated_scores_pool_batch), X read once
+                    if not hasattr(self, "_fused_scores"):
+                        self._fused_scores = VF.FusedAttnScores()
+                    w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
+                         (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
+                    fused = self._fused_scores.scores_and_pool(X2, *w)
+                if fused is not None:
+                    out_feat, a = fused
                 else:
-                    out_feat = VF.scored_pool(X2, a)[None, :]
+                    a = self._attention_scores(X2)
+                    if x_grad:         # other layer widths than 512 -> 256: library GEMMs (see _attention_scores) + torch pooling
+                        out_feat = torch.softmax(a, dim=0)[None, :] @ X2.float()
+                    else:
+                        out_feat = VF.scored_pool(X2, a)[None, :]
             if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
                 raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
         if self.pred_head == "Adapter":

@@ -1161,6 +1161,23 @@ class FusedAttnScores:
         self._keep = (meta_d, bags)                # the kernels read these
         return pooled, a, offs
 
+    def scores_and_pool(self, X2, Wa, ba, Wg, bg, w2, c):
+        """(pooled [1, 512] fp32, raw scores [N]) of ONE bag through the one-launch route of pool_bags, or None where that route does
+        not apply (fp32 bags, the ungated module, bags below vlsa_gated_scores_big_tile's size): the caller then takes the score
+        kernel and the pooling kernel one after the other."""
+        big_rows, big_min = _score_big_tile(X2.dtype == torch.float32, Wg is not None)
+        if not big_rows or X2.shape[0] < big_min or _NO_FUSED_POOL:
+            return None
+        lib = nat.load()
+        prep = self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
+        N = X2.shape[0]
+        a = torch.empty(N, dtype=torch.float32, device=X2.device)
+        ws = torch.empty(lib.vlsa_gated_scores_pool_ws_floats(N), dtype=torch.float32, device=X2.device)
+        pooled = torch.empty(1, 512, dtype=torch.float32, device=X2.device)
+        nat.check(lib.vlsa_gated_scores_pool(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a), _p(ws),
+                                             _p(pooled), _stream()), "vlsa_gated_scores_pool")
+        return pooled, a
+
     def __call__(self, X2, Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
         lib = nat.load()
         gated = Wg is not None
