@@ -82,8 +82,9 @@ def test_deepmil_bf16_bag_uses_fused_scores(pooling):
     assert (attn_b - attn_f).abs().max().item() < TOL * max(1.0, attn_f.abs().max().item())
 
 
+@pytest.mark.parametrize("pooling", ["gated_attention", "attention"])
 @pytest.mark.parametrize("N", [16384, 20001, 70000])
-def test_deepmil_large_bf16_bag_scores_and_pooling_in_one_launch(N):
+def test_deepmil_large_bf16_bag_scores_and_pooling_in_one_launch(N, pooling):
     """A large bf16 bag through DeepMIL(gated_attention) in eval mode takes vlsa_gated_scores_pool_batch (scores + pooling partials in
     ONE launch of the persistent LDS-DMA kernel + the per-bag fold): same logits / attention weights as the fp32 bag's route (score
     kernel, then pooling kernel) and as the CPU oracle's pooling (model/layers.py:103-122)."""
@@ -92,17 +93,21 @@ def test_deepmil_large_bf16_bag_scores_and_pooling_in_one_launch(N):
     from oracle import vlsa_oracle as O
     dev = torch.device("cuda", 0)
     torch.manual_seed(13)
-    m = DeepMIL(dim_in=512, dim_hid=256, use_feat_proj=False, pooling="gated_attention", pred_head="Adapter").to(dev).eval()
+    gated = pooling == "gated_attention"
+    m = DeepMIL(dim_in=512, dim_hid=256, use_feat_proj=False, pooling=pooling, pred_head="Adapter").to(dev).eval()
     X = cases.make_bag(N, 3400 + N, "clustered").to(torch.bfloat16)
     Xd = X.to(dev)
     fs = F.FusedAttnScores()
     sg = m.sigma
-    w = (sg.fc1[0].weight, sg.fc1[0].bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias)
+    w = ((sg.fc1[0].weight, sg.fc1[0].bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
+         (sg.attention[0].weight, sg.attention[0].bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
     with torch.no_grad():
         got = fs.scores_and_pool(Xd, *w)
         assert got is not None                                     # the one-launch route applies
         pooled, a = got
-        ref_pooled, ref_a = O.gated_attention_pooling(X.float(), *[t.detach().cpu() for t in w])[:2]
+        wc = [None if t is None else t.detach().cpu() for t in w]
+        ref_pooled, ref_a = (O.gated_attention_pooling(X.float(), *wc) if gated else
+                             O.attention_pooling(X.float(), wc[0], wc[1], wc[4], wc[5]))[:2]
         assert (a.cpu() - ref_a.reshape(-1)).abs().max().item() < TOL
         assert (pooled.cpu().reshape(-1) - ref_pooled.reshape(-1)).abs().max().item() < TOL
         two = F.scored_pool(Xd, fs(Xd, *w))                        # score kernel, then pooling kernel

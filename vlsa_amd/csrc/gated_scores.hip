@@ -674,12 +674,16 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
 }
 
 // Rows per tile of the persistent LDS-DMA kernel (gated_scores_tile.hip) and the total number of rows from which a batched launch
-// should use it -- 0 / 0 where it does not apply (fp32 bags, the ungated module: measured no faster there).
+// should use it -- 0 / 0 where it does not apply (fp32 bags).
 extern "C" int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_total_rows) {
     if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !rows || !min_total_rows) return VLSA_EINVAL;
-    const bool on = x_dtype == VLSA_DT_BF16 && gs_tile_min_rows(gated != 0) < (1ll << 61);
+    // (the ungated module's plain score launches keep the fragment-order kernel -- equal speed --, but its scores + pooling in one
+    // launch save the second read of X: the batched / pooled routes this answer steers use the tile kernel for both modules)
+    static const bool off = [] { const char* e = getenv("VLSA_GS_TILE"); return e && atoll(e) == 0; }();
+    const bool on = x_dtype == VLSA_DT_BF16 && !off;
+    const long long mn = gs_tile_min_rows(true);
     *rows = on ? 256 : 0;
-    *min_total_rows = on ? gs_tile_min_rows(gated != 0) : 0;
+    *min_total_rows = on ? mn : 0;
     return VLSA_OK;
 }
 

@@ -1103,6 +1103,8 @@ class FusedAttnScores:
         rpt = max_rows
         big_rows, big_min = _score_big_tile(f32, bool(gated))
         fused = bool(big_rows) and sum(rows) >= big_min and not _NO_FUSED_POOL
+        if big_rows and not fused and not gated:
+            big_rows = 0                          # (the ungated module's plain score launches keep the fragment-order kernel)
         if fused:            # a large batch: the persistent LDS-DMA kernel, scores and pooling in ONE launch (a workgroup per row tile)
             rpt = big_rows
             if sum((n + rpt - 1) // rpt for n in rows) < 256:                    # less than one round: the lowest tiles that still fit it
