@@ -32,13 +32,6 @@
 #ifndef VLSA_GT_ABL
 #define VLSA_GT_ABL 0
 #endif
-// 1: in k_scores_tile_p only the four waves of row half 0 issue the LDS-DMA (12 instructions per step each); 0 (default): all eight
-// (6 each).  Measured equal (336.4 vs 337.9 us at 393 216 patches, same box): the older half's barrier wait shrinks by what its own
-// steps grow.
-#ifndef VLSA_GT_ISSUE4
-#define VLSA_GT_ISSUE4 0
-#endif
-
 // -DVLSA_GT_STAMP: wave 0 of workgroup 0 records shader-cycle stamps of its first tiles (tools/gt_stamps.py reads them)
 #ifdef VLSA_GT_STAMP
 __device__ long long vlsa_gt_stamps[256];
@@ -143,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
                                                           const unsigned char* __restrict__ prep, float* __restrict__ a_out0,
                                                           int n_tiles, int nrt_arg, int tall_rounds, const GsBatch bt, const GtPool pool) {
     using namespace gt;
-    constexpr int NW = 8, NDMA = VLSA_GT_ISSUE4 ? 12 : 6;
+    constexpr int NW = 8, NDMA = 6;             // LDS-DMA instructions per wave and step
     constexpr bool SEQ = GATED && POOL;         // both column halves in this workgroup, one pass each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,15 +168,12 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, nrt; const unsigned char* x0; };
     const int xr = lane >> 2;
     const int xchunk = ((lane & 3) ^ ((0 - (xr >> 2)) & 3)) << 4;
-    constexpr bool ISSUE4 = VLSA_GT_ISSUE4 != 0;
-    // Who stages what.  ISSUE4: the SIMD's arbiter serves its OLDER wave first (tools/probes/mfma_issue.hip: of two waves with MFMAs
-    // ready the older one gets every slot), so the waves of row half 0 reached each step's barrier ~800 cycles before their partners
-    // and idled there while the partners, alone, could not keep the matrix pipe full.  The older half therefore does ALL of the
-    // staging (wave wn: LDS row blocks wn, wn + 4, wn + 8, wn + 12 and weight pieces wn, wn + 4, ..., wn + 28: 12 instructions per
-    // step, issue slots its partner does not have to spend), the younger half none.  Otherwise wave w stages row blocks w, w + 8 and
-    // weight pieces w, w + 8, w + 16, w + 24.
-    constexpr int NJ = ISSUE4 ? 12 : 6, NJA = ISSUE4 ? 4 : 2, JW = ISSUE4 ? 4 : 8;     // instructions per step, of them X row blocks; piece stride
-    const int wi = ISSUE4 ? wn : w;
+    // Who stages what: wave w LDS row blocks w and w + 8 and pieces w, w + 8, w + 16, w + 24 of the step's weight block.  (The SIMD's
+    // arbiter serves its OLDER wave first -- tools/probes/mfma_issue.hip --, so the waves of row half 0 reach each step's barrier 500-800
+    // cycles before their partners.  Letting the older half do ALL of the staging, 12 instructions per step, measured equal: 336.4 vs
+    // 337.9 us at 393 216 patches; its barrier wait shrinks by what its own steps grow.)
+    constexpr int NJ = 6, NJA = 2, JW = 8;      // instructions per step, of them X row blocks; piece stride
+    const int wi = w;
     auto src_of = [&](int t) -> Src {
         const void* Xv = Xv0;
         long long N = N0, ldx = ldx0;
@@ -238,7 +228,6 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         }
     };
     auto issue = [&](const Src& sc, int hvx, int ks, int buf) {
-        if (ISSUE4 && wm != 0) return;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) issue_one(sc, hvx, ks, buf, j);
     };
@@ -342,14 +331,10 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
             // The six DMA instructions of the step are spread over the 32 MFMAs of this half, one per five or six: a wave issues in
             // order, and eight waves pushing 48 LDS-DMA instructions into the CU's one texture-address unit at once (16 cycles each)
             // stalled every wave's MFMAs behind its own last DMA.
-            auto dma = [&](int slot) {          // eight slots per step: NJ / 8 instructions each (ISSUE4: 2, 1, 2, 1, ...)
-                if (!ISSUE4 || wm == 0) {
-                    const int j0 = ISSUE4 ? (3 * slot + 1) / 2 : slot, j1 = ISSUE4 ? (3 * slot + 4) / 2 : (slot < 6 ? slot + 1 : slot);
-#pragma unroll
-                    for (int j = j0; j < j1; ++j) {
-                        if (s + 3 < gs::kSteps) issue_one(cur, hv, s + 3, s % 3, j);
-                        else if (has_next) issue_one(nxt, hv_next, s % 3, s % 3, j);
-                    }
+            auto dma = [&](int slot) {          // eight slots per step, six instructions
+                if (slot < NJ) {
+                    if (s + 3 < gs::kSteps) issue_one(cur, hv, s + 3, s % 3, slot);
+                    else if (has_next) issue_one(nxt, hv_next, s % 3, s % 3, slot);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
