@@ -110,6 +110,8 @@ bash tools/pmc_tile.sh 393216 gated > /dev/null 2>&1
 [ -f tools/probes/libmfma_issue.so ] && python tools/probes/mfma_issue.py 2>&1 | grep -v amdgpu > $O/mfma_issue.txt
 python tools/kbench_featproj.py 2>&1 | grep "N=" > $O/kbench_featproj.txt
 python tools/bench_deepmil.py > $O/bench_deepmil.txt 2>&1
+(python tools/bench_deepmil.py | grep bfloat16; echo "VLSA_GS_NO_FUSED_POOL=1:"; VLSA_GS_NO_FUSED_POOL=1 python tools/bench_deepmil.py | grep bfloat16) > $O/bench_deepmil_fused.txt 2>&1
+python tools/kbench_pool.py 2>&1 | grep -v amdgpu > $O/kbench_pool.txt
 python tools/bench_module.py > $O/bench_module.txt 2>&1
 python tools/bench_paths.py > $O/bench_paths.txt 2>&1
 python tools/bench_zeroshot.py > $O/bench_zeroshot.txt 2>&1
