@@ -18,13 +18,16 @@ import torch
 from vlsa_amd import functional as F, _native as nat
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 393216
 gated = not (len(sys.argv) > 2 and sys.argv[2] == "ungated")
+pool = len(sys.argv) > 3 and sys.argv[3] == "pool"            # scores + pooling in one launch (k_scores_tile_p<.., POOL>)
 dev = "cuda"
 Wa = torch.randn(256, 512, device=dev) / 22; ba = torch.randn(256, device=dev) * 0.05
 Wg = torch.randn(256, 512, device=dev) / 22 if gated else None; bg = torch.randn(256, device=dev) * 0.05 if gated else None
 w2 = torch.randn(1, 256, device=dev) / 16; c = torch.randn(1, device=dev)
 X = torch.randn(n, 512, device=dev).to(torch.bfloat16)
 fs = F.FusedAttnScores()
-for _ in range(20): fs(X, Wa, ba, Wg, bg, w2, c)
+for _ in range(20):
+    if pool: fs.scores_and_pool(X, Wa, ba, Wg, bg, w2, c)
+    else: fs(X, Wa, ba, Wg, bg, w2, c)
 torch.cuda.synchronize()
 lib = nat.load()
 buf = (ctypes.c_longlong * 256)()
@@ -45,6 +48,11 @@ for tile in range(4):
         row.append(f"s{s}: half {st[k]-prev} wait {st[k+1]-st[k]} bar {st[k+2]-st[k+1]}")
         prev = st[k + 2]; k += 3
     print("   " + " | ".join(row))
+    if pool and (gated is False or True):
+        # (gated + pool: two passes per tile; the stamps below are those of ONE pass, the pooling stamps exist behind the second)
+        print(f"   second half of step 15: {st[k]-prev}; stamps behind the K loop (deltas): {[st[k+i+1]-st[k+i] for i in range(3)]}")
+        k += 4 if not gated else 2
+        continue
     print(f"   second half of step 15: {st[k]-prev}; epilogue {st[k+1]-st[k]}; tile total {st[k+1]-base}")
     k += 2
 

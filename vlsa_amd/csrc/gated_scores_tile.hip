@@ -423,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         if constexpr (POOL) {
             if (last_pass) {
                 // ---- pooling partial of the tile: m = max a_n, w_n = e^(a_n - m), l = sum w_n, acc = sum w_n x_n -------------------
+                VLSA_GT_ST(stk++);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
                     }
                 }
                 // the eight waves' partial sums: four rounds of 128 columns through the 4 KB scratch, fixed order
+                VLSA_GT_ST(stk++);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                           // everybody has read tsc / scr
                 asm volatile("" ::: "memory");
