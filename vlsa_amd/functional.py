@@ -1168,7 +1168,8 @@ class FusedAttnScores:
         not apply (fp32 bags, the ungated module, bags below vlsa_gated_scores_big_tile's size): the caller then takes the score
         kernel and the pooling kernel one after the other."""
         big_rows, big_min = _score_big_tile(X2.dtype == torch.float32, Wg is not None)
-        if not big_rows or X2.shape[0] < big_min or _NO_FUSED_POOL:
+        if (not big_rows or X2.shape[0] < big_min or _NO_FUSED_POOL or X2.stride(0) * 512 >= (1 << 31) or X2.stride(1) != 1
+                or (X2.data_ptr() & 15) or (X2.stride(0) * 2) % 16):
             return None
         lib = nat.load()
         prep = self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
