@@ -35,7 +35,8 @@ for it in range(n_cases):
     fs = F.FusedAttnScores()
     if rng.random() < 0.25:                       # several bags per launch (the DeepMIL batch route's score launch)
         B = rng.randint(2, 12)
-        Ns = [rng.choice(edges[:24] + [rng.randint(1, 6000)]) for _ in range(B)]
+        big = rng.random() < 0.5                   # (round 5: batches of >= 16 384 rows take the one-launch scores + pooling route)
+        Ns = [rng.choice(edges[:24] + [rng.randint(1, 6000)] + ([rng.randint(6000, 40000)] * 3 if big else [])) for _ in range(B)]
         bags = [torch.randn(n, 512, device=dev, generator=g).to(dtype) for n in Ns]
         pooled, scores, offs = fs.pool_bags(bags, Wa, ba, Wg, bg, w2, c)
         want, want_a = [], []
@@ -51,8 +52,14 @@ for it in range(n_cases):
         if rng.random() < 0.3:
             wide = torch.zeros(N, 512 + 8 * rng.randint(1, 40), dtype=dtype, device=dev); wide[:, :512] = X; X = wide[:, :512]
         got = fs(X, Wa, ba, Wg, bg, w2, c)
-        err = float((got.double() - ref(X, Wa, ba, Wg, bg, w2, c)).abs().max())
+        want_a = ref(X, Wa, ba, Wg, bg, w2, c)
+        err = float((got.double() - want_a).abs().max())
         tag = f"N={N} stride={X.stride(0)}"
+        one = fs.scores_and_pool(X, Wa, ba, Wg, bg, w2, c)       # (round 5: scores + pooling in one launch, where it applies)
+        if one is not None:
+            want_p = (torch.softmax(want_a, 0)[None] @ X.double()).squeeze(0)
+            err = max(err, float((one[1].double() - want_a).abs().max()), float((one[0].double().reshape(-1) - want_p).abs().max()))
+            tag += " +pool"
     worst = max(worst, err)
     if not err < 1e-4:
         print(f"FAIL case {it}: gated={gated} {dtype} {tag}: {err:.3e}")
