@@ -33,6 +33,10 @@
 // timing-only ablations listed at gs_tiling() below): of the 435 us at 400k patches the X loads cost 92 (343 without them), the
 // weight loads 36, the activations 34 (they were ~25 % of a tile with IEEE divisions and ds_bpermute shuffles), the barrier 25,
 // the A-fragment reads 7; LDS-DMA ring vs register ring vs deeper prefetch: equal.
+//
+// Round 5: large gated bf16 bags / batches (>= 16 384 rows) and every scores + pooling launch of bf16 bags take k_scores_tile_p
+// (gated_scores_tile.hip: both operands through LDS-DMA, persistent 256 x 256 tiles); this file keeps the fragment-order kernels for
+// everything else (fp32 bags, the ungated module's plain scores, small bags) and the C entry points, which dispatch.
 #include <cstdlib>
 
 #include "vlsa_common.h"
