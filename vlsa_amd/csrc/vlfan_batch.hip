@@ -643,8 +643,11 @@ __global__ __launch_bounds__(512, 4) void k_vlfan_merge_pool_batch(const float* 
 // 64 x 50k bags 8): ONE workgroup per bag, thread = column.  The (m, l) of all G x P partial records go through 1 KB of LDS,
 // then every accumulator piece a thread needs (<= 16 queries x 2 partials per round) is in flight at once.  At B = 256, G = 1
 // k_vlfan_merge_pool_batch took 13.6 us (2 048 workgroups of 512 threads, a serial pooling loop each); this one 256 workgroups.
-// <= 8 KiB LDS, <= 96 VGPRs: may co-reside with a persistent streaming kernel of another stream.
-__global__ __launch_bounds__(512, 3) void k_vlfan_merge_pool_small(const float* __restrict__ pm, const float* __restrict__ pl,
+// <= 8 KiB LDS, <= 96 VGPRs AND four waves (256 threads, two columns each): co-resides with a persistent streaming kernel of another
+// stream -- that kernel's two waves per SIMD leave 96 registers per lane of a SIMD, i.e. room for ONE 88-register wave: as an 8-wave
+// workgroup (round 5's first version) this kernel waited for the NEXT launch's streaming kernel to end (kernel trace: it "ran" 154 us),
+// and the tails of two launches were paid behind every pair of streaming kernels.
+__global__ __launch_bounds__(256) void k_vlfan_merge_pool_small(const float* __restrict__ pm, const float* __restrict__ pl,
                                                                     const float* __restrict__ pacc, int G, int P, int D,
                                                                     float* __restrict__ m2, float* __restrict__ l,
                                                                     float* __restrict__ out, MergeStrides st, int pool_mode,
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(512, 3) void k_vlfan_merge_pool_small(const float* 
         sm_[g][p] = ok ? pm[(size_t)g * st.sm + p] : -INFINITY;
         sl_[g][p] = ok ? pl[(size_t)g * st.sl + p] : 0.f;
     }
-    if (pool_mode == VLSA_POOL_WEIGHT && tid == 256) {
+    if (pool_mode == VLSA_POOL_WEIGHT && tid == 255) {
         float mx = -INFINITY, sum = 0.f;
         for (int q = 0; q < P; ++q) mx = fmaxf(mx, pool_w[q]);
         for (int q = 0; q < P; ++q) { spw[q] = expf(pool_w[q] - mx); sum += spw[q]; }
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(512, 3) void k_vlfan_merge_pool_small(const float* 
         }
     }
     __syncthreads();
-    for (int c = tid; c < D; c += 512) {
+    for (int c = tid; c < D; c += 256) {
         float acc[VLSA_MAX_P];
 #pragma unroll
         for (int p = 0; p < VLSA_MAX_P; ++p) acc[p] = 0.f;
@@ -752,7 +755,7 @@ int vlsa_launch_head_rows_batch(const float* rows, int B, int P, int D, int pool
 static int launch_merge_pool(const float* pm, const float* pl, const float* pacc, int B, int G, int P, int D, float* m2, float* l,
                              float* out, const MergeStrides& st, int pool_mode, const float* pool_w, float* pooled, hipStream_t s) {
     if (G <= 8)
-        hipLaunchKernelGGL(k_vlfan_merge_pool_small, dim3(B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st, pool_mode, pool_w,
+        hipLaunchKernelGGL(k_vlfan_merge_pool_small, dim3(B), dim3(256), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st, pool_mode, pool_w,
                            pooled);
     else
         hipLaunchKernelGGL(k_vlfan_merge_pool_batch, dim3((D + 63) / 64, B), dim3(512), 0, s, pm, pl, pacc, G, P, D, m2, l, out, st,
