@@ -683,9 +683,8 @@ extern "C" int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int
     if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !rows || !min_total_rows) return VLSA_EINVAL;
     // (the ungated module's plain score launches keep the fragment-order kernel -- equal speed --, but its scores + pooling in one
     // launch save the second read of X: the batched / pooled routes this answer steers use the tile kernel for both modules)
-    static const bool off = [] { const char* e = getenv("VLSA_GS_TILE"); return e && atoll(e) == 0; }();
-    const bool on = x_dtype == VLSA_DT_BF16 && !off;
     const long long mn = gs_tile_min_rows(true);
+    const bool on = x_dtype == VLSA_DT_BF16 && mn < (1ll << 61);       // (VLSA_GS_TILE=0 switches the kernel off)
     *rows = on ? 256 : 0;
     *min_total_rows = on ? mn : 0;
     return VLSA_OK;
