@@ -45,7 +45,7 @@ def test_host_side_queries_need_no_gpu():
             assert mr.value in (64, 128, 256) and rt.value >= 64
     assert lib.vlsa_gated_scores_tiling(99, 0, ctypes.addressof(mr), ctypes.addressof(rt)) != 0
     # the persistent LDS-DMA score kernel: where it applies, and the tiling of a single-bag scores + pooling launch (host arithmetic):
-    # the tiles of 256 walkers cover the bag with heights of 32 .. 256 rows whose per-walker sums differ by at most one 32-row unit
+    # the tiles of 256 walkers cover the bag with heights of 16 .. 256 rows whose per-walker sums differ by at most one 16-row unit
     rows, mn = ctypes.c_int(0), ctypes.c_int64(0)
     assert lib.vlsa_gated_scores_big_tile(_native.DT_BF16, 1, ctypes.addressof(rows), ctypes.addressof(mn)) == 0
     assert rows.value in (0, 256) and (rows.value == 0 or mn.value >= 1)       # (0: switched off through VLSA_GS_TILE=0)
@@ -54,10 +54,10 @@ def test_host_side_queries_need_no_gpu():
     for N in (1, 31, 32, 33, 8191, 8192, 8193, 16384, 50_000, 65_536, 65_537, 393_216, 400_000, 4_000_000):
         tiles = lib.vlsa_gated_scores_pool_ws_floats(N) // 514
         assert lib.vlsa_gated_scores_pool_ws_floats(N) == 514 * tiles
-        units = -(-N // (32 * 256))                 # 32-row units per walker
-        rounds = -(-units // 8)
-        lo, hi = (units // rounds) * 32, -(-units // rounds) * 32      # the two tile heights of the plan
-        assert 32 <= lo <= hi <= 256
+        units = -(-N // (16 * 256))                 # 16-row units per walker
+        rounds = -(-units // 16)
+        lo, hi = (units // rounds) * 16, -(-units // rounds) * 16      # the two tile heights of the plan
+        assert 16 <= lo <= hi <= 256
         assert -(-N // hi) <= tiles <= -(-N // lo), (N, tiles, lo, hi)
         assert tiles <= rounds * 256
 

@@ -116,9 +116,9 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() {
 //   * the DMA ring runs across tile boundaries: the last three half-steps of a tile stage steps 1, 2, 0 of the NEXT tile (the
 //     buffers those half-steps release; 16 steps over a ring of three leave every tile starting in buffer 0), so the next tile's
 //     operands arrive under the activations of this one;
-//   * tiles are h = 32 nrt <= 256 rows, chosen by the host so that the rows spread evenly over the workgroups (a 50 000-patch
-//     bag: per column half 128 tiles of 224 rows, then 112 of 192, instead of 1.53 rounds of 256-row tiles paid as 2):
-//     row half wm owns tile rows [16 nrt wm, 16 nrt (wm + 1)) at LDS rows 128 wm + ...; row tiles >= nrt are skipped under
+//   * tiles are 16 u <= 256 rows, chosen by the host so that the rows spread evenly over the workgroups (a 50 000-patch bag:
+//     per column half 128 tiles of 208 rows, then 113 of 192, instead of 1.53 rounds of 256-row tiles paid as 2): row half 0
+//     owns the first (u + 1) / 2 16-row tiles at LDS rows 0 ..., row half 1 the rest at LDS rows 128 ...; a half's unused row tiles are skipped under
 //     wave-uniform branches, their DMA instructions are still issued -- with an offset behind the
 //     descriptor's range, which reads zeros without a memory request -- so that every wave counts the same vmcnt;
 //   * the cross-wave scratch has its own 4 KB behind the ring (buffer 0 is being refilled during the epilogue).
@@ -134,7 +134,7 @@ struct GtPool { float* m; float* l; float* acc; };
 template <bool GATED, bool POOL>
 __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict__ Xv0, long long N0, long long ldx0,
                                                           const unsigned char* __restrict__ prep, float* __restrict__ a_out0,
-                                                          int n_tiles, int nrt_arg, int tall_rounds, const GsBatch bt, const GtPool pool) {
+                                                          int n_tiles, int u_arg, int tall_rounds, const GsBatch bt, const GtPool pool) {
     using namespace gt;
     constexpr int NW = 8, NDMA = 6;             // LDS-DMA instructions per wave and step
     constexpr bool SEQ = GATED && POOL;         // both column halves in this workgroup, one pass each
@@ -144,11 +144,12 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     const int wm = w >> 2, wn = w & 3;
     const int g = lane >> 4, i16 = lane & 15;
     const GatedPrepLayout L(GATED ? 1 : 0);
-    // 16-row tiles per row half: tile height 32 nrt.  (A static nrt = 8 instantiation spilled 33-40 registers where this one fits: the
-    // uniform branches around the row tiles keep the scheduler from hoisting across them.)  One bag: the tiles of the first
-    // `tall_rounds` rounds (a round = one tile per walker) are 32 (nrt_arg + 1) rows high, the others 32 nrt_arg: the walkers' row
-    // counts differ by at most one 32-row unit (a 50 000-patch bag: 128 tiles of 224 rows, then 112 of 192 -- 13 units per walker, not
-    // 2 x 7).  A batch (tile table): every tile 32 nrt_arg rows.
+    // A tile is `u` 16-row tiles high, row half 0 owning the first (u + 1) / 2 of them and row half 1 the rest (the halves share the
+    // SIMDs: what counts is their sum).  (A static instantiation spilled 33-40 registers where this one fits: the uniform branches
+    // around the row tiles keep the scheduler from hoisting across them.)  One bag: the tiles of the first `tall_rounds` rounds (a
+    // round = one tile per walker) have u = u_arg + 1, the others u_arg: the walkers' row counts differ by at most 16 rows (a
+    // 50 000-patch bag: per column half 128 tiles of 208 rows, then 113 of 192 -- 25 units per walker, not 2 x 14).  A batch (tile
+    // table): every tile u_arg x 16 rows (the table's rows_per_tile, a multiple of 32).
     // gated: the column halves of a row tile on blocks b and b + 8 (same XCD under the round-robin dispatch; gridDim.x is a
     // multiple of 16): workgroup (hv, k) walks row tiles k, k + G / 2, ...
     const int bid = blockIdx.x;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
     const unsigned int lds0 = (unsigned int)(uintptr_t)(lds_void_ptr_t)smem;
 
     // a tile's X source, all of it wave-uniform (SGPRs): the descriptor over its rows, the row pitch, where its scores go
-    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, nrt; const unsigned char* x0; };
+    struct Src { i32x4t rs; int ldb; float* a; long long row0; int nrows, n0, n1; const unsigned char* x0; };   // n0, n1: 16-row tiles of row half 0 / 1
     const int xr = lane >> 2;
     const int xchunk = ((lane & 3) ^ ((0 - (xr >> 2)) & 3)) << 4;
     // Who stages what: wave w LDS row blocks w and w + 8 and pieces w, w + 8, w + 16, w + 24 of the step's weight block.  (The SIMD's
@@ -190,15 +191,18 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
             tile -= bt.tile_start[b];
         }
         Src r;
+        int u = u_arg;
         if (bt.bags != nullptr || tall_rounds == 0) {
-            r.nrt = nrt_arg;
-            r.row0 = (long long)tile * (32 * nrt_arg);
+            r.row0 = (long long)tile * (16 * u_arg);
         } else {            // round = tile / walkers (one bag: every walker is present in every full round)
             const int rnd = __builtin_amdgcn_readfirstlane(tile / stride), tall = rnd < tall_rounds ? rnd : tall_rounds;
-            r.nrt = nrt_arg + (rnd < tall_rounds ? 1 : 0);
-            r.row0 = 32ll * stride * ((long long)rnd * nrt_arg + tall) + 32ll * (tile - rnd * stride) * r.nrt;
+            u = u_arg + (rnd < tall_rounds ? 1 : 0);
+            r.row0 = 16ll * stride * ((long long)rnd * u_arg + tall) + 16ll * (tile - rnd * stride) * u;
         }
-        const int rows_pt = 32 * r.nrt;
+        u = __builtin_amdgcn_readfirstlane(u);
+        r.n0 = (u + 1) >> 1;
+        r.n1 = u >> 1;
+        const int rows_pt = 16 * u;
         r.nrows = (int)((N - r.row0) < rows_pt ? (N - r.row0) : rows_pt);
         if (r.nrows < 0) r.nrows = 0;
         r.a = a;
@@ -208,20 +212,19 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         r.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned int)xaddr);
         r.rs[1] = __builtin_amdgcn_readfirstlane((int)((xaddr >> 32) & 0xffffu));
         r.rs[2] = __builtin_amdgcn_readfirstlane(r.nrows > 0 ? (int)(((long long)(r.nrows - 1) * ldx + gs::kD) * 2) : 0);
-        r.nrt = __builtin_amdgcn_readfirstlane(r.nrt);
         r.rs[3] = 0x00020000;
         return r;
     };
-    // DMA instruction j of step ks into ring buffer buf: j < NJA: LDS row block b = wi + JW j (= tile rows 16 b ..., or 16 (nrt + b - 8) ...
+    // DMA instruction j of step ks into ring buffer buf: j < NJA: LDS row block b = wi + JW j (= tile rows 16 b ..., or 16 (n0 + b - 8) ...
     // for the second row half; a block behind the tile's height: an EMPTY descriptor -- the instruction is still issued and counted, and
     // reads zeros without a memory request); else piece wi + JW (j - NJA) of the step's weight block
     auto issue_one = [&](const Src& sc, int hvx, int ks, int buf, int j) {
         const unsigned int sa = lds0 + buf * kStage, sb = sa + kA;
         if (j < NJA) {
             const int b = wi + JW * j, hb = b & 7;                   // (uniform)
-            const int tb = b < 8 ? b : sc.nrt + hb;
+            const int tb = b < 8 ? b : sc.n0 + hb;
             i32x4t d = sc.rs;
-            d[2] = __builtin_amdgcn_readfirstlane(hb < sc.nrt ? sc.rs[2] : 0);
+            d[2] = __builtin_amdgcn_readfirstlane(hb < (b < 8 ? sc.n0 : sc.n1) ? sc.rs[2] : 0);
             VLSA_GT_DMA(sa + b * 1024, (16 * tb + xr) * sc.ldb + xchunk, d, ks * 64);
         } else {
             VLSA_GT_DMA(sb + (wi + JW * (j - NJA)) * 1024, wi * 1024 + lane * 16, wrs, (hvx * gs::kSteps + ks) * kB + (j - NJA) * JW * 1024);
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         const bool last_pass = !SEQ || hv == 1;         // of this tile (uniform)
         const int t_next = last_pass ? t + stride : t, hv_next = SEQ ? (hv ^ 1) : hv;
         const bool has_next = t_next < n_tiles;         // uniform
-        const int nrt = cur.nrt;
+        const int nrt = wm ? cur.n1 : cur.n0;           // this wave's 16-row tiles
         Src nxt = cur;
         if (has_next && last_pass) nxt = src_of(t_next);
         // steps 0, 1, 2 of this tile have been issued (by the prologue or by the previous tile's last half-steps, step 0 last)
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
 
         // ---- epilogue of the tile (the next tile's first three steps are in flight) ------------------------------------------
         VLSA_GT_ST(stk++);
-        const unsigned int rid0 = bt.row_base + (unsigned int)cur.row0 + (unsigned int)(16 * nrt * wm);
+        const unsigned int rid0 = bt.row_base + (unsigned int)cur.row0 + (unsigned int)(wm ? 16 * cur.n0 : 0);
         float w2v[NH];
 #pragma unroll
         for (int j = 0; j < NH; ++j) w2v[j] = cst[512 * hv + 256 + 64 * wn + 16 * j + i16];
@@ -401,11 +404,10 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int half_rows = 16 * nrt;
         if (tid < 256) {
             const int lr = tid & 127;
-            const int tr = (tid >> 7) * half_rows + lr;         // LDS row -> row of the tile
-            const bool valid = lr < half_rows && tr < cur.nrows;
+            const int tr = (tid >> 7) * 16 * cur.n0 + lr;       // LDS row -> row of the tile
+            const bool valid = lr < 16 * ((tid >> 7) ? cur.n1 : cur.n0) && tr < cur.nrows;
             const float part = scr[tid] + scr[256 + tid] + scr[512 + tid] + scr[768 + tid];
             if constexpr (SEQ) {            // the halves meet in LDS; the second pass stores the finished score
                 const float v = hv == 0 ? cst[1024] + part : tsc[tid] + part;
@@ -434,7 +436,8 @@ __global__ __launch_bounds__(512, 2) void k_scores_tile_p(const void* __restrict
                 // lane = columns 8 lane .. 8 lane + 7; eight 16-byte row loads in flight
                 float accp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 float lsum = 0.f;
-                const int lr0 = 32 * (w & 3), trb = (w >> 2) * half_rows;   // first LDS row inside the half, tile row of the half's row 0
+                const int lr0 = 32 * (w & 3), trb = (w >> 2) * 16 * cur.n0;   // first LDS row inside the half, tile row of the half's row 0
+                const int half_rows = 16 * ((w >> 2) ? cur.n1 : cur.n0);
                 const unsigned char* xw = cur.x0 + lane * 16;
 #pragma unroll 1
                 for (int r8 = 0; r8 < 32; r8 += 8) {
@@ -554,18 +557,18 @@ int gs_tile_prepare(const float* Wa, const float* Wg, int gated, unsigned char* 
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }
 
-// Tiling of a single-bag launch: U = ceil(N / (32 walkers)) 32-row units per walker in R = ceil(U / 8) rounds (a round = one tile per
+// Tiling of a single-bag launch: U = ceil(N / (16 walkers)) 16-row units per walker in R = ceil(U / 16) rounds (a round = one tile per
 // walker, at most 256 rows): the first U % R rounds one unit taller than the others.
-struct GtPlan { int n_tiles, nrt, tall_rounds; };
+struct GtPlan { int n_tiles, u, tall_rounds; };
 static GtPlan gs_tile_plan(long long N, int walkers) {
-    const long long U = (N + 32ll * walkers - 1) / (32ll * walkers), R = (U + 7) / 8;
+    const long long U = (N + 16ll * walkers - 1) / (16ll * walkers), R = (U + 15) / 16;
     const long long base = U / R, rem = U % R;
     GtPlan p;
-    p.nrt = (int)base;
+    p.u = (int)base;
     p.tall_rounds = (int)rem;
-    const long long tall_rows = rem * walkers * 32 * (base + 1);
-    if (N <= tall_rows) p.n_tiles = (int)((N + 32 * (base + 1) - 1) / (32 * (base + 1)));
-    else p.n_tiles = (int)(rem * walkers + (N - tall_rows + 32 * base - 1) / (32 * base));
+    const long long tall_rows = rem * walkers * 16 * (base + 1);
+    if (N <= tall_rows) p.n_tiles = (int)((N + 16 * (base + 1) - 1) / (16 * (base + 1)));
+    else p.n_tiles = (int)(rem * walkers + (N - tall_rows + 16 * base - 1) / (16 * base));
     return p;
 }
 
@@ -587,15 +590,15 @@ int gs_tile_launch(const void* X, long long N, long long ldx, const unsigned cha
     const bool pool = ws != nullptr;
     if (pool && pooled == nullptr) return VLSA_EINVAL;
     const int walkers = (gated && !pool) ? 128 : 256;       // (pooling: a workgroup walks both column halves of its row tiles)
-    int nrt, tall_rounds = 0;
+    int nrt, tall_rounds = 0;      // (nrt: 16-row tiles per tile)
     if (bt.bags == nullptr) {
         const GtPlan pl = gs_tile_plan(N, walkers);
         n_tiles = pl.n_tiles;
-        nrt = pl.nrt;
+        nrt = pl.u;
         tall_rounds = pl.tall_rounds;
     } else {
         if (rows_per_tile < 32 || rows_per_tile > 256 || (rows_per_tile % 32) || n_tiles < 1) return VLSA_EINVAL;
-        nrt = rows_per_tile / 32;
+        nrt = rows_per_tile / 16;
     }
     const int wg = n_tiles < walkers ? n_tiles : walkers;
     const unsigned int grid = (gated && !pool) ? 2u * (unsigned)((wg + 7) / 8 * 8) : (unsigned)wg;
