@@ -164,7 +164,7 @@ def _dropout_keep(seed, rows, units, p):
     return h >= thr
 
 
-@pytest.mark.parametrize("N", [3000, 17001])       # (17 001 bf16 rows: the persistent LDS-DMA score kernel, gated_scores_tile.hip)
+@pytest.mark.parametrize("N", [3000, 19001])       # (19 001 bf16 rows: the persistent LDS-DMA score kernel, gated_scores_tile.hip)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gated_scores_training_dropout_forward_and_backward(dtype, N):
     """Gated_Attention_Pooling in train mode (nn.Dropout behind tanh and sigmoid, model/layers.py:94,99): the fused kernels with

@@ -34,7 +34,8 @@
 // weight loads 36, the activations 34 (they were ~25 % of a tile with IEEE divisions and ds_bpermute shuffles), the barrier 25,
 // the A-fragment reads 7; LDS-DMA ring vs register ring vs deeper prefetch: equal.
 //
-// Round 5: large gated bf16 bags / batches (>= 16 384 rows) and every scores + pooling launch of bf16 bags take k_scores_tile_p
+// Round 5: large bf16 bags (gs_tile_use() below: gated from 18 432 rows on, ungated 18 432 .. 65 536) and the scores + pooling launches
+// of bf16 bags / batches of >= 16 384 rows take k_scores_tile_p
 // (gated_scores_tile.hip: both operands through LDS-DMA, persistent 256 x 256 tiles); this file keeps the fragment-order kernels for
 // everything else (fp32 bags, the ungated module's plain scores, small bags) and the C entry points, which dispatch.
 #include <cstdlib>
@@ -616,15 +617,27 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
     return gs_tile_prepare(Wa, Wg, gated, static_cast<unsigned char*>(prep), (hipStream_t)stream);
 }
 
-// bf16 bags of at least this many rows take k_scores_tile (gated_scores_tile.hip); VLSA_GS_TILE = <rows> moves the threshold
-// (0: never)
-static long long gs_tile_min_rows(bool gated) {
+// Which plain score launches of bf16 bags take k_scores_tile_p (gated_scores_tile.hip).  Size sweep, both kernels on one box, 16 bags in
+// rotation (profiles/r05_gs_sweep.txt; us, tile kernel / fragment-order kernel):
+//   gated:   12k 21.0 / 18.8, 16 384: 23.3 / 20.9, 20k 25.8 / 28.0, 28k 32.0 / 37.5, 32 768: 34.6 / 40.0, 40k 45.8 / 45.4, 50k 52.3 / 57.9,
+//            70k 71 / 74.5, 100k 97 / 105, 200k 177 / 196, 400k 343.5 / 383.5                                  -> from 18 432 rows on;
+//   ungated: 16 384: 16.6 / 16.4, 20k 17.7 / 20.4, 28k 22.3 / 24.2, 32 768: 23.8 / 22.5, 40k 26.5 / 28.4, 50k 29.9 / 33.0, 60k 33.0 / 37.5,
+//            70k 44.3 / 41.7, 100k 53.2 / 55.5, 200k 101.6 / 99.6, 400k 191 / 189  -> 18 432 .. 65 536 rows (one round of its 256 walkers).
+// VLSA_GS_TILE = <rows>: from that many rows on, both modules; 0: never.
+static long long gs_tile_env() {
     static const long long env = [] { const char* e = getenv("VLSA_GS_TILE"); return e ? atoll(e) : -1ll; }();
-    if (env == 0) return (1ll << 62);
-    if (env > 0) return env;       // (both modules)
-    // gated: 393 216 patches 336 vs 376 us, 50 000: 50-52 vs 53-55, 20 000: 26.3 vs 28.9 (same box each); ungated: within +-2 % of the
-    // four-wave fragment-order kernel at every size (184 vs 186 us at 393 216): it keeps that kernel unless VLSA_GS_TILE asks
-    return gated ? 16384 : (1ll << 62);
+    return env;
+}
+static bool gs_tile_use(bool gated, long long N) {
+    const long long env = gs_tile_env();
+    if (env == 0) return false;
+    if (env > 0) return N >= env;
+    return gated ? N >= 18432 : (N >= 18432 && N <= 65536);
+}
+// rows of a batch (or a bag) from which scores + pooling in ONE launch of that kernel beat two launches (both modules)
+static long long gs_tile_min_rows_pooled() {
+    const long long env = gs_tile_env();
+    return env == 0 ? (1ll << 62) : env > 0 ? env : 16384;
 }
 
 static bool gs_round64() {
@@ -681,9 +694,8 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
 // should use it -- 0 / 0 where it does not apply (fp32 bags).
 extern "C" int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_total_rows) {
     if ((x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32) || !rows || !min_total_rows) return VLSA_EINVAL;
-    // (the ungated module's plain score launches keep the fragment-order kernel -- equal speed --, but its scores + pooling in one
-    // launch save the second read of X: the batched / pooled routes this answer steers use the tile kernel for both modules)
-    const long long mn = gs_tile_min_rows(true);
+    // (this answer steers the batched / pooled routes: both modules; plain score launches: gs_tile_use)
+    const long long mn = gs_tile_min_rows_pooled();
     const bool on = x_dtype == VLSA_DT_BF16 && mn < (1ll << 61);       // (VLSA_GS_TILE=0 switches the kernel off)
     *rows = on ? 256 : 0;
     *min_total_rows = on ? mn : 0;
@@ -760,7 +772,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         }
     }
     // round 5: large bf16 bags take the LDS-DMA tile kernel (gated_scores_tile.hip)
-    if (!f32 && N >= gs_tile_min_rows(gated != 0) && 256ll * ldx * 2 < (1ll << 31)) {
+    if (!f32 && gs_tile_use(gated != 0, (long long)N) && 256ll * ldx * 2 < (1ll << 31)) {
         // the ungated module's tiles are whole (one workgroup per row tile stores its scores): nothing to zero
         if (gated && hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
         return gs_tile_launch(X, (long long)N, (long long)ldx, pp, gated, a, 0, 0, dropb, nullptr, nullptr, st);
