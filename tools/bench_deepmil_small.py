@@ -1,0 +1,21 @@
+"""DeepMIL module call (eval, bf16, Adapter head) on slide-sized bags: host-bound -- what the one-launch scores + pooling route saves there
+(run again with VLSA_GS_NO_FUSED_POOL=1 for the two-launch route)."""
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from vlsa_amd.deepmil import DeepMIL
+dev = "cuda"
+for pooling in ("gated_attention", "attention"):
+    torch.manual_seed(1)
+    m = DeepMIL(dim_in=512, dim_hid=256, use_feat_proj=False, pooling=pooling, pred_head="Adapter").to(dev).eval()
+    for n in (700, 2798, 10000):
+        bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16)[None] for _ in range(16)]
+        with torch.no_grad():
+            for i in range(30): m(bags[i % 16])
+            torch.cuda.synchronize(); us = 1e30
+            for _ in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(100): m(bags[i % 16])
+                e1.record(); torch.cuda.synchronize(); us = min(us, e0.elapsed_time(e1) * 1e3 / 100)
+        print(f"{pooling:16s} N={n:6d} bf16: module call {us:6.1f} us")

@@ -23,7 +23,7 @@ for gated in (True, False):
     w2 = torch.randn(1, 256, device=dev) / 16; c = torch.randn(1, device=dev)
     W = (Wa, ba, Wg, bg, w2, c)
     fs = F.FusedAttnScores()
-    for n in (20000, 50000, 100000, 400000):
+    for n in ([int(x) for x in sys.argv[1:]] or (20000, 50000, 100000, 400000)):
         torch.cuda.empty_cache()
         bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16) for _ in range(4 if n > 100000 else 16)]
         a = t(lambda i: fs(bags[i % len(bags)], *W))

@@ -34,8 +34,8 @@
 // weight loads 36, the activations 34 (they were ~25 % of a tile with IEEE divisions and ds_bpermute shuffles), the barrier 25,
 // the A-fragment reads 7; LDS-DMA ring vs register ring vs deeper prefetch: equal.
 //
-// Round 5: large bf16 bags (gs_tile_use() below: gated from 18 432 rows on, ungated 18 432 .. 65 536) and the scores + pooling launches
-// of bf16 bags / batches of >= 16 384 rows take k_scores_tile_p
+// Round 5: large bf16 bags (gs_tile_use() below: gated from 18 432 rows on, ungated 18 432 .. 65 536) and ALL scores + pooling launches
+// of bf16 bags / batches take k_scores_tile_p
 // (gated_scores_tile.hip: both operands through LDS-DMA, persistent 256 x 256 tiles); this file keeps the fragment-order kernels for
 // everything else (fp32 bags, the ungated module's plain scores, small bags) and the C entry points, which dispatch.
 #include <cstdlib>
@@ -634,10 +634,13 @@ static bool gs_tile_use(bool gated, long long N) {
     if (env > 0) return N >= env;
     return gated ? N >= 18432 : (N >= 18432 && N <= 65536);
 }
-// rows of a batch (or a bag) from which scores + pooling in ONE launch of that kernel beat two launches (both modules)
+// rows of a batch (or a bag) from which scores + pooling in ONE launch of that kernel beat two launches: every size, both modules
+// -- below ~16k rows the two-launch route is bound by its host work and its launches, not by either kernel (one 2 798-patch bag: 29.6 vs
+// 40.6 us gated, 20.4 vs 35.3 ungated; a batch of 4: 47 vs 51 / 36 vs 51 us per call; profiles/r05_kbench_pool_small.txt).
+// VLSA_GS_TILE = <rows> also moves this threshold (0: never).
 static long long gs_tile_min_rows_pooled() {
     const long long env = gs_tile_env();
-    return env == 0 ? (1ll << 62) : env > 0 ? env : 16384;
+    return env == 0 ? (1ll << 62) : env > 0 ? env : 1;
 }
 
 static bool gs_round64() {
