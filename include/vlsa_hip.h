@@ -365,7 +365,8 @@ int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_t
 /* Scores AND attention pooling (model/layers.py:110-121,144-152: a_n, then sum_n softmax(a)_n x_n) of a batch of bf16 bags in ONE
  * launch of that kernel + the per-bag fold of its per-tile partials: X leaves HBM once.  Arguments as vlsa_gated_scores_batch with
  * rows_per_tile a multiple of 32 in (max_rows, 256]; ws: n_tiles * 514 floats; pooled [B, 512] fp32; a is written whole. */
-int64_t vlsa_gated_scores_pool_ws_floats(int64_t N);      /* ONE bag by pointer: ws floats; pooled [512] */
+int64_t vlsa_gated_scores_pool_ws_floats(int64_t N);      /* ONE bag by pointer (bf16 or fp32; fp32: the same result from the
+                                                            * fragment-order score kernel + pooling partials + merge, one host call): ws floats; pooled [512] */
 int vlsa_gated_scores_pool(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a, float* ws,
                            float* pooled, void* stream);
 int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,

@@ -52,14 +52,14 @@ def test_host_side_queries_need_no_gpu():
     assert lib.vlsa_gated_scores_big_tile(_native.DT_F32, 1, ctypes.addressof(rows), ctypes.addressof(mn)) == 0 and rows.value == 0
     assert lib.vlsa_gated_scores_pool_ws_floats(0) == 0
     for N in (1, 31, 32, 33, 8191, 8192, 8193, 16384, 50_000, 65_536, 65_537, 393_216, 400_000, 4_000_000):
-        tiles = lib.vlsa_gated_scores_pool_ws_floats(N) // 514
-        assert lib.vlsa_gated_scores_pool_ws_floats(N) == 514 * tiles
+        ws = lib.vlsa_gated_scores_pool_ws_floats(N)
         units = -(-N // (16 * 256))                 # 16-row units per walker
         rounds = -(-units // 16)
         lo, hi = (units // rounds) * 16, -(-units // rounds) * 16      # the two tile heights of the plan
         assert 16 <= lo <= hi <= 256
-        assert -(-N // hi) <= tiles <= -(-N // lo), (N, tiles, lo, hi)
-        assert tiles <= rounds * 256
+        assert ws >= 514 * -(-N // hi), (N, ws, hi)                  # one (m, l, acc[512]) record per tile of the bf16 route
+        assert ws >= 544 * lib.vlsa_pool_num_partials(N) + 32        # (pm, pl, pacc) + (m2, l) of the chained fp32 route
+        assert ws <= max(514 * min(-(-N // lo), rounds * 256), 544 * lib.vlsa_pool_num_partials(N) + 64)
 
 
 def test_cpu_tensor_is_refused_loudly():

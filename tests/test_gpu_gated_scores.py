@@ -121,6 +121,31 @@ def test_deepmil_large_bf16_bag_scores_and_pooling_in_one_launch(N, pooling):
 
 
 @pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("N", [1, 300, 2798, 20001])
+def test_fp32_bag_scores_and_pooling_from_one_host_call(N, gated):
+    """fp32 bags (the reference's own format): vlsa_gated_scores_pool chains the score kernel, the pooling partials and their merge inside
+    the library -- same scores as the plain score launch (bit for bit), pooled row within 1e-4 of the oracle and of the two-call route."""
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    X = cases.make_bag(N, 3500 + N, "clustered" if N % 2 else "iid")
+    W = _weights(3600 + N, gated, scale=3.0)
+    Wd = [None if t is None else t.to(dev) for t in W]
+    fs = F.FusedAttnScores()
+    if F._NO_FUSED_POOL:
+        pytest.skip("VLSA_GS_NO_FUSED_POOL=1")
+    Xd = X.to(dev)
+    got = fs.scores_and_pool(Xd, *Wd)
+    assert got is not None
+    pooled, a = got
+    assert torch.equal(a, fs(Xd, *Wd))
+    ref_a = _ref(X, *W)
+    assert (a.cpu() - ref_a).abs().max().item() < TOL
+    want = torch.softmax(ref_a.double(), 0)[None] @ X.double()
+    assert (pooled.cpu().double() - want).abs().max().item() < TOL
+    assert (pooled.reshape(-1) - F.scored_pool(Xd, a).reshape(-1)).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("gated", [True, False])
 @pytest.mark.parametrize("N", [16384, 16385, 33000, 100003])
 def test_whole_row_kernel_matches_the_oracle(N, gated, monkeypatch):
     """k_gated_scores_rows (opt-in through VLSA_GS_ROWSK: persistent 128-row tiles, the bag's rows staged as whole rows in LDS --

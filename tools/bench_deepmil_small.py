@@ -9,7 +9,8 @@ for pooling in ("gated_attention", "attention"):
     torch.manual_seed(1)
     m = DeepMIL(dim_in=512, dim_hid=256, use_feat_proj=False, pooling=pooling, pred_head="Adapter").to(dev).eval()
     for n in (700, 2798, 10000):
-        bags = [torch.randn(n, 512, device=dev).to(torch.bfloat16)[None] for _ in range(16)]
+        dt = torch.float32 if "fp32" in sys.argv else torch.bfloat16
+        bags = [torch.randn(n, 512, device=dev).to(dt)[None] for _ in range(16)]
         with torch.no_grad():
             for i in range(30): m(bags[i % 16])
             torch.cuda.synchronize(); us = 1e30
@@ -18,4 +19,4 @@ for pooling in ("gated_attention", "attention"):
                 e0.record()
                 for i in range(100): m(bags[i % 16])
                 e1.record(); torch.cuda.synchronize(); us = min(us, e0.elapsed_time(e1) * 1e3 / 100)
-        print(f"{pooling:16s} N={n:6d} bf16: module call {us:6.1f} us")
+        print(f"{pooling:16s} N={n:6d} {str(dt)[6:]}: module call {us:6.1f} us")

@@ -934,13 +934,39 @@ extern "C" int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_d
 }
 
 // The same for ONE bag given by pointer (no bag table): ws = vlsa_gated_scores_pool_ws_floats(N) floats, pooled [512].
-extern "C" int64_t vlsa_gated_scores_pool_ws_floats(int64_t N) { return N < 1 ? 0 : 514ll * gs_tile_pool_tiles((long long)N); }
+// fp32 bags (the reference's own format), or VLSA_GS_TILE=0: the same result from ONE host call through the fragment-order score kernel,
+// the pooling partials (vlsa_scored_pool_partial) and their merge -- three launches whose Python route (six allocations, three calls,
+// an autograd Function) is what bounds a slide-sized bag's module call.
+extern "C" int vlsa_pool_num_partials(int64_t N);
+extern "C" int vlsa_scored_pool_partial(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const float* scores, float* pm, float* pl,
+                                        float* pacc, void* stream);
+extern "C" int vlsa_vlfan_merge(const float* pm, const float* pl, const float* pacc, int G, int P, int D, int normalise, float* m2, float* l,
+                                float* out, void* stream);
+extern "C" int64_t vlsa_gated_scores_pool_ws_floats(int64_t N) {
+    if (N < 1) return 0;
+    const int64_t tiles = 514ll * gs_tile_pool_tiles((long long)N);
+    const int64_t chain = (int64_t)vlsa_pool_num_partials(N) * (16 + 16 + 512) + 64;      // pm, pl, pacc of the partials + (m2, l)
+    return tiles > chain ? tiles : chain;
+}
 extern "C" int vlsa_gated_scores_pool(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
                                       float* ws, float* pooled, void* stream) {
     if (!X || !prep || !a || !ws || !pooled || N < 1 || ldx < D) return VLSA_EINVAL;
-    if (D != gs::kD || x_dtype != VLSA_DT_BF16) return VLSA_EUNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * 2) % 16) || 256ll * ldx * 2 >= (1ll << 31)) return VLSA_EINVAL;
-    const GsBatch none{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f, 0u};
-    return gs_tile_launch(X, (long long)N, (long long)ldx, static_cast<const unsigned char*>(prep), gated, a, 0, 0, none, ws, pooled,
-                          (hipStream_t)stream);
+    if (D != gs::kD || (x_dtype != VLSA_DT_BF16 && x_dtype != VLSA_DT_F32)) return VLSA_EUNSUPPORTED;
+    const long long esz = x_dtype == VLSA_DT_F32 ? 4 : 2;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || ((ldx * esz) % 16) || 256ll * ldx * esz >= (1ll << 31)) return VLSA_EINVAL;
+    if (x_dtype == VLSA_DT_BF16 && gs_tile_min_rows_pooled() <= (long long)N) {
+        const GsBatch none{nullptr, nullptr, nullptr, 0, 0u, 0u, 1.f, 0u};
+        return gs_tile_launch(X, (long long)N, (long long)ldx, static_cast<const unsigned char*>(prep), gated, a, 0, 0, none, ws, pooled,
+                              (hipStream_t)stream);
+    }
+    int rc = gated_scores_impl(X, x_dtype, N, ldx, D, prep, gated, a, 0.f, 0u, stream);
+    if (rc != VLSA_OK) return rc;
+    const int G = vlsa_pool_num_partials(N);
+    float* pm = ws;
+    float* pl = pm + (size_t)G * 16;
+    float* pacc = pl + (size_t)G * 16;
+    float* ml = pacc + (size_t)G * 512;
+    rc = vlsa_scored_pool_partial(X, x_dtype, N, ldx, D, a, pm, pl, pacc, stream);
+    if (rc != VLSA_OK) return rc;
+    return vlsa_vlfan_merge(pm, pl, pacc, G, 1, D, 1, ml, ml + 16, pooled, stream);
 }

@@ -1164,12 +1164,13 @@ class FusedAttnScores:
         return pooled, a, offs
 
     def scores_and_pool(self, X2, Wa, ba, Wg, bg, w2, c):
-        """(pooled [1, 512] fp32, raw scores [N]) of ONE bag through the one-launch route of pool_bags, or None where that route does
-        not apply (fp32 bags, the ungated module, bags below vlsa_gated_scores_big_tile's size): the caller then takes the score
-        kernel and the pooling kernel one after the other."""
-        big_rows, big_min = _score_big_tile(X2.dtype == torch.float32, Wg is not None)
-        if (not big_rows or X2.shape[0] < big_min or _NO_FUSED_POOL or X2.stride(0) * 512 >= (1 << 31) or X2.stride(1) != 1
-                or (X2.data_ptr() & 15) or (X2.stride(0) * 2) % 16):
+        """(pooled [1, 512] fp32, raw scores [N]) of ONE bag from ONE host call (vlsa_gated_scores_pool): bf16 bags -- scores and pooling
+        in one launch of the persistent LDS-DMA kernel; fp32 bags -- score kernel, pooling partials and merge chained inside the
+        library.  None where the bag's layout rules it out (or VLSA_GS_NO_FUSED_POOL=1): the caller then takes the score kernel and
+        the pooling kernel one after the other."""
+        esz = X2.element_size()
+        if (_NO_FUSED_POOL or X2.stride(0) * 256 * esz >= (1 << 31) or X2.stride(1) != 1 or (X2.data_ptr() & 15)
+                or (X2.stride(0) * esz) % 16):
             return None
         lib = nat.load()
         prep = self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
