@@ -369,6 +369,11 @@ int64_t vlsa_gated_scores_pool_ws_floats(int64_t N);      /* ONE bag by pointer 
                                                             * fragment-order score kernel + pooling partials + merge, one host call): ws floats; pooled [512] */
 int vlsa_gated_scores_pool(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a, float* ws,
                            float* pooled, void* stream);
+/* ... and DeepMIL's Adapter head (model/deepmil.py:283-286, as vlsa_adapter_head) behind it, same host call: W1 [R, 512], W2 [512, R],
+ * R % 4 == 0; ws gets R more floats (the hidden row); logit [512]. */
+int vlsa_gated_scores_pool_adapter(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                                   float* ws, float* pooled, const float* W1, int R, const float* W2, float keep_ratio, float* logit,
+                                   void* stream);
 int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated, const int* tile_start,
                                  int n_tiles, int rows_per_tile, float* a, const int64_t* a_off, float* ws, float* pooled,
                                  void* stream);

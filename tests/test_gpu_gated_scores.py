@@ -145,6 +145,73 @@ def test_fp32_bag_scores_and_pooling_from_one_host_call(N, gated):
     assert (pooled.reshape(-1) - F.scored_pool(Xd, a).reshape(-1)).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("N", [1, 257, 2799, 19001])
+def test_scores_pooling_and_adapter_head_from_one_host_call(N, gated, dtype):
+    """vlsa_gated_scores_pool_adapter: the Adapter head (model/deepmil.py:283-286) behind scores + pooling in the same host call --
+    same scores and pooled row as the call without it, logit identical to the separate vlsa_adapter_head launch on that row and within
+    1e-4 of keep * f + (1 - keep) * relu(W2 relu(W1 f)) in float64."""
+    from vlsa_amd import functional as F
+    if F._NO_FUSED_POOL:
+        pytest.skip("VLSA_GS_NO_FUSED_POOL=1")
+    dev = torch.device("cuda", 0)
+    X = cases.make_bag(N, 7100 + N, "clustered" if N % 2 else "iid").to(dtype)
+    W = _weights(7200 + N, gated, scale=3.0)
+    Wd = [None if t is None else t.to(dev) for t in W]
+    g = torch.Generator().manual_seed(7300 + N)
+    W1 = torch.randn(128, 512, generator=g) / 512 ** 0.5
+    W2 = torch.randn(512, 128, generator=g) / 128 ** 0.5
+    fs = F.FusedAttnScores()
+    Xd = X.to(dev)
+    pooled0, a0 = fs.scores_and_pool(Xd, *Wd)
+    pooled, a, logit = fs.scores_and_pool(Xd, *Wd, adapter=(W1.to(dev), W2.to(dev), 0.8))
+    assert torch.equal(a, a0) and torch.equal(pooled, pooled0)
+    assert logit.shape == (1, 512)
+    assert torch.equal(logit.reshape(-1), F.adapter_head(pooled, W1.to(dev), W2.to(dev), 0.8))
+    f = pooled.cpu().double().reshape(-1)
+    want = 0.8 * f + 0.2 * torch.relu(W2.double() @ torch.relu(W1.double() @ f))
+    assert (logit.cpu().double().reshape(-1) - want).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("R", [4, 36, 64, 128, 192, 320, 512, 640])
+def test_adapter_head_alone(R):
+    """vlsa_adapter_head: keep f + (1 - keep) relu(W2 relu(W1 f)) (model/deepmil.py:283-286, model/layers.py:50-62) -- two launches of
+    k_rows_dot_relu (one wave per output row), any R % 4 == 0."""
+    from vlsa_amd import functional as F
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(8100 + R)
+    f = torch.randn(512, generator=g)
+    W1 = torch.randn(R, 512, generator=g) / 512 ** 0.5
+    W2 = torch.randn(512, R, generator=g) / R ** 0.5
+    got = F.adapter_head(f.to(dev), W1.to(dev), W2.to(dev), 0.3).cpu().double()
+    want = 0.3 * f.double() + 0.7 * torch.relu(W2.double() @ torch.relu(W1.double() @ f.double()))
+    assert (got - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("R", [36, 256])
+def test_scores_pooling_and_adapter_head_other_widths_and_large_bags(R):
+    """R != 128, and a bag beyond 65 536 rows (more than one round of tiles per walker)."""
+    from vlsa_amd import functional as F
+    if F._NO_FUSED_POOL:
+        pytest.skip("VLSA_GS_NO_FUSED_POOL=1")
+    dev = torch.device("cuda", 0)
+    for N in (5000, 70001):
+        X = cases.make_bag(N, 8200 + N, "iid").to(torch.bfloat16).to(dev)
+        Wd = [None if t is None else t.to(dev) for t in _weights(8300 + N, True, scale=3.0)]
+        g = torch.Generator().manual_seed(8400 + R)
+        W1 = (torch.randn(R, 512, generator=g) / 512 ** 0.5).to(dev)
+        W2 = (torch.randn(512, R, generator=g) / R ** 0.5).to(dev)
+        fs = F.FusedAttnScores()
+        pooled0, a0 = fs.scores_and_pool(X, *Wd)
+        pooled, a, logit = fs.scores_and_pool(X, *Wd, adapter=(W1, W2, 0.5))
+        assert torch.equal(a, a0)
+        assert torch.equal(pooled, pooled0)
+        f = pooled.double().reshape(-1)
+        want = 0.5 * f + 0.5 * torch.relu(W2.double() @ torch.relu(W1.double() @ f))
+        assert (logit.double().reshape(-1) - want).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("gated", [True, False])
 @pytest.mark.parametrize("N", [16384, 16385, 33000, 100003])
 def test_whole_row_kernel_matches_the_oracle(N, gated, monkeypatch):

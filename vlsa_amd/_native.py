@@ -102,6 +102,8 @@ _SIGNATURES = {
     "vlsa_gated_scores_big_tile": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "vlsa_gated_scores_pool_ws_floats": (c_int64, [c_int64]),
     "vlsa_gated_scores_pool": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_gated_scores_pool_adapter": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "vlsa_gated_scores_pool_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p]),
     "vlsa_gated_scores_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

@@ -970,3 +970,19 @@ extern "C" int vlsa_gated_scores_pool(const void* X, int x_dtype, int64_t N, int
     if (rc != VLSA_OK) return rc;
     return vlsa_vlfan_merge(pm, pl, pacc, G, 1, D, 1, ml, ml + 16, pooled, stream);
 }
+
+// ... and DeepMIL's Adapter head behind it (vlsa_adapter_head: model/deepmil.py:283-286) from the same host call: the whole N-sized and
+// head part of DeepMIL.forward(eval) for one bag.  ws: vlsa_gated_scores_pool_ws_floats(N) + R floats; W1 [R, 512], W2 [512, R]; logit [512].
+// (Fold + both head layers as ONE single-workgroup launch was built and measured: 27 us for that kernel -- one CU pulls the 0.35 MB of
+// tile partials and the 0.5 MB of head weights at 30-50 GB/s -- against 5 + 5 + 5 us for the three grid launches; module call 50-58
+// instead of 39-40 us.  The three launches stay.)
+extern "C" int vlsa_adapter_head(const float* f, int D, const float* W1, int R, const float* W2, float keep_ratio, float* hidden, float* out,
+                                 void* stream);
+extern "C" int vlsa_gated_scores_pool_adapter(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* prep, int gated, float* a,
+                                              float* ws, float* pooled, const float* W1, int R, const float* W2, float keep_ratio,
+                                              float* logit, void* stream) {
+    if (!W1 || !W2 || !logit || R < 4 || (R % 4)) return VLSA_EINVAL;
+    const int rc = vlsa_gated_scores_pool(X, x_dtype, N, ldx, D, prep, gated, a, ws, pooled, stream);
+    if (rc != VLSA_OK) return rc;
+    return vlsa_adapter_head(pooled, D, W1, R, W2, keep_ratio, ws + vlsa_gated_scores_pool_ws_floats(N), logit, stream);
+}

@@ -409,7 +409,7 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
         assert X.shape[0] == 1
         if self.feat_proj is not None:
             X = self.feat_proj(X)
-        raw_attn = None
+        raw_attn = fused_logit = None
         x_grad = torch.is_grad_enabled() and X.requires_grad   # a trainable Feat_Projecter in front: the pooling must hand dX back
         if self.sigma == "mean":
             out_feat = X.float().mean(dim=1) if x_grad else VF.scored_pool(X, None)[None, :]
@@ -419,30 +419,42 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
             X2 = VF._bag2d(X)
             sg = self.sigma
             gated = isinstance(sg, Gated_Attention_Pooling)
-            lin_a = sg.fc1[0] if gated else sg.attention[0]
-            if (x_grad and (not gated or sg.fc1[2].p == sg.score[2].p)
+            sm = sg._modules          # (plain dict look-ups: seven nn.Sequential.__getitem__ calls are 10 us of a 40 us module call)
+            if gated:
+                f1, sc = sm["fc1"]._modules, sm["score"]._modules
+                lin_a, lin_g, lin_o, drop_a, drop_g = f1["0"], sc["0"], sm["fc2"], f1["2"], sc["2"]
+            else:
+                at = sm["attention"]._modules
+                lin_a, lin_g, lin_o, drop_a, drop_g = at["0"], None, at["2"], None, None
+            if (x_grad and (not gated or drop_a.p == drop_g.p)
                     and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
                 # scores + pooling as ONE autograd node whose backward is HIP end to end: parameter gradients AND
                 # dX = dHa Wa + dHg Wg + A dpooled (vlsa_attn_scores_backward_dx); 512 -> 256 hidden, the reference's sizes
                 if not hasattr(self, "_fused_scores"):
                     self._fused_scores = VF.FusedAttnScores()
-                w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
-                     (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
-                drop_p = float(sg.fc1[2].p) if (gated and sg.training and sg.fc1[2].p > 0) else 0.0
+                w = (lin_a.weight, lin_a.bias, lin_g.weight if gated else None, lin_g.bias if gated else None, lin_o.weight, lin_o.bias)
+                drop_p = float(drop_a.p) if (gated and sg.training and drop_a.p > 0) else 0.0
                 pooled, a = VF.attn_pool_autograd(X2, self._fused_scores, *w, drop_p=drop_p)
                 out_feat = pooled[None, :]
             else:
                 fused = None
-                if (not torch.is_grad_enabled() and not (gated and sg.training and sg.fc1[2].p > 0)
+                if (not torch.is_grad_enabled() and not (gated and sg.training and drop_a.p > 0)
                         and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
                     # inference on a large bf16 bag: scores and pooling in ONE launch (vlsa_gated_scores_pool_batch), X read once
                     if not hasattr(self, "_fused_scores"):
                         self._fused_scores = VF.FusedAttnScores()
-                    w = ((lin_a.weight, lin_a.bias, sg.score[0].weight, sg.score[0].bias, sg.fc2.weight, sg.fc2.bias) if gated else
-                         (lin_a.weight, lin_a.bias, None, None, sg.attention[2].weight, sg.attention[2].bias))
-                    fused = self._fused_scores.scores_and_pool(X2, *w)
+                    w = (lin_a.weight, lin_a.bias, lin_g.weight if gated else None, lin_g.bias if gated else None, lin_o.weight, lin_o.bias)
+                    adapter = None
+                    if self.pred_head == "Adapter":
+                        fc = self.visual_adapter._modules["fc"]._modules
+                        W1, W2 = fc["0"].weight, fc["2"].weight
+                        if W1.shape[1] == 512 and W2.shape[0] == 512 and W1.shape[0] % 4 == 0:
+                            adapter = (W1, W2, self.keep_ratio)
+                    fused = self._fused_scores.scores_and_pool(X2, *w, adapter=adapter)
                 if fused is not None:
-                    out_feat, a = fused
+                    out_feat, a = fused[0], fused[1]
+                    if len(fused) == 3:
+                        fused_logit = fused[2]
                 else:
                     a = self._attention_scores(X2)
                     if x_grad:         # other layer widths than 512 -> 256: library GEMMs (see _attention_scores) + torch pooling
@@ -451,7 +463,9 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
                         out_feat = VF.scored_pool(X2, a)[None, :]
             if ret_with_attn:  # what the reference hands back: raw scores (attention) / softmax weights (gated attention)
                 raw_attn = a[None, :] if isinstance(self.sigma, Attention_Pooling) else F.softmax(a, dim=0)[None, :]
-        if self.pred_head == "Adapter":
+        if fused_logit is not None:
+            logit = fused_logit                      # (computed behind the pooling in the same host call)
+        elif self.pred_head == "Adapter":
             fc = self.visual_adapter.fc
             if not (torch.is_grad_enabled() and any(p.requires_grad for p in fc.parameters())) and out_feat.is_cuda:
                 logit = VF.adapter_head(out_feat, fc[0].weight, fc[2].weight, self.keep_ratio)[None, :]   # two small HIP launches

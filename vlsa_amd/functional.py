@@ -1047,6 +1047,9 @@ def _score_big_tile(f32: bool, gated: bool):
     return t
 
 
+_POOL_WS: dict = {}        # N -> vlsa_gated_scores_pool_ws_floats(N)
+
+
 class FusedAttnScores:
     """Raw attention scores a[N] of (Gated_)Attention_Pooling over all patches of a bf16 or fp32 bag in ONE MFMA kernel
     (vlsa_gated_scores; model/layers.py:85-153): the [N, 256] hidden activations never reach memory.  Holds the weights
@@ -1163,11 +1166,12 @@ class FusedAttnScores:
         self._keep = (meta_d, bags)                # the kernels read these
         return pooled, a, offs
 
-    def scores_and_pool(self, X2, Wa, ba, Wg, bg, w2, c):
+    def scores_and_pool(self, X2, Wa, ba, Wg, bg, w2, c, adapter=None):
         """(pooled [1, 512] fp32, raw scores [N]) of ONE bag from ONE host call (vlsa_gated_scores_pool): bf16 bags -- scores and pooling
         in one launch of the persistent LDS-DMA kernel; fp32 bags -- score kernel, pooling partials and merge chained inside the
         library.  None where the bag's layout rules it out (or VLSA_GS_NO_FUSED_POOL=1): the caller then takes the score kernel and
-        the pooling kernel one after the other."""
+        the pooling kernel one after the other.  adapter = (W1 [R, 512], W2 [512, R], keep_ratio): DeepMIL's Adapter head
+        (model/deepmil.py:283-286) behind it in the same call -> (pooled, scores, logit [1, 512])."""
         esz = X2.element_size()
         if (_NO_FUSED_POOL or X2.stride(0) * 256 * esz >= (1 << 31) or X2.stride(1) != 1 or (X2.data_ptr() & 15)
                 or (X2.stride(0) * esz) % 16):
@@ -1175,12 +1179,26 @@ class FusedAttnScores:
         lib = nat.load()
         prep = self._packed(X2.device, Wa, ba, Wg, bg, w2, c)
         N = X2.shape[0]
-        a = torch.empty(N, dtype=torch.float32, device=X2.device)
-        ws = torch.empty(lib.vlsa_gated_scores_pool_ws_floats(N), dtype=torch.float32, device=X2.device)
-        pooled = torch.empty(1, 512, dtype=torch.float32, device=X2.device)
-        nat.check(lib.vlsa_gated_scores_pool(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a), _p(ws),
-                                             _p(pooled), _stream()), "vlsa_gated_scores_pool")
-        return pooled, a
+        nws = _POOL_WS.get(N)
+        if nws is None:
+            if len(_POOL_WS) > 4096:
+                _POOL_WS.clear()
+            nws = _POOL_WS[N] = lib.vlsa_gated_scores_pool_ws_floats(N)
+        Na = (N + 63) & ~63                              # (the parts behind the scores stay 256-B aligned)
+        if adapter is None:
+            buf = torch.empty(Na + 512 + nws, dtype=torch.float32, device=X2.device)     # ONE allocation: scores | pooled | workspace
+            a, pooled, ws = buf[:N], buf[Na:Na + 512].view(1, 512), buf[Na + 512:]
+            nat.check(lib.vlsa_gated_scores_pool(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a), _p(ws),
+                                                 _p(pooled), _stream()), "vlsa_gated_scores_pool")
+            return pooled, a
+        W1, W2, keep = adapter                           # DeepMIL's Adapter head behind the pooling, same host call
+        R = W1.shape[0]
+        buf = torch.empty(Na + 1024 + nws + R, dtype=torch.float32, device=X2.device)    # scores | pooled | logit | workspace
+        a, pooled, logit, ws = buf[:N], buf[Na:Na + 512].view(1, 512), buf[Na + 512:Na + 1024].view(1, 512), buf[Na + 1024:]
+        nat.check(lib.vlsa_gated_scores_pool_adapter(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a),
+                                                     _p(ws), _p(pooled), _p(_f32c(W1)), R, _p(_f32c(W2)), float(keep), _p(logit), _stream()),
+                  "vlsa_gated_scores_pool_adapter")
+        return pooled, a, logit
 
     def __call__(self, X2, Wa, ba, Wg, bg, w2, c, drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
         lib = nat.load()
