@@ -13,6 +13,9 @@
 // Matrix-pipe load per 16-row tile per wave: 32 f32 steps (scores, 32 cycles each) + 24 bf16 steps (sum, 16 cycles) = 1408
 // cycles; with the sum in f32 as well (round 1) it was 2048 = ~95 % of the pipe at HBM rate, and the kernel sat at 62-64 %.
 #include "vlsa_common.h"
+#ifndef VLSA_F32_ABL
+#define VLSA_F32_ABL 0     // timing-only ablations / schedule variants (tools/f32_ablate.py); 0 = the product
+#endif
 
 namespace vlsa {
 
@@ -234,12 +237,26 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                     xa[4 * j + 3] = v[3];
                 }
                 f32x4 Sb = {0.f, 0.f, 0.f, 0.f};
+#if (VLSA_F32_ABL & 4)
+                S[0] = xa[0] + xa[31];      // timing only: no score MFMAs
+#elif (VLSA_F32_ABL & 32)
+                f32x4 Sc = {0.f, 0.f, 0.f, 0.f}, Sd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 32; kk += 4) {
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], qf[kk], S, 0, 0, 0);
+                    Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 1], qf[kk + 1], Sb, 0, 0, 0);
+                    Sc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 2], qf[kk + 2], Sc, 0, 0, 0);
+                    Sd = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 3], qf[kk + 3], Sd, 0, 0, 0);
+                }
+                S = (S + Sb) + (Sc + Sd);
+#else
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 2) {
                     S = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], qf[kk], S, 0, 0, 0);
                     Sb = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk + 1], qf[kk + 1], Sb, 0, 0, 0);
                 }
                 S += Sb;
+#endif
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 32; kk += 2) {
@@ -314,6 +331,25 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                     whi[r] = (__bf16)wv[r];
                     wlo[r] = (__bf16)(wv[r] - (float)whi[r]);
                 }
+#if (VLSA_F32_ABL & 2)
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[ct][0] += xb[0][ct] + xb[1][ct] + xb[2][ct] + xb[3][ct];   // timing only: reads stay
+#elif (VLSA_F32_ABL & 16)
+                bf16x4 xh[8], xl[8];
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xh[ct][r] = (__bf16)xb[r][ct];
+                        xl[ct][r] = (__bf16)(xb[r][ct] - (float)xh[ct][r]);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xh[ct], acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh[ct], acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xl[ct], acc[ct], 0, 0, 0);
+#else
 #pragma unroll
                 for (int ct = 0; ct < 8; ++ct) {
                     bf16x4 xh, xl;
@@ -322,10 +358,15 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_f32_batch(const BagDes
                         xh[r] = (__bf16)xb[r][ct];
                         xl[r] = (__bf16)(xb[r][ct] - (float)xh[r]);
                     }
+#if (VLSA_F32_ABL & 1)
+                    acc[ct][0] += (float)xh[0] + (float)xl[1] + (float)xh[2] + (float)xl[3] + (float)xl[0] + (float)xh[1] + (float)xl[2] + (float)xh[3];   // timing only: splits stay, no MFMAs
+#else
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xh, acc[ct], 0, 0, 0);
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wlo, xh, acc[ct], 0, 0, 0);
                     acc[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(whi, xl, acc[ct], 0, 0, 0);
+#endif
                 }
+#endif
                 ++kown;
             }
             
