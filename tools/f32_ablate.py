@@ -5,13 +5,13 @@
 import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBD = os.path.join(ROOT, "vlsa_amd", "_lib")
-NAMES = {0: "the product", 1: "weighted sum: splits, no MFMAs", 2: "weighted sum: LDS reads only", 4: "no score MFMAs", 6: "neither contraction",
+NAMES = {"old": "the previous build (copy it to variants/libvlsa_f32_old.so by hand)", 0: "the product", 1: "weighted sum: splits, no MFMAs", 2: "weighted sum: LDS reads only", 4: "no score MFMAs", 6: "neither contraction",
          16: "weighted sum term-major (independent MFMAs back to back)", 32: "four score accumulators", 48: "both re-orderings"}
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.join(LIBD, "variants"), exist_ok=True)
     objs = [o for o in glob.glob(os.path.join(LIBD, "obj", "*.o")) if not o.endswith("vlfan_batch_f32.o")]
     for bits in NAMES:
-        if bits == 0:
+        if bits in (0, "old"):
             continue
         o = f"/tmp/f32_abl{bits}.o"
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DVLSA_F32_ABL={bits}", "-c",
