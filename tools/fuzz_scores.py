@@ -55,11 +55,20 @@ for it in range(n_cases):
         want_a = ref(X, Wa, ba, Wg, bg, w2, c)
         err = float((got.double() - want_a).abs().max())
         tag = f"N={N} stride={X.stride(0)}"
-        one = fs.scores_and_pool(X, Wa, ba, Wg, bg, w2, c)       # (round 5: scores + pooling in one launch, where it applies)
+        head = None
+        if rng.random() < 0.5:                                    # ... with DeepMIL's Adapter head behind it in the same host call
+            R = rng.choice([4, 36, 64, 128, 128, 128, 256, 512, 640])
+            head = (torch.randn(R, 512, device=dev, generator=g) / 22, torch.randn(512, R, device=dev, generator=g) / R ** 0.5, rng.choice([0.2, 0.8, 1.0]))
+        one = fs.scores_and_pool(X, Wa, ba, Wg, bg, w2, c, adapter=head)       # (round 5: scores + pooling in one launch, where it applies)
         if one is not None:
             want_p = (torch.softmax(want_a, 0)[None] @ X.double()).squeeze(0)
             err = max(err, float((one[1].double() - want_a).abs().max()), float((one[0].double().reshape(-1) - want_p).abs().max()))
             tag += " +pool"
+            if head is not None:
+                W1, W2, keep = head
+                want_l = keep * want_p + (1 - keep) * torch.relu(W2.double() @ torch.relu(W1.double() @ want_p))
+                err = max(err, float((one[2].double().reshape(-1) - want_l).abs().max()))
+                tag += f" +head R={W1.shape[0]}"
     worst = max(worst, err)
     if not err < 1e-4:
         print(f"FAIL case {it}: gated={gated} {dtype} {tag}: {err:.3e}")
