@@ -363,7 +363,8 @@ int vlsa_attn_scores(const float* H, const float* Hg, int64_t N, int hid, const 
 int vlsa_gated_scores_tiling(int x_dtype, int gated, int* max_rows, int* round_tiles);
 int vlsa_gated_scores_big_tile(int x_dtype, int gated, int* rows, int64_t* min_total_rows);
 /* Scores AND attention pooling (model/layers.py:110-121,144-152: a_n, then sum_n softmax(a)_n x_n) of a batch of bf16 bags in ONE
- * launch of that kernel + the per-bag fold of its per-tile partials: X leaves HBM once.  Arguments as vlsa_gated_scores_batch with
+ * launch of that kernel + the per-bag fold of its per-tile partials (one launch latency chain instead of two; the second pass over a
+ * tile's rows and the pooling pass come through the L2 from the MALL / HBM again: profiles/r05_pmc_pool_traffic.json).  Arguments as vlsa_gated_scores_batch with
  * rows_per_tile a multiple of 32 in (max_rows, 256]; ws: n_tiles * 514 floats; pooled [B, 512] fp32; a is written whole. */
 int64_t vlsa_gated_scores_pool_ws_floats(int64_t N);      /* ONE bag by pointer (bf16 or fp32; fp32: the same result from the
                                                             * fragment-order score kernel + pooling partials + merge, one host call): ws floats; pooled [512] */

@@ -920,7 +920,7 @@ extern "C" int vlsa_gated_scores_batch(const void* bag_desc, int B, int x_dtype,
 }
 
 // Scores AND attention pooling of a batch of bf16 bags in ONE launch of the persistent LDS-DMA kernel (+ the per-bag fold of its
-// per-tile partials): X leaves HBM once.  Arguments as vlsa_gated_scores_batch with rows_per_tile a multiple of 32 in (max_rows of
+// per-tile partials).  Arguments as vlsa_gated_scores_batch with rows_per_tile a multiple of 32 in (max_rows of
 // vlsa_gated_scores_tiling, 256]; ws: n_tiles x 514 floats; pooled [B, 512] fp32 = sum_n softmax(a)_n x_n per bag.  a is written
 // whole (no zeroing needed).
 extern "C" int vlsa_gated_scores_pool_batch(const void* bag_desc, int B, int x_dtype, int D, const void* prep, int gated,

@@ -123,8 +123,10 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() {
 //     descriptor's range, which reads zeros without a memory request -- so that every wave counts the same vmcnt;
 //   * the cross-wave scratch has its own 4 KB behind the ring (buffer 0 is being refilled during the epilogue).
 //
-// POOL: scores AND the softmax-weighted row sum of the attention pooling (model/layers.py:117-121,148-152) in the same launch -- X
-// leaves HBM once.  A workgroup then needs its rows' COMPLETE scores: for the gated module it walks both column halves of its row tile
+// POOL: scores AND the softmax-weighted row sum of the attention pooling (model/layers.py:117-121,148-152) in the same launch (no
+// second launch, no second pass of another kernel's latency chain; the L2s still fetch the bag's rows ~2.9 times from the fabric --
+// MALL or HBM, FETCH_SIZE cannot tell -- where score kernel + pooling kernel fetch 2.3 times: profiles/r05_pmc_pool_traffic.json; the
+// launch is matrix-pipe-bound, not bound by those 3 TB/s).  A workgroup then needs its rows' COMPLETE scores: for the gated module it walks both column halves of its row tile
 // one after the other (two passes of 16 steps over the same rows, the second read of X out of the L2 / MALL; the pass's partial scores
 // meet in LDS: no atomics, no zeroed output), then takes max, exp and sum over the tile's scores and accumulates w_n x_n over its rows
 // (16-byte row loads: the rows just went through this CU's L2) into ONE partial (m, l, acc[512]) per tile, folded per bag by

@@ -440,7 +440,7 @@ class DeepMIL(VF.nat.TransientCaches, nn.Module):
                 fused = None
                 if (not torch.is_grad_enabled() and not (gated and sg.training and drop_a.p > 0)
                         and VF.FusedAttnScores.supported(X2, lin_a.in_features, lin_a.out_features)):
-                    # inference on a large bf16 bag: scores and pooling in ONE launch (vlsa_gated_scores_pool_batch), X read once
+                    # inference on a large bf16 bag: scores and pooling in ONE launch (vlsa_gated_scores_pool / _adapter)
                     if not hasattr(self, "_fused_scores"):
                         self._fused_scores = VF.FusedAttnScores()
                     w = (lin_a.weight, lin_a.bias, lin_g.weight if gated else None, lin_g.bias if gated else None, lin_o.weight, lin_o.bias)
