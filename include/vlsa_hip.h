@@ -557,12 +557,14 @@ typedef struct vlsa_tt_rows {
 size_t vlsa_tt_packed_bytes(const vlsa_tt_model* model, int with_backward);
 int vlsa_tt_pack_weights(const vlsa_tt_model* model, void* packed, int with_backward, void* stream);
 size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* model, const vlsa_tt_rows* rows, int save_for_backward);
-/* With VLSA_TT_PERSIST=1 in the environment, CONCH-size towers with <= 112 compact rows run the 12 blocks of vlsa_tt_forward as
+/* With VLSA_TT_PERSISTENT or-ed into `save_for_backward` (the library reads no environment; the Python mirror sets the bit when its
+ * caller asks for it), CONCH-size towers with <= 112 compact rows run the 12 blocks of vlsa_tt_forward as
  * ONE persistent launch whose stages hand their activations over through in-kernel counters (text_tower.hip:
  * k_tt_forward_persistent; measured slower than the default launch-per-stage path on MI355X, hence opt-in).  Every wait in it is bounded; a time-out (a workgroup that never became resident because a foreign kernel held its
  * CU) is reported in four 32-bit words of the workspace: {code != 0, stage, workgroup, counter value} at this byte offset
  * (-1: this model / row plan takes the launch-per-stage path, which has no in-kernel waits).  The results of a launch whose
  * code is non-zero are void: the caller reads the words back (asynchronously is fine) and must not use them. */
+#define VLSA_TT_PERSISTENT 0x100
 int64_t vlsa_tt_status_offset(const vlsa_tt_model* model, const vlsa_tt_rows* rows, int save_for_backward);
 int vlsa_tt_forward(const vlsa_tt_model* model, const vlsa_tt_rows* rows, const void* packed, const float* emb,
                     int64_t emb_seq_stride, int64_t emb_tok_stride, void* workspace, int save_for_backward, float* out,

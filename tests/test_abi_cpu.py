@@ -48,7 +48,7 @@ def test_host_side_queries_need_no_gpu():
     # the tiles of 256 walkers cover the bag with heights of 16 .. 256 rows whose per-walker sums differ by at most one 16-row unit
     rows, mn = ctypes.c_int(0), ctypes.c_int64(0)
     assert lib.vlsa_gated_scores_big_tile(_native.DT_BF16, 1, ctypes.addressof(rows), ctypes.addressof(mn)) == 0
-    assert rows.value in (0, 256) and (rows.value == 0 or mn.value >= 1)       # (0: switched off through VLSA_GS_TILE=0)
+    assert rows.value in (0, 256) and (rows.value == 0 or mn.value >= 1)       # (0: switched off in a -DVLSA_EXPERIMENT build)
     assert lib.vlsa_gated_scores_big_tile(_native.DT_F32, 1, ctypes.addressof(rows), ctypes.addressof(mn)) == 0 and rows.value == 0
     assert lib.vlsa_gated_scores_pool_ws_floats(0) == 0
     for N in (1, 31, 32, 33, 8191, 8192, 8193, 16384, 50_000, 65_536, 65_537, 393_216, 400_000, 4_000_000):
@@ -60,6 +60,24 @@ def test_host_side_queries_need_no_gpu():
         assert ws >= 514 * -(-N // hi), (N, ws, hi)                  # one (m, l, acc[512]) record per tile of the bf16 route
         assert ws >= 544 * lib.vlsa_pool_num_partials(N) + 32        # (pm, pl, pacc) + (m2, l) of the chained fp32 route
         assert ws <= max(514 * min(-(-N // lo), rounds * 256), 544 * lib.vlsa_pool_num_partials(N) + 64)
+
+
+def test_default_build_reads_no_environment():
+    """SURVEY.md 8(b) / include/vlsa_hip.h: "no global state".  The A/B switches of the measurement tools (VLSA_GS_*, VLSA_TT_*,
+    VLSA_MAX_PARTIALS, VLSA_EXP ...) exist only in a -DVLSA_EXPERIMENT build: the default library neither imports getenv nor carries
+    any of their names."""
+    import subprocess
+    from vlsa_amd import build
+    if os.environ.get("VLSA_EXTRA_HIPCC_FLAGS") or os.environ.get("VLSA_HIP_LIB"):
+        pytest.skip("not the default build")
+    lib = build.build_native()
+    blob = open(lib, "rb").read()
+    assert b"getenv" not in blob
+    names = sorted(set(re.findall(rb"VLSA_[A-Z0-9_]{2,}", blob)))
+    assert names == [], names
+    nm = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout
 
 
 def test_cpu_tensor_is_refused_loudly():

@@ -212,20 +212,3 @@ def test_scores_pooling_and_adapter_head_other_widths_and_large_bags(R):
         assert (logit.double().reshape(-1) - want).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("gated", [True, False])
-@pytest.mark.parametrize("N", [16384, 16385, 33000, 100003])
-def test_whole_row_kernel_matches_the_oracle(N, gated, monkeypatch):
-    """k_gated_scores_rows (opt-in through VLSA_GS_ROWSK: persistent 128-row tiles, the bag's rows staged as whole rows in LDS --
-    built in round 4, measured no faster than k_gated_scores, profiles/r04_kbench_gated_rows.txt): same scores, 1e-4."""
-    from vlsa_amd import functional as F
-    dev = torch.device("cuda", 0)
-    X = cases.make_bag(N, 5200 + N, "clustered" if N % 2 else "iid").to(torch.bfloat16)
-    W = _weights(5300 + N, gated, scale=3.0)
-    Wd = [None if t is None else t.to(dev) for t in W]
-    fs = F.FusedAttnScores()
-    monkeypatch.setenv("VLSA_GS_ROWSK", "16384")
-    a = fs(X.to(dev), *Wd)
-    monkeypatch.setenv("VLSA_GS_ROWSK", "0")
-    b = fs(X.to(dev), *Wd)
-    assert (a.cpu() - _ref(X, *W)).abs().max().item() < TOL
-    assert (a - b).abs().max().item() < 5e-5 and not torch.equal(a, b)      # (two kernels: different summation orders)

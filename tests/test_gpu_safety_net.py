@@ -191,3 +191,18 @@ def test_resident_rows_modified_in_place_are_reported():
     x.mul_(2.0)                                                                # the handler would be corrupting the resident bag
     with pytest.raises(RuntimeError, match="IN PLACE"):
         rb[0]
+
+
+def test_in_place_write_before_a_later_lazy_upload_is_still_reported():
+    """the first epoch uploads lazily -- item 1 goes into the SAME arena segment after item 0's view was written in place; the
+    snapshot of the arena's own version must advance by the upload's bumps only, not absorb the user's write."""
+    from vlsa_amd.ingest import ResidentBags
+    rb = ResidentBags(_Items([300, 200]), dtype=torch.float32)
+    x = _item(rb, 0)
+    x.add_(1.0)                                                                # in place, BEFORE item 1 was ever read
+    try:
+        _item(rb, 1)                                                           # its upload must not launder the write ...
+    except RuntimeError as e:                                                  # (same segment: reported right here)
+        assert "IN PLACE" in str(e)
+    with pytest.raises(RuntimeError, match="IN PLACE"):
+        rb[0]                                                                  # ... whichever segment item 1 went to

@@ -151,3 +151,42 @@ def test_deepcopy_and_pickle_drop_the_native_caches():
     e2 = copy.deepcopy(enc)
     assert e2._cm is None and "_cm_arr" not in e2.__dict__ and "_tt_cache" not in e2.__dict__
     assert set(e2.state_dict()) == set(enc.state_dict())
+
+
+def test_unpickled_model_in_a_fresh_process_still_sees_a_reassigned_parameter(tmp_path):
+    """a VLSA unpickled in a fresh process never runs ``_assemble``; the structure hooks are then installed lazily by the
+    first key, so a re-assigned learner parameter changes the key (and the text features are recomputed)."""
+    import os
+    import subprocess
+    import sys
+    model, tower, learner = _model()
+    path = tmp_path / "model.pt"
+    torch.save(model, path)
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = f"""
+import sys
+sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})
+import torch, torch.nn as nn
+import test_text_cache_cpu as T          # the pickled classes live here
+sys.modules.setdefault("tests.test_text_cache_cpu", T)
+from vlsa_amd import vlsa as V
+assert not V._HOOKS_INSTALLED[0]
+m = torch.load({str(path)!r}, weights_only=False)
+assert not V._HOOKS_INSTALLED[0]          # unpickling assembled nothing
+with torch.no_grad():
+    a = m.forward_text_only().clone()
+    k0 = m._provider_key()
+    assert V._HOOKS_INSTALLED[0]
+    calls = m.prompt_encoder.calls
+    m.forward_text_only()
+    assert m.prompt_encoder.calls == calls
+    m.prompt_learner.context_embeds = nn.Parameter(m.prompt_learner.context_embeds.detach() + 1.0)
+    k1 = m._provider_key()
+    assert k1 != k0
+    b = m.forward_text_only()
+    assert m.prompt_encoder.calls == calls + 1 and not torch.equal(a, b)
+print("ok")
+"""
+    env = dict(os.environ)
+    res = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr

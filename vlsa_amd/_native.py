@@ -19,6 +19,7 @@ DT_F32, DT_BF16 = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_MFMA, KERNEL_DMA = 0, 1, 2, 3
 POOL_MEAN, POOL_MAX, POOL_WEIGHT, POOL_GIVEN = 0, 1, 2, 3
 MAX_P, MAX_K, MAX_D = 16, 64, 1024
+TT_PERSISTENT = 0x100      # vlsa_tt_forward: or-ed into save_for_backward (VLSA_TT_PERSISTENT)
 P_STRIDE = 16
 
 

@@ -420,186 +420,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gated_scores(const void* __restr
 }
 
 
-// =================================================================================================================
-// Round 4: k_gated_scores_rows -- the same scores for LARGE bf16 bags with the bag's rows staged as WHOLE rows.
-//
-// Round 3 found k_gated_scores bound by its vector-memory path, not by the matrix pipe: a K step's X chunk is 64 bytes of every
-// row (16 rows x 64 B per load instruction: ~16 B/clk/CU), and a workgroup streams its 512 KB of weight fragments per 64-row tile
-// (8 KB of L2 -> L1 traffic per patch row).  Here:
-//   * a workgroup tile is 128 rows x 128 hidden units (of both branches): the weight stream per row halves;
-//   * X is read as WHOLE 512-byte row halves -- a wave load instruction covers 2 rows x 512 contiguous bytes -- through registers
-//     into LDS (plain loads: the compiler's vmcnt bookkeeping stays exact; LDS-DMA and register loads do not retire in one common
-//     order, see the header) and kept there for all K steps of the half: two K halves of the tile x 64 KB, double buffered, ONE
-//     barrier per 8 K steps instead of one per step;
-//   * the workgroups are persistent (one per CU: 132 KB of LDS): while a K half is consumed the next one -- the second half of this
-//     tile or the first half of the workgroup's next tile -- is loaded, two row pairs per K step during the first four steps;
-//     the weight ring (three steps ahead) runs across tile boundaries, the epilogue of a tile overlaps the loads of the next.
-//   * LDS image of a K half: row r at r x 512 B, its 16-byte chunk c at position c ^ (r & 15): the four lane groups of a
-//     ds_read_b128 A-fragment read ({rows 0-3, 12-15 | chunk g} + {rows 4-11 | chunk g + 1}, ...) then hit 16 different bank sets
-//     (two rows collide only if r1 ^ r2 == 1 across the two row sets of a group: impossible).
-// Arithmetic, weight packing (k_prepare_gated_weights), activations and dropout are those of k_gated_scores<.., RT = 8, HG = 1>:
-// 8 waves, wave w owns 16 hidden units of both branches for all 8 row tiles (64 accumulator registers), 32 MFMAs per K step.
-namespace gr {
-constexpr int kR = 128;                       // rows per workgroup tile
-constexpr int kHalf = kR * 512;               // bytes of one K half of a tile in LDS
-constexpr int kScr = 2 * kHalf;               // cross-wave scratch behind the two buffers: 8 waves x 128 floats
-constexpr int kLds = kScr + 8 * kR * 4;       // 135,168 B
-}  // namespace gr
-
-template <bool GATED>
-__global__ __launch_bounds__(512, 2) void k_gated_scores_rows(const void* __restrict__ Xv, long long N, long long ldx,
-                                                              const unsigned char* __restrict__ prep, float* __restrict__ a_out,
-                                                              int n_row_tiles, const GsBatch bt) {
-    using namespace gs;
-    constexpr int NF = GATED ? 4 : 2, NB = GATED ? 2 : 1, RT = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, i16 = lane & 15;
-    const GatedPrepLayout L(GATED ? 1 : 0);
-    const int G = gridDim.x;
-    // workgroup-tile v = (row tile, hidden half): v and v + 8 (same XCD under the round-robin dispatch) share the row tile, so the
-    // second read of its rows comes from that XCD's L2; G is a multiple of 16 (or every workgroup has one tile), hence a workgroup
-    // keeps its hidden half -- and its weight stream -- for all of its tiles
-    // (n_row_tiles is padded to a multiple of 8 by the host: tiles behind the bag's last row are empty)
-    const int nv = 2 * n_row_tiles;
-    auto half_of = [&](int v) { return (v >> 3) & 1; };
-    auto tile_of = [&](int v) { return ((v >> 4) << 3) + (v & 7); };
-    const int half = half_of(blockIdx.x);
-    const unsigned char* wp = prep + L.wpack + (size_t)(half * 8 + w) * kSteps * NF * 1024 + lane * 16;
-    const int h0 = 128 * half + 16 * w + i16;
-    const float bav = reinterpret_cast<const float*>(prep + L.ba)[h0];
-    const float bgv = GATED ? reinterpret_cast<const float*>(prep + L.bg)[h0] : 0.f;
-    const float w2v = reinterpret_cast<const float*>(prep + L.w2)[h0];
-    const float cv = reinterpret_cast<const float*>(prep + L.c)[0];
-
-    // the thread's share of a K half: 8 chunks of 16 B; chunk j -> row 16 j + 2 w + (lane >> 5), chunk lane & 31 of the half row
-    const int xrow = 2 * w + (lane >> 5), xc = lane & 31;
-    const int x_lds = xrow * 512 + ((xc ^ (xrow & 15)) << 4);           // + j * 16 rows = j * 8192 B  (the swizzle only sees r & 15)
-    struct Src { __amdgpu_buffer_rsrc_t rs; int voff; };
-    auto src_of = [&](int v) -> Src {       // buffer descriptor over the tile's rows (v >= nv: an empty one -- its loads return zeros without a request)
-        const int t = tile_of(v < nv ? v : 0);
-        const long long row0 = (long long)t * gr::kR;
-        const long long left = v < nv ? N - row0 : 0;
-        const int nrows = (int)(left < gr::kR ? (left > 0 ? left : 0) : gr::kR);
-        const unsigned long long xbase = reinterpret_cast<unsigned long long>(Xv) + (unsigned long long)row0 * ldx * 2ull;
-        Src r;
-        r.rs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>((static_cast<unsigned long long>((unsigned)__builtin_amdgcn_readfirstlane((int)(xbase >> 32))) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)xbase)),
-            0, __builtin_amdgcn_readfirstlane(nrows > 0 ? (int)(((long long)(nrows - 1) * ldx + kD) * 2) : 0), 0x00020000);
-        r.voff = (int)((long long)xrow * ldx * 2) + xc * 16;
-        return r;
-    };
-    const int row16_step = __builtin_amdgcn_readfirstlane((int)(16ll * ldx * 2));      // bytes between the thread's chunks j and j + 1
-    auto ldx16 = [&](const Src& sc, int j, int kh) {
-        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(sc.rs, sc.voff + j * row16_step, kh * 512, 0));
-    };
-
-    f32x4 acc[RT][NB];
-    bf16x8 B[4][NF];                        // weight ring: step s lives in B[s & 3], three steps ahead
-    bool abl_first = true;                  // (timing-only ablations, VLSA_GS_ABL: see the top of the file)
-    auto load_b = [&](int ks, bf16x8 (&dst)[NF]) {
-        if ((VLSA_GS_ABL & 2) && !abl_first) return;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const bf16x8*>(wp + (size_t)((ks & (kSteps - 1)) * NF + f) * 1024);
-    };
-    load_b(0, B[0]);
-    load_b(1, B[1]);
-    load_b(2, B[2]);
-    // prologue: the first K half of the first tile (the only loads nothing overlaps)
-    int v = blockIdx.x;
-    Src cur = src_of(v);
-    {
-        bf16x8 x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = ldx16(cur, j, 0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16x8_mag*>(smem + x_lds + j * 8192) = x[j];
-    }
-    __syncthreads();
-    float_mag* scr = reinterpret_cast<float_mag*>(smem + gr::kScr);
-
-    for (; v < nv; v += G) {
-        const Src nxt = src_of(v + G);
-        const int t = tile_of(v);
-        const long long row0 = (long long)t * gr::kR;
-        const int nrows = (int)((N - row0) < gr::kR ? (N - row0) : gr::kR);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const float bb = b == 0 ? bav : bgv;
-                acc[rt][b] = f32x4{bb, bb, bb, bb};
-            }
-#pragma unroll 1
-        for (int kh = 0; kh < 2; ++kh) {
-            // this phase reads buffer kh, and fills buffer kh ^ 1 with the phase after it: K half 1 of this tile, or K half 0 of the next
-            const unsigned char* rb = smem + kh * gr::kHalf;
-            unsigned char* wb = smem + (kh ^ 1) * gr::kHalf;
-            const Src ls = kh == 0 ? cur : nxt;
-            bf16x8 xq[4][2];                   // the next phase's rows: loaded in steps 0-3, published FOUR steps later (HBM latency ~ 2 K steps)
-            bf16x8 abl_a[(VLSA_GS_ABL & 1) ? RT : 1] = {};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ks = kh * 8 + i;
-                load_b(ks + 3, B[(i + 3) & 3]);        // (8 steps per half: the ring slot only depends on i)
-                if (i == 4) abl_first = false;
-                if (i >= 4 && !(VLSA_GS_ABL & 4)) {                  // the row pairs loaded four steps ago are published
-                    *reinterpret_cast<bf16x8_mag*>(wb + x_lds + (2 * (i - 4)) * 8192) = xq[i - 4][0];
-                    *reinterpret_cast<bf16x8_mag*>(wb + x_lds + (2 * (i - 4) + 1) * 8192) = xq[i - 4][1];
-                }
-                if (i < 4 && !(VLSA_GS_ABL & 4)) {                   // two row pairs of the next phase per step (literal i: no load sits behind a branch)
-                    xq[i][0] = ldx16(ls, 2 * i, kh ^ 1);
-                    xq[i][1] = ldx16(ls, 2 * i + 1, kh ^ 1);
-                }
-                const bf16x8 (&cb)[NF] = B[i & 3];
-                // all eight A fragments of the step in flight at once, then its 16 NB MFMAs (hi terms, then lo terms: MFMAs on one
-                // accumulator are 8 NB apart); the fence keeps the scheduler from hoisting LATER steps' reads (256 registers + spills)
-                bf16x8 A[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    if ((VLSA_GS_ABL & 1) && i > 0) { A[rt] = abl_a[rt]; continue; }
-                    A[rt] = *reinterpret_cast<const bf16x8_mag*>(rb + rt * 8192 + i16 * 512 + (((4 * i + g) ^ i16) << 4));
-                    if (VLSA_GS_ABL & 1) abl_a[rt] = A[rt];
-                }
-#pragma unroll
-                for (int term = 0; term < 2; ++term)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) acc[rt][b] = gs_mfma(A[rt], cb[2 * b + term], acc[rt][b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!(VLSA_GS_ABL & 8)) __syncthreads();                   // buffer kh ^ 1 is complete, nobody reads buffer kh any more
-        }
-        // ---- epilogue of the tile (the next tile's first K half is in LDS, its first weight fragments are in flight) -------
-        const unsigned int rid0 = bt.row_base + (unsigned int)row0;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float e = (VLSA_GS_ABL & 16) ? acc[rt][0][r] + acc[rt][NB - 1][r]
-                          : GATED ? gate_act(acc[rt][0][r], acc[rt][NB - 1][r]) : tanh_act(acc[rt][0][r]);
-                if (GATED && bt.drop_thr != 0u) {
-                    const unsigned int row = rid0 + 16 * rt + 4 * g + r, h = (unsigned int)h0;
-                    const bool ka = dropout_bits(bt.drop_seed, row, h) >= bt.drop_thr;
-                    const bool kg = dropout_bits(bt.drop_seed, row, h + 256u) >= bt.drop_thr;
-                    e = (ka && kg) ? e * bt.drop_scale * bt.drop_scale : 0.f;
-                }
-                const float s16 = row16_sum(e * w2v);
-                if (i16 == 0) scr[w * gr::kR + 16 * rt + 4 * g + r] = s16;
-            }
-        __syncthreads();
-        if (tid < nrows) {
-            float sum = half == 0 ? cv : 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) sum += scr[ww * gr::kR + tid];
-            atomicAdd(a_out + row0 + tid, sum);     // two addends per element on a zeroed array: order-independent
-        }
-        cur = nxt;
-    }
-}
+// (Round 4's whole-row variant k_gated_scores_rows -- 128 x 128 tiles, X staged as whole rows in LDS -- measured no faster than
+// k_gated_scores (profiles/r04_kbench_gated_rows.txt) and left the library in round 6: docs/LAB_NOTEBOOK.md, `git log -S k_gated_scores_rows`.)
 }  // namespace vlsa
 
 using namespace vlsa;
@@ -625,7 +447,7 @@ extern "C" int vlsa_prepare_gated_weights(const float* Wa, const float* ba, cons
 //            70k 44.3 / 41.7, 100k 53.2 / 55.5, 200k 101.6 / 99.6, 400k 191 / 189  -> 18 432 .. 65 536 rows (one round of its 256 walkers).
 // VLSA_GS_TILE = <rows>: from that many rows on, both modules; 0: never.
 static long long gs_tile_env() {
-    static const long long env = [] { const char* e = getenv("VLSA_GS_TILE"); return e ? atoll(e) : -1ll; }();
+    static const long long env = [] { const char* e = VLSA_ENV("VLSA_GS_TILE"); return e ? atoll(e) : -1ll; }();
     return env;
 }
 static bool gs_tile_use(bool gated, long long N) {
@@ -644,7 +466,7 @@ static long long gs_tile_min_rows_pooled() {
 }
 
 static bool gs_round64() {
-    static const bool on = [] { const char* e = getenv("VLSA_GS_R64"); return e && atoi(e) == 1; }();   // (A/B hook; off: +-2 us either way, tools/gs_rows.py)
+    static const bool on = [] { const char* e = VLSA_ENV("VLSA_GS_R64"); return e && atoi(e) == 1; }();   // (A/B hook; off: +-2 us either way, tools/gs_rows.py)
     return on;
 }
 
@@ -673,13 +495,13 @@ static bool gs_round64() {
 // 128-row x 128-unit workgroup tile needs 8 KB of X and 16 KB of weights per 512 MFMA cycles and wave.
 struct GsTiling { int max_rows, round_tiles; bool four_waves; int halves; };
 static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
-    static const int shape = [] { const char* e = getenv("VLSA_GS_HG2"); return e ? atoi(e) : -1; }();   // (A/B hook: 0 / 1 / 2)
+    static const int shape = [] { const char* e = VLSA_ENV("VLSA_GS_HG2"); return e ? atoi(e) : -1; }();   // (A/B hook: 0 / 1 / 2)
     if (!f32 && !gated && shape != 0) {
         const bool all_hidden = shape == 2 || (shape < 0 && n_hint > 32768 && n_hint <= 65536);
         if (all_hidden) return {128, 512, true, 1};
         return {128, 256, true, 2};
     }
-    static const bool g4 = [] { const char* e = getenv("VLSA_GS_G4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    static const bool g4 = [] { const char* e = VLSA_ENV("VLSA_GS_G4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     // gated, bf16: four waves x 64 rows x 128 hidden units of both branches (HG = 2): 154 registers -> three workgroups per CU, as
     // for the ungated module (it took the leaner buffer loads to get under 168 registers; with 182 the shape lost, 447 vs 418 us).
     // 400k patches 429 -> 379 us, 50k 63.8 -> 56.8, 24 576 33.4 -> 30.0 (same box).  A workgroup streams its 512 KB of weights
@@ -687,7 +509,7 @@ static GsTiling gs_tiling(bool f32, bool gated, int64_t n_hint) {
     // "round" reported to the batch caller is 64 tiles for that reason.
     if (!f32 && gated && g4) return {64, 64, true, 2};
     // fp32 bags: the same two shapes (LDS images of RT KB; 164 registers): ungated 50k patches 62.4 -> 52.0 us, gated 105.7 -> 81.5
-    static const bool f4 = [] { const char* e = getenv("VLSA_GS_F4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    static const bool f4 = [] { const char* e = VLSA_ENV("VLSA_GS_F4"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     if (f32 && !gated && f4) return {128, 256, true, 2};
     if (f32 && gated && f4) return {64, 64, true, 2};
     return {(f32 && gated) ? 128 : gs::kRows, 128, false, 2};
@@ -750,30 +572,6 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
         dropb.drop_seed = seed;
         dropb.drop_scale = 1.f / (1.f - drop_p);
     }
-    // The whole-row kernel (k_gated_scores_rows) is OPT-IN: VLSA_GS_ROWSK = n sends bf16 bags of >= n rows through it.  Measured
-    // (profiles/r04_kbench_gated_rows.txt, same box): gated 400k patches 378 vs 386 us, 50k 62.7 vs 56.8; ungated 241 vs 190 / 41.8 vs
-    // 32.2 -- no better than k_gated_scores.  Its timing-only ablations say why: the parts are ADDITIVE (no A reads - 22 us, no weight
-    // loads - 33, no X loads - 66, no barriers - 17, no activations - 48, of 377 us; everything but the MFMAs: 248 us; MFMAs alone: 195):
-    // a wave's stream of loads, LDS traffic, VALU and MFMAs is serial, two waves per SIMD overlap little of it, and the whole-row X
-    // path, although 4x cheaper per byte, is not what was holding the matrix pipe back.
-    {
-        const char* e_rows = getenv("VLSA_GS_ROWSK");
-        const long long min_rows = e_rows ? atoll(e_rows) : 0ll;
-        if (!f32 && min_rows > 0 && N >= min_rows && 16ll * ldx * 2 < (1ll << 31)) {
-            static DeviceOnce once;
-            if (once.first()) {
-                (void)hipFuncSetAttribute((const void*)k_gated_scores_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gr::kLds);
-                (void)hipFuncSetAttribute((const void*)k_gated_scores_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gr::kLds);
-            }
-            if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
-            const int n_row_tiles = (int)(((N + gr::kR - 1) / gr::kR + 7) / 8 * 8);      // whole groups of 8 row tiles x 2 halves
-            const int nv = 2 * n_row_tiles;
-            const unsigned int grid = (unsigned int)(nv < 256 ? nv : 256);
-            if (gated) hipLaunchKernelGGL((k_gated_scores_rows<true>), dim3(grid), dim3(512), gr::kLds, st, X, (long long)N, (long long)ldx, pp, a, n_row_tiles, dropb);
-            else hipLaunchKernelGGL((k_gated_scores_rows<false>), dim3(grid), dim3(512), gr::kLds, st, X, (long long)N, (long long)ldx, pp, a, n_row_tiles, dropb);
-            return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
-        }
-    }
     // round 5: large bf16 bags take the LDS-DMA tile kernel (gated_scores_tile.hip)
     if (!f32 && gs_tile_use(gated != 0, (long long)N) && 256ll * ldx * 2 < (1ll << 31)) {
         // the ungated module's tiles are whole (one workgroup per row tile stores its scores): nothing to zero
@@ -782,7 +580,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
     }
     if (hipMemsetAsync(a, 0, (size_t)N * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     const int64_t round_rows = round_tiles * (int64_t)max_rows;
-    static const bool split = [] { const char* e = getenv("VLSA_GS_SPLIT"); return !(e && atoi(e) == 0); }();   // (A/B hook)
+    static const bool split = [] { const char* e = VLSA_ENV("VLSA_GS_SPLIT"); return !(e && atoi(e) == 0); }();   // (A/B hook)
     int64_t seg_rows[2] = {N, 0};
     // (four-wave workgroups: three fit a CU and run out of step with each other, a partly filled last round costs little and a
     // second launch more -- 50k patches: 37.8 us as one launch of 128-row tiles, 41.5 split; tools/gs_rows_sweep.py)
@@ -802,7 +600,7 @@ static int gated_scores_impl(const void* X, int x_dtype, int64_t N, int64_t ldx,
             if (rows_per_tile > 64 && gs_round64()) rows_per_tile = (rows_per_tile + 63) / 64 * 64;
             if (rows_per_tile > max_rows) rows_per_tile = max_rows;
         }
-        if (const char* e = getenv("VLSA_GS_ROWS")) {          // experiment hook (tools/gs_rows.py): force the tile height
+        if (const char* e = VLSA_ENV("VLSA_GS_ROWS")) {          // experiment hook (tools/gs_rows.py): force the tile height
             const int v = atoi(e);
             if (v >= 16 && v <= max_rows && v % 16 == 0) rows_per_tile = v;
         }

@@ -1446,7 +1446,7 @@ inline Scratch scratch_of(float* p, const Shape& s) {
 
 #ifdef VLSA_TT_DEBUG
 static int tt_debug_bits_all() {
-    const char* e = getenv("VLSA_TT_DEBUG_ALL");
+    const char* e = VLSA_ENV("VLSA_TT_DEBUG_ALL");
     return e ? (atoi(e) << 8) : 0;
 }
 #endif
@@ -1533,7 +1533,7 @@ void launch_ln_bwd(const float* da, const float* x, const float* gamma, const fl
 
 // threads of an attention workgroup: a wave per row of the prompt (up to 16 waves); VLSA_TT_ATTN_THREADS overrides (A/B hook)
 int attn_threads(int max_len) {
-    if (const char* e = getenv("VLSA_TT_ATTN_THREADS")) {
+    if (const char* e = VLSA_ENV("VLSA_TT_ATTN_THREADS")) {
         const int v = atoi(e);
         if (v >= 64 && v <= 1024 && v % 64 == 0) return v;
     }
@@ -1542,14 +1542,13 @@ int attn_threads(int max_len) {
 }
 
 // ---- persistent forward: when it applies, and its launch --------------------------------------------------------
-bool persist_supported(const Shape& s, const vlsa_tt_rows* r) {
-    // OPT-IN (VLSA_TT_PERSIST=1; read per call: tests and benches flip it inside one process).  Measured on MI355X, K = 12 rank prompts
-    // (profiles/r04_bench_text_persist.txt, r04_tt_persist_stamps.txt): 836-872 us against 616 us for the launch-per-stage path -- a
-    // stage's in-kernel hand-off (drain of the write-through stores + counter + poll + first round of sc1 loads, ~3.5 us) costs MORE
-    // than the ~3.2 us kernel boundary it replaces, and the 4-byte sc1 epilogue stores are 2x slower than plain ones; the weight
-    // prefetch it buys (task bodies 5.8 vs 8.5 us for QKV) does not make up for it.  Kept, tested and off by default.
-    const char* e = getenv("VLSA_TT_PERSIST");
-    if (!e || atoi(e) == 0) return false;
+bool persist_supported(const Shape& s, const vlsa_tt_rows* r, int flags) {
+    // OPT-IN per call (VLSA_TT_PERSISTENT or-ed into save_for_backward; the library itself reads no environment).  Measured on MI355X,
+    // K = 12 rank prompts (profiles/r04_bench_text_persist.txt, r04_tt_persist_stamps.txt): 836-872 us against 616 us for the
+    // launch-per-stage path -- a stage's in-kernel hand-off (drain of the write-through stores + counter + poll + first round of sc1
+    // loads, ~3.5 us) costs MORE than the ~3.2 us kernel boundary it replaces, and the 4-byte sc1 epilogue stores are 2x slower than
+    // plain ones; the weight prefetch it buys (task bodies 5.8 vs 8.5 us for QKV) does not make up for it.  Kept, tested, off by default.
+    if (!(flags & VLSA_TT_PERSISTENT)) return false;
     const int RT = (s.M + 15) / 16;       // 7 row tiles x 36 QKV column tiles = 252 workgroups: one round of the CUs
     return s.d == 768 && s.heads == 12 && s.layers <= kPMaxLayers && RT <= 7 && RT * 16 <= s.M_pad && r->max_len <= kPAttnMaxS
            && (s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads <= 256;
@@ -1579,7 +1578,7 @@ extern "C" int vlsa_tt_debug_stamps(long long* host) {
 }
 #include <cstdlib>
 static int tt_debug_bits() {
-    const char* e = getenv("VLSA_TT_DEBUG_BITS");
+    const char* e = VLSA_ENV("VLSA_TT_DEBUG_BITS");
     return e ? (atoi(e) << 8) : 0;
 }
 #define TT_DBG_BITS tt_debug_bits()
@@ -1625,6 +1624,7 @@ extern "C" int vlsa_tt_pack_weights(const vlsa_tt_model* m, void* packed, int wi
 }
 
 extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_rows* r, int save_for_backward) {
+    save_for_backward &= 0xff;
     Shape s;
     if (!r || !shape_of(m, r, s)) return 0;
     const size_t regions = save_for_backward ? (size_t)s.layers : 1;
@@ -1634,7 +1634,9 @@ extern "C" size_t vlsa_tt_workspace_bytes(const vlsa_tt_model* m, const vlsa_tt_
 extern "C" int64_t vlsa_tt_status_offset(const vlsa_tt_model* m, const vlsa_tt_rows* r, int save_for_backward) {
     Shape s;
     if (!r || !shape_of(m, r, s)) return -1;
-    if (save_for_backward == 2 || !persist_supported(s, r)) return -1;         // the launch-per-stage path has no in-kernel waits
+    const int flags = save_for_backward;
+    save_for_backward &= 0xff;
+    if (save_for_backward == 2 || !persist_supported(s, r, flags)) return -1;         // the launch-per-stage path has no in-kernel waits
     const size_t nreg = save_for_backward ? (size_t)s.layers : 1;
     float* base = nullptr;
     const Scratch c = scratch_of(base + nreg * layer_floats(s), s);
@@ -1647,6 +1649,8 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     Shape s;
     if (!r || !shape_of(m, r, s)) return VLSA_EINVAL;
     if (!packed || !emb || !workspace || !out) return VLSA_EINVAL;
+    const int tt_flags = save_for_backward;
+    save_for_backward &= 0xff;
     hipStream_t st = (hipStream_t)stream;
     const int d = s.d, Mp = s.M_pad;
     float* ws = static_cast<float*>(workspace);
@@ -1660,13 +1664,13 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
                        r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
     TT_LAUNCHED();
     const bool keep_attn = save_for_backward == 2;          // a training tower: the attention output of every block stays
-    const bool persist = !keep_attn && persist_supported(s, r);
+    const bool persist = !keep_attn && persist_supported(s, r, tt_flags);
     if (persist) {
         PArgs a{};
         a.ws = ws; a.wset = wset;
         a.x_final = c.x_final; a.xin_t = c.xin_t; a.xmid_t = c.xmid_t; a.attn_t = c.attn_t; a.hact_t = c.hact_t; a.qkv_alt = c.qkv_alt;
         a.ctr = c.pctr; a.status = c.pctr + kPCtrWords;
-        if (const char* e = getenv("VLSA_TT_STAMPS")) {      // measurement aid (tools/tt_persist_stamps.py): stamps behind the status words
+        if (const char* e = VLSA_ENV("VLSA_TT_STAMPS")) {      // measurement aid (tools/tt_persist_stamps.py): stamps behind the status words
             a.stamps = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(c.pctr + kPCtrWords + 8) + 7) & ~(uintptr_t)7);
             a.stamp_wg = atoi(e);
         }

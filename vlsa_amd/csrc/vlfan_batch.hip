@@ -864,7 +864,7 @@ extern "C" int vlsa_vlfan_partial_batch_scores(const void* bag_desc, int B, int 
     }
     const __bf16* qsplit = reinterpret_cast<const __bf16*>(static_cast<const unsigned char*>(qprep) + L.qsplit);
 #ifdef VLSA_TIMING
-    static const int xm = getenv("VLSA_EXP") ? atoi(getenv("VLSA_EXP")) : 0;
+    static const int xm = VLSA_ENV("VLSA_EXP") ? atoi(VLSA_ENV("VLSA_EXP")) : 0;
 #else
     constexpr int xm = 0;
 #endif

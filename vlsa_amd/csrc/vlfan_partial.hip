@@ -421,7 +421,7 @@ using namespace vlsa;
 
 static int g_max_partials() {
     static int v = [] {
-        const char* e = getenv("VLSA_MAX_PARTIALS");
+        const char* e = VLSA_ENV("VLSA_MAX_PARTIALS");
         int x = e ? atoi(e) : 0;
         return x > 0 ? x : 256;  // one workgroup per CU on MI355X (256 CUs)
     }();

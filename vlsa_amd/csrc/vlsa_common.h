@@ -6,6 +6,16 @@
 
 #include "../../include/vlsa_hip.h"
 
+// Experiment switches.  The shipped library reads NO process environment (no global state): every A/B hook of the
+// measurement tools goes through VLSA_ENV, which is getenv only in a -DVLSA_EXPERIMENT build (tools/*: VLSA_EXTRA_HIPCC_FLAGS) and a
+// null pointer -- the hook's name does not even reach the binary -- otherwise.  tests/test_abi_cpu.py greps the default build.
+#ifdef VLSA_EXPERIMENT
+#include <cstdlib>
+#define VLSA_ENV(name) getenv(name)
+#else
+#define VLSA_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 // wave priority of the short tail / preparation kernels that co-run with a persistent streaming kernel
 #ifndef VLSA_TAIL_PRIO
 #define VLSA_TAIL_PRIO 3

@@ -68,11 +68,15 @@ __global__ __launch_bounds__(1024) void k_xchg_put(XchgPut a, unsigned int epoch
         bool ok = true;
         if (a.gate[d] != nullptr) ok = spin_until(a.gate[d], gate_epoch, timeout_ticks);
         if (!ok) atomicOr(status, 1u);
-        s_ok = 1;  // on a time-out the transfer still goes out (the status word voids the run; nothing may hang behind us)
+        // On a gate time-out NOTHING goes out: the owner may not have consumed the previous epoch yet, and overwriting its inbox /
+        // result box would make IT broadcast a garbage merge with a clean status word.  No copy and no flag: the peer's own
+        // wait on that flag then times out too (bounded), so every rank that could have read stale records carries a non-zero status,
+        // and the host side (ShardedVlfanBatchPlan.finish) reduces the status words over the control group before anyone uses a result.
+        s_ok = ok ? 1 : 0;
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
-    (void)s_ok;
+    if (!s_ok) return;
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.src[d]);
     f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(a.dst[d]);
     const unsigned int n = a.n16[d];

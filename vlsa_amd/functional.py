@@ -545,7 +545,7 @@ class VlfanInferencePlan:
         buffers (a caller that must hand out fresh tensors per bag saves three copy kernels)."""
         lib, s, k = self.lib, _stream(), self._c
         reuse = params_key is not None and params_key == getattr(self, "_params_key", None)
-        self._params_key = params_key
+        self._params_key = None          # set again once the call that prepares this key has returned OK (ADVICE r5)
         if outs:
             k = dict(k)
             for name, t in outs.items():
@@ -561,6 +561,7 @@ class VlfanInferencePlan:
                                              self.kernel, k["qprep"], k["That"], k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G,
                                              k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"], k["v"], k["vhat"],
                                              k["vnorm"], k["logits"], k["incidence"], s), "vlsa_vlfan_forward_bag")
+        self._params_key = params_key
         if query_pool_module is not None:   # (gated-)attention pooling over the P rows, then the head on the pooled row
             pooled, self.pool_scores = query_pool_attention(self.out[None], query_pool_module)
             nat.check(lib.vlsa_head_forward(_p(pooled), 1, self.D, nat.POOL_GIVEN, None, None if self.identity_head else _p(W),
@@ -1057,6 +1058,7 @@ class FusedAttnScores:
 
     def __init__(self):
         self._key, self._prep = None, None
+        self._pool_ws = {}        # (device, stream) -> tile workspace of scores_and_pool (scratch, never returned)
 
     @staticmethod
     def supported(X2: torch.Tensor, dim_in: int, dim_hid: int) -> bool:
@@ -1184,17 +1186,27 @@ class FusedAttnScores:
             if len(_POOL_WS) > 4096:
                 _POOL_WS.clear()
             nws = _POOL_WS[N] = lib.vlsa_gated_scores_pool_ws_floats(N)
-        Na = (N + 63) & ~63                              # (the parts behind the scores stay 256-B aligned)
+        # What the caller may keep alive (pooled / logit views end up as DeepMIL's outputs, the scores as its attention) must not pin the
+        # tile workspace (~0.35 MB per bag: an evaluation loop that keeps features on the GPU grew by 0.5 MB per slide):
+        # scores and the 512-float outputs are their own small tensors, the workspace is scratch of this object, one per (device, stream)
+        # -- launches of one stream are ordered, so the next call may overwrite it.
+        dev = X2.device
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        R = 0 if adapter is None else adapter[0].shape[0]
+        ws = self._pool_ws.get(key)
+        if ws is None or ws.numel() < nws + R:
+            if len(self._pool_ws) > 16:
+                self._pool_ws.clear()
+            ws = self._pool_ws[key] = torch.empty(max(nws + R, 1 << 16), dtype=torch.float32, device=dev)
+        a = torch.empty(N, dtype=torch.float32, device=dev)
         if adapter is None:
-            buf = torch.empty(Na + 512 + nws, dtype=torch.float32, device=X2.device)     # ONE allocation: scores | pooled | workspace
-            a, pooled, ws = buf[:N], buf[Na:Na + 512].view(1, 512), buf[Na + 512:]
+            pooled = torch.empty(1, 512, dtype=torch.float32, device=dev)
             nat.check(lib.vlsa_gated_scores_pool(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a), _p(ws),
                                                  _p(pooled), _stream()), "vlsa_gated_scores_pool")
             return pooled, a
         W1, W2, keep = adapter                           # DeepMIL's Adapter head behind the pooling, same host call
-        R = W1.shape[0]
-        buf = torch.empty(Na + 1024 + nws + R, dtype=torch.float32, device=X2.device)    # scores | pooled | logit | workspace
-        a, pooled, logit, ws = buf[:N], buf[Na:Na + 512].view(1, 512), buf[Na + 512:Na + 1024].view(1, 512), buf[Na + 1024:]
+        out = torch.empty(2, 1, 512, dtype=torch.float32, device=dev)                    # pooled | logit
+        pooled, logit = out[0], out[1]
         nat.check(lib.vlsa_gated_scores_pool_adapter(_p(X2), _dt(X2), N, X2.stride(0), X2.shape[1], _p(prep), int(Wg is not None), _p(a),
                                                      _p(ws), _p(pooled), _p(_f32c(W1)), R, _p(_f32c(W2)), float(keep), _p(logit), _stream()),
                   "vlsa_gated_scores_pool_adapter")
@@ -1617,8 +1629,8 @@ class VlfanBatchPlan:
         (an evaluation loop prepares once, not once per launch; outs['That'] is then filled by a copy of the plan's)."""
         lib, s, c, k = self.lib, _stream(), nat.check, self._c
         reuse = params_key is not None and params_key == getattr(self, "_params_key", None)
-        self._params_key = params_key
-        own_That = None
+        self._params_key = None          # set again below, once the preparation of THIS key has been enqueued (ADVICE r5: a failed
+        own_That = None                  # prepare call followed by a retry with the same key must not reuse a stale block)
         if outs:
             k = dict(k)
             for name, t in outs.items():
@@ -1630,6 +1642,7 @@ class VlfanBatchPlan:
         if not reuse:
             c(lib.vlsa_prepare_queries_and_text(_p(Q), nq, self.D, int(self.gated), self.scale, k["qprep"], _p(T), self.K,
                                                 k["That"], k["tnorm"], s), "prepare_queries_and_text")
+        self._params_key = params_key
         if own_That is not None:
             own_That.copy_(self.That)
         ad = _p(self.attn.desc) if self.want_attn else None

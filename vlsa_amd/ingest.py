@@ -150,6 +150,7 @@ class DeviceBagArena:
                 raise ValueError(f"slides must be host float tensors [n, {self.D}]")
         total = sum(t.shape[0] for t in slides)
         row = self.layout.reserve(key, total)
+        v_before = self.data._version               # only the arena's OWN bumps move `clean_version` (below)
         prev = torch.get_num_threads()
         if prev > self.host_threads > 0:
             torch.set_num_threads(self.host_threads)
@@ -165,7 +166,10 @@ class DeviceBagArena:
         ev = torch.cuda.Event()
         ev.record(self._stream)
         self._ready[key] = ev
-        self.clean_version = self.data._version     # the arena's in-place version after ITS OWN last write (see `modified_in_place`)
+        # the arena's in-place version after ITS OWN writes (see `modified_in_place`): advanced by this upload's bumps only -- a
+        # user's in-place write to a resident view BEFORE a later (lazy, first-epoch) upload into the same segment must not be
+        # absorbed into the snapshot
+        self.clean_version = getattr(self, "clean_version", v_before) + (self.data._version - v_before)
         return self._view(key)
 
     def modified_in_place(self) -> bool:

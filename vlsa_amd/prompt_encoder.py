@@ -15,6 +15,7 @@ embeddings of the prompt learner); the tower itself is frozen in every shipped c
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -180,10 +181,13 @@ class _TextTowerFn(torch.autograd.Function):
         s = ctypes.c_void_p(torch.cuda.current_stream(emb.device).cuda_stream)
         packed = enc._packed_weights(emb.device, with_backward=bool(save))
         plan.check_status()                  # a time-out of an EARLIER persistent launch (see below) surfaces here at the latest
+        # opt-in persistent forward: asked for per call through a flag bit -- the switch lives HERE (VLSA_TT_PERSIST=1, read per call:
+        # tests and benches flip it inside one process); libvlsa_hip.so reads no environment
+        flags = save | (nat.TT_PERSISTENT if os.environ.get("VLSA_TT_PERSIST", "0") not in ("", "0") else 0)
         nat.check(lib.vlsa_tt_forward(ctypes.byref(model), ctypes.byref(plan.c), ctypes.c_void_p(packed.data_ptr()),
-                                      ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), save,
+                                      ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), ctypes.c_void_p(ws.data_ptr()), flags,
                                       ctypes.c_void_p(out.data_ptr()), s), "vlsa_tt_forward")
-        off = lib.vlsa_tt_status_offset(ctypes.byref(model), ctypes.byref(plan.c), save)
+        off = lib.vlsa_tt_status_offset(ctypes.byref(model), ctypes.byref(plan.c), flags)
         if off >= 0:
             # the persistent launch reports a timed-out wait in its workspace: read the four words back WITHOUT stalling the
             # caller (pinned buffer + event) and look at them once the copy has landed -- here at the next call, in backward,

@@ -254,17 +254,25 @@ class PeerBuffers:
     def resbox(self, o: int, slot: int, owner: int) -> int:
         return self.base[o] + self.FLAG_BYTES + 4 * (2 * self.inbox_floats(o) + (slot * self.world + owner) * self.F)
 
-    def close(self):
+    def close_peers(self):
+        """unmap the OTHER ranks' buffers (local, safe at any time: this rank stops writing into them)"""
         for q in self._opened:
             self.lib.vlsa_xchg_close(ctypes.c_void_p(q))
         self._opened = []
+
+    def close(self):
+        """unmap the peers AND free this rank's exported buffer.  The caller must have made sure that no peer still writes into it:
+        ``ShardedVlfanBatchPlan.close`` (device sync + barrier) is the collective way to get here."""
+        self.close_peers()
         if self.own:
             self.lib.vlsa_xchg_free(ctypes.c_void_p(self.own))
             self.own = 0
 
     def __del__(self):
+        # Garbage collection is not a collective: peers may still be writing into this rank's exported buffer, so only the peer
+        # mappings go here; the buffer itself is released by close() or with the process (ADVICE r5).
         try:
-            self.close()
+            self.close_peers()
         except Exception:
             pass
 
@@ -378,8 +386,21 @@ class ShardedVlfanBatchPlan:
                 "what": f"records to their owners ({rec_out} B out / {rec_in} B in) + packed results of {self.nmax} bags per owner ({res} B each way)"}
 
     def status(self) -> int:
-        """time-out bits of the "ipc" exchange's flag waits (0 = every wait was served; syncs the stream)"""
+        """time-out bits of THIS rank's flag waits of the "ipc" exchange (0 = every wait was served; syncs the stream)"""
         return int(self.status_word.item()) if self.exchange != "allgather" else 0
+
+    def status_all(self) -> int:
+        """COLLECTIVE: the OR of every rank's time-out bits.  A sender whose gate timed out sends nothing (csrc/xchg.hip), so the owner
+        of those bags times out in turn and its merge is void -- but a third rank that only RECEIVES that owner's results has a clean
+        word of its own.  Results of a launch may be used once this is 0 on every rank (`finish(check=True)` raises otherwise)."""
+        if self.exchange != "ipc" or self.world == 1:
+            return self.status()
+        t = torch.tensor([self.status()], dtype=torch.int32)
+        ctl = self.group
+        if self.dist.get_backend(ctl) == "nccl":
+            t = t.to(self.status_word.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=ctl)      # (bits: MAX of small masks loses which bit, not whether)
+        return int(t.item())
 
     def _set_groups(self, groups):
         P, D, rf = self.P, self.D, self.rf
@@ -557,9 +578,16 @@ class ShardedVlfanBatchPlan:
         self._tail(slot, epoch, T, ls, W, b, pw, ab)
         self._pending = None
 
-    def finish(self):
+    def finish(self, check: bool = False):
+        """logits of the last launch.  ``check=True`` (COLLECTIVE, syncs): raise unless every rank's flag waits were served -- what a
+        caller outside a timed region should use; the throughput loops check once after their last step (bench.py)."""
         if self._pending is not None:
             self._drain()
+        if check:
+            st = self.status_all()
+            if st != 0:
+                raise VlsaNativeError(f"sharded exchange: a flag wait timed out on some rank (status bits up to {st}); the results of this "
+                                      "launch are void on every rank")
         return self.logits
 
     def close(self):

@@ -45,14 +45,21 @@ def _bump_structure_epoch(*_args, **_kwargs):
     return None
 
 
+_HOOKS_INSTALLED = [False]
+
+
 def _install_structure_hooks():
-    if getattr(_install_structure_hooks, "done", False):
+    """Idempotent.  Called from ``VLSA._assemble`` AND lazily from ``_provider_key`` / ``_encoder_lists``: a model unpickled in a fresh
+    process (``torch.save(model)`` / ``copy``: ``TransientCaches.__getstate__``) never runs ``_assemble``, and without the hooks a
+    re-assigned provider parameter would keep the stale key."""
+    if _HOOKS_INSTALLED[0]:
         return
+    _HOOKS_INSTALLED[0] = True
+    _STRUCT_EPOCH[0] += 1          # lists walked before the hooks existed are not trusted
     from torch.nn.modules import module as _m
     _m.register_module_parameter_registration_hook(_bump_structure_epoch)
     _m.register_module_buffer_registration_hook(_bump_structure_epoch)
     _m.register_module_module_registration_hook(_bump_structure_epoch)
-    _install_structure_hooks.done = True
 
 
 def _env_flag(name: str) -> bool:
@@ -271,6 +278,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         mods = self._provider_modules()
         if not mods:
             return None
+        if not _HOOKS_INSTALLED[0]:
+            _install_structure_hooks()
         epoch = _STRUCT_EPOCH[0]
         kept = self._provider_lists
         key = [torch.is_grad_enabled()]
@@ -622,6 +631,8 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         """(encoder, its submodules, its tensors + logit scale, structure epoch): kept between calls, re-walked when the encoder
         object changed, when ANY module registered a parameter / buffer / submodule since (``_STRUCT_EPOCH``: a re-assigned
         ``enc.Q = nn.Parameter(...)`` is seen at the next call), on ``_apply``, ``load_state_dict`` and before every window / batch."""
+        if not _HOOKS_INSTALLED[0]:
+            _install_structure_hooks()
         ll = self._la_lists
         enc = self._modules["mil_encoder"]
         if ll is None or ll[0] is not enc or ll[3] != _STRUCT_EPOCH[0]:
@@ -702,11 +713,14 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
                 ref = self.forward(Xp if Xp.dim() == 3 else Xp[None])[0]
         finally:
             self._materialising, self._la, self._pending_calls = prev, la, pending
-        err = float((ref.detach().float().reshape(-1) - logits_row.detach().float().reshape(-1)).abs().max())
+        ref = ref.detach().float().reshape(-1)
+        err = float((ref - logits_row.detach().float().reshape(-1)).abs().max())
+        # the logits scale with exp(logit_scale), which trains: the tolerance is relative to the largest reference logit (>= 1)
+        tol = PARANOID_TOLERANCE * max(1.0, float(ref.abs().max()))
         self._paranoid_checks = getattr(self, "_paranoid_checks", 0) + 1
-        if not (err <= PARANOID_TOLERANCE):
+        if not (err <= tol):
             raise ParanoidMismatch(f"vlsa_amd (VLSA_AMD_PARANOID): {what}: batched logits differ from the per-bag route by {err:.3e} "
-                                   f"(> {PARANOID_TOLERANCE:g}) for a bag of {tuple(X.shape)}; set VLSA_AMD_NO_DEFER=1 / "
+                                   f"(> {tol:g}) for a bag of {tuple(X.shape)}; set VLSA_AMD_NO_DEFER=1 / "
                                    "VLSA_AMD_NO_LOOKAHEAD=1 to run without the shortcut and report this")
         return err
 
