@@ -27,7 +27,7 @@ def _net(P=4, K=3):
 def test_first_model_installs_the_structure_hooks_and_state_follows_reassignment():
     from vlsa_amd import vlsa as V
     net = _net()
-    assert V._install_structure_hooks.done
+    assert V._HOOKS_INSTALLED[0]
     T = net._text_features()
     s0 = net._eval_state(T)
     assert net._same_state(s0, net._eval_state(T))
