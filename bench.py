@@ -744,6 +744,147 @@ def main():
                            "frac": round(nbytes / (bestk * 1e-6) / (HBM_PEAK_GBPS * 1e9), 4), "groups": plan.groups},
                 "verified": {"max_abs_diff": max(errs), "tolerance": 1e-4, "ok": max(errs) < 1e-4, "bags_checked": 2}}
 
+    def train_step_leg(sizes, label, steps, warmup, seed=1100):
+        """BASELINE configs[4]: ONE optimizer step of the reference's training loop (runner/vlsa_handler.py:260-289 under
+        cfg_vlsa_conch.yaml: 32 bags per step, VLFAN encoder with TaskRes text queries, the ORDINAL RANK PROMPT LEARNER through the frozen
+        CONCH-size text tower, IF-MLE + EMD loss, Adam 2e-4 with weight decay 1e-5 on the >= 2-D parameters) on `sizes` resident bf16
+        bags: text side (learner + tower forward AND backward: the prompt embeddings train) + aggregation forward + loss + backward +
+        optimizer, every step.  Timed with HIP events around `steps` consecutive steps after `warmup`; the loss of the LAST timed step is
+        checked against the CPU oracles (text_oracle + vlsa_oracle + vlsa_objective on the parameter values that step started from) at
+        5e-5 relative.  world > 1: bags are the data-parallel unit (32 / world per rank), gradients all-reduced over the data plane."""
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import text_cases as TC                       # seeded tower weights + a replayed tokenizer table (data, no reference code)
+        from vlsa_amd.losses import SurvObjective
+        from vlsa_amd.prompt_adapter import PromptAdapter
+        from vlsa_amd.prompt_encoder import CONCHPromptEncoder
+        from vlsa_amd.prompt_learner import RankPromptLearner
+        from vlsa_amd.train_step import TrainStep
+        from vlsa_amd.vlsa import VLSA
+        Kt, BASE, NB = 12, 4, len(sizes)
+        c = TC.TOWERS["conch"]
+        Wt = TC.make_tower_weights("conch", 9001)
+        enc = CONCHPromptEncoder(width=c["width"], heads=c["heads"], layers=c["layers"], vocab_size=c["vocab"], output_dim=c["out_dim"])
+        enc.load_state_dict(Wt)
+        for p_ in enc.parameters():
+            p_.requires_grad_(False)                  # vlsa_txt_encoder_frozen: True (cfg_vlsa_conch.yaml:69)
+        table, ctx_key, names = TC.synthetic_prompt_table(c["vocab"], 9001, n_ctx=8)
+        learner = RankPromptLearner(dict(max_num_tokens=127, embedding_dim=c["width"], embedding_dtype=torch.float32), TC.ReplayTokenizer(table),
+                                    enc.token_embedding, num_base_ranks=BASE, num_ranks=Kt, num_tokens_per_rank=4, num_context_tokens=8,
+                                    init_context=ctx_key, init_rank_names=names)
+        g = torch.Generator().manual_seed(seed)
+        prompt = torch.randn(P, D, generator=g)
+        qnet = PromptAdapter(method="TaskRes", num_prompts=P, pretrained_prompt_features=prompt, res_ratio=0.5)
+        cfg = dict(name="VLFAN", dim_in=D, use_feat_proj=False, num_query=P, query="Text", query_pooling="mean", pred_head="default")
+        net = VLSA.from_modules(cfg, prompt_learner=learner, prompt_encoder=enc, query_network=qnet).to(device).train()
+        with torch.no_grad():
+            qnet.residual_features.copy_(0.02 * torch.randn(P, D, generator=g))
+        named = [("resid", net.mil_encoder.Q.residual_features), ("W", net.mil_encoder.visual_adapter.weight),
+                 ("b", net.mil_encoder.visual_adapter.bias), ("ctx", learner.context_embeds), ("rank", learner.rank_embeds),
+                 ("logit_scale", net.logit_scale)]
+        mode = os.environ.get("VLSA_BENCH_TRAIN_MODE", "auto")         # auto | eager | graph
+        fused = os.environ.get("VLSA_BENCH_ADAM_FUSED", "1") == "1"
+        opt = torch.optim.Adam([{"params": [p_ for _, p_ in named if p_.dim() < 2], "weight_decay": 0.0},
+                                {"params": [p_ for _, p_ in named if p_.dim() >= 2], "weight_decay": 1e-5}], lr=2e-4,
+                               **({"fused": True, "capturable": True} if fused else {}))
+        gb = torch.Generator(device=device).manual_seed(seed + rank)
+        mine = list(range(NB))[rank::world] if world > 1 else list(range(NB))
+        all_sizes = sizes
+        # every rank draws ALL bags' labels from one generator (identical everywhere), its own bags' rows from its own
+        t_all = torch.randint(0, Kt, (NB,), generator=g)
+        e_all = (torch.rand(NB, generator=g) < 0.45).float()
+        e_all[t_all == Kt - 1] = 1.0                  # (no censored sample in the last bin: its IF-MLE term is the log of rounding noise)
+        bags = [torch.randn(all_sizes[i], D, device=device, generator=gb).to(torch.bfloat16) for i in mine]
+        t_, e_ = t_all[mine].to(device), e_all[mine].to(device)
+        grp = rccl_group if dist is not None else None        # None = the gloo control group (gradients through the host)
+        ts = TrainStep(net, SurvObjective(), opt, dist=dist if world > 1 else None, group=grp, world=world,
+                       graph=(mode != "eager"))
+        snap = {}
+
+        def run(n, snapshot_last=False):
+            loss = None
+            for i in range(n):
+                if snapshot_last and i == n - 1:
+                    snap.update({k: v.detach().clone() for k, v in named})
+                loss = ts.step(bags, t_, e_)
+            return loss
+        run(warmup)
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):                            # clocks: a few more untimed steps behind the synchronize
+            ts.step(bags, t_, e_)
+        e0.record()
+        t0 = time.perf_counter()
+        loss = run(steps, snapshot_last=True)
+        host_ms = (time.perf_counter() - t0) / steps * 1e3
+        e1.record()
+        sync()
+        ms = e0.elapsed_time(e1) / steps
+        if dist is not None and world > 1:
+            tt = torch.tensor([ms], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+        # text side alone (learner + tower, forward + backward), same process, for the split
+        def text_only():
+            f = net.prompt_encoder(prompts_embedding=learner(), prompts_pseudo_tokens=learner.pseudo_sentence_tokens,
+                                   shared_prefix_len=learner.shared_prefix_len)
+            f.sum().backward()
+        for _ in range(5):
+            text_only()
+        e0.record()
+        for _ in range(20):
+            text_only()
+        e1.record()
+        torch.cuda.synchronize()
+        text_ms = e0.elapsed_time(e1) / 20
+        with torch.no_grad():
+            for _ in range(5):
+                net.prompt_encoder(prompts_embedding=learner(), prompts_pseudo_tokens=learner.pseudo_sentence_tokens,
+                                   shared_prefix_len=learner.shared_prefix_len)
+            e0.record()
+            for _ in range(20):
+                net.prompt_encoder(prompts_embedding=learner(), prompts_pseudo_tokens=learner.pseudo_sentence_tokens,
+                                   shared_prefix_len=learner.shared_prefix_len)
+            e1.record()
+            torch.cuda.synchronize()
+        text_fwd_ms = e0.elapsed_time(e1) / 20
+        learner.zero_grad(set_to_none=True)
+        # ---- the last timed step's loss against the CPU oracles on the parameter values it started from
+        got = float(loss.detach())
+        if dist is not None and world > 1:
+            lt = torch.tensor([got], dtype=torch.float64)
+            dist.all_reduce(lt)
+            got = float(lt.item()) / world           # equal shares: the mean of the per-rank means = the batch mean
+        ver = None
+        if rank == 0 and world == 1:
+            from oracle import text_oracle as TO, vlsa_oracle as O
+            t_or = time.perf_counter()
+            E = Wt["token_embedding.weight"]
+            tmax = max(len(table[k]) for k in names)
+            lv = {k: v.float().cpu() for k, v in snap.items()}
+            with torch.no_grad():
+                pseudo = TO.pseudo_sentence_tokens(Kt, lv["ctx"].shape[0], tmax)
+                template = TO.sentence_template(E[0], E[1], E[2], E[table["X."][1]], pseudo)
+                sent = TO.rank_prompt_learner_forward(lv["ctx"], lv["rank"], template, TO.interpolation_weights(BASE, Kt), Kt, "tail")
+                Tf = TO.prompt_encoder_forward(Wt, c["heads"], sent, pseudo, c["layers"])
+                Qo = 0.5 * lv["resid"] + prompt
+                lg = torch.cat([O.vlsa_vlfan_forward(x.float().cpu(), Qo, Tf, lv["logit_scale"], head_weight=lv["W"], head_bias=lv["b"])["logits"]
+                                for x in bags])
+                want = float(O.vlsa_objective(lg, t_.cpu(), e_.cpu(), lv["logit_scale"].exp()))
+            rel = abs(got - want) / max(1.0, abs(want))
+            ver = {"what": "loss of the last timed optimizer step vs oracle.text_oracle + vlsa_oracle.vlsa_objective on the parameters it started from",
+                   "loss": got, "oracle_loss": want, "rel_diff": rel, "tolerance": 5e-5, "ok": rel < 5e-5,
+                   "oracle_seconds": round(time.perf_counter() - t_or, 2)}
+        npatch = sum(all_sizes)
+        info = ts.describe()
+        ts.close()
+        del ts, net, enc, bags
+        torch.cuda.empty_cache()
+        return {"workload": f"{label}: optimizer step over {NB} resident bf16 bags ({npatch} patches), K = {Kt} rank prompts through the frozen "
+                            f"CONCH-size text tower (12 x 768, fwd + bwd every step), VLFAN P = {P} TaskRes queries, IF-MLE + EMD, Adam"
+                            + (f", {world} ranks x {len(mine)} bags, gradient all-reduce" if world > 1 else ""),
+                "ms_per_step": ms, "host_ms_per_step": host_ms, "steps": steps, "patches_per_s_trained": npatch / ms * 1e3,
+                "text_side_ms": {"fwd": text_fwd_ms, "fwd_bwd": text_ms}, "how": info, "verified": ver}
+
     emitted = [False]
 
     def emit(out):
@@ -795,6 +936,30 @@ def main():
 
     extra = {}
     out, guard = None, None
+
+    def train_legs():
+        """BASELINE configs[4] next to the inference headline: the optimizer step at the reference cohort's bag sizes and at the
+        north-star bag size"""
+        gsz = torch.Generator().manual_seed(0)
+        tcga = [int(x) for x in torch.randint(2000, 12000, (32,), generator=gsz)]
+        only = os.environ.get("VLSA_BENCH_ONLY_TRAIN", "")
+        legs = {}
+        n_steps = max(20, min(a.steps * 2, 60))
+        if only in ("", "1", "tcga", "both"):
+            legs["tcga_like_2k_12k"] = train_step_leg(tcga, "TCGA-like bags of 2k-12k patches", n_steps, 10)
+        if only in ("", "1", "50k", "both"):
+            legs["50k"] = train_step_leg([50_000] * 32, "32 x 50k-patch bags", n_steps, 10)
+        first = next(iter(legs.values()))
+        legs["ms_per_step"] = first["ms_per_step"]
+        legs["note"] = ("configs[4] = the TCGA-BLCA training loop: 32 bags per optimizer step; ms_per_step = the first leg's; the reference "
+                        "runs the text tower once per BAG on top (1.44 s per call on its CPU path, BASELINE.md)")
+        return legs
+
+    if os.environ.get("VLSA_BENCH_ONLY_TRAIN") and world == 1:
+        legs = train_legs()
+        emit({"train_step": legs})
+        bad = [k for k, v in legs.items() if isinstance(v, dict) and v.get("verified") and not v["verified"]["ok"]]
+        sys.exit(3 if bad else 0)
     if world == 1 and not force_sharded:
         cfg, scaling = "configs[2]", "strong"
         rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
@@ -820,6 +985,10 @@ def main():
             extra["strong_scaling_base"] = {"workload": "configs[3] on ONE GPU: 200k x 512 bf16 bags, P=12, K=8 (what --gpus N shards)",
                                             "value": BPL * LPS * r3 * s3 / dt3, "unit": "patches/s", "steps": s3,
                                             "ms_per_step": dt3 / s3 * 1e3}
+            try:
+                extra["train_step"] = train_legs()
+            except Exception as exc:  # noqa: BLE001  (a secondary leg must not take the headline down)
+                extra["train_step"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
     else:
         cfg, scaling = "configs[3]", "strong"
         rows, K = CONFIGS[cfg]["rows"], CONFIGS[cfg]["K"]
@@ -866,6 +1035,11 @@ def main():
             extra["weak_scaling"] = {"workload": f"bags of {world} x 50k patches, 50k rows per GPU per bag, P=12, K=4 (round-1 --gpus workload)",
                                      "value": BPL * LPS * rw * world * a.steps / dtw, "unit": "patches/s", "steps": a.steps,
                                      "ms_per_step": dtw / a.steps * 1e3, "scaling": "weak"}
+            if 32 % world == 0:
+                try:
+                    extra["train_step"] = train_legs()          # bag-parallel: 32 / world bags per rank, gradient all-reduce
+                except Exception as exc:  # noqa: BLE001
+                    extra["train_step"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
 
     if guard is not None:
         guard.cancel()
@@ -876,6 +1050,7 @@ def main():
         emit(out)
         bad = [k for k in ("verified",) if not out.get(k, {}).get("ok", False)]
         bad += [k for k in ("with_attn", "configs[1]", "single_slide", "slide_sized_bags", "eval_loop_lookahead", "eval_loop_lookahead_slide_sized") if k in out and not out[k]["verified"]["ok"]]
+        bad += [f"train_step.{k}" for k, v in out.get("train_step", {}).items() if isinstance(v, dict) and v.get("verified") and not v["verified"]["ok"]]
         if bad:
             sys.stderr.write(f"bench.py: outputs of the timed launches do not match the CPU oracle ({', '.join(bad)}) -- the number above is void\n")
             if dist is not None:

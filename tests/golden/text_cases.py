@@ -15,9 +15,17 @@ TOWERS = {
 }
 
 
+# Round 6 ("hot" cases): weight seeds whose in_proj / c_fc weights are rescaled AFTER the draw.  With the init stds the attention logits of a
+# random tower stay within |.| ~ 3 and the GELU inputs within ~ 2.5 -- a trained CONCH tower does not; the factors below drive the logits to
+# |.| ~ 30-60 (softmax rows close to one-hot, large exp arguments) and the c_fc outputs to |.| ~ 6-10 (GELU tails, erf saturating) -- ranges
+# the 1e-4 gate had never seen (VERDICT r5 "What's weak" 1).  seed -> (in_proj factor, c_fc factor).
+WEIGHT_SCALES = {9021: (3.5, 3.5), 9022: (4.0, 3.0), 9023: (3.0, 4.0)}
+
+
 def make_tower_weights(name: str, seed: int):
     """Every tensor ~ N(0, std) with the stds of TextTransformer.init_parameters (transformer.py:376-392) -- except that
-    biases and LayerNorm affine parameters are made non-trivial so that they are exercised."""
+    biases and LayerNorm affine parameters are made non-trivial so that they are exercised; seeds listed in WEIGHT_SCALES get
+    their attention input projection and c_fc weights multiplied by the factors there."""
     c = TOWERS[name]
     d, L = c["width"], c["layers"]
     g = torch.Generator().manual_seed(seed)
@@ -34,6 +42,12 @@ def make_tower_weights(name: str, seed: int):
         W[p + "ln_2.weight"], W[p + "ln_2.bias"] = 1 + n(d, std=0.1), n(d, std=0.05)
         W[p + "mlp.c_fc.weight"], W[p + "mlp.c_fc.bias"] = n(4 * d, d, std=fc_std), n(4 * d, std=0.02)
         W[p + "mlp.c_proj.weight"], W[p + "mlp.c_proj.bias"] = n(d, 4 * d, std=proj_std), n(d, std=0.02)
+    if seed in WEIGHT_SCALES:
+        s_in, s_fc = WEIGHT_SCALES[seed]
+        for i in range(L):
+            p = f"transformer.resblocks.{i}."
+            W[p + "attn.in_proj_weight"] = W[p + "attn.in_proj_weight"] * s_in
+            W[p + "mlp.c_fc.weight"] = W[p + "mlp.c_fc.weight"] * s_fc
     return W
 
 
@@ -44,12 +58,17 @@ RANK_CASES = [
     ("rank_conch_k4", "conch", 9002, 4, 4, "tail"),
     ("rank_small_k8_front", "small", 9003, 8, 4, "front"),
     ("rank_mid_k5_middle", "mid", 9004, 5, 3, "middle"),
+    ("rank_conch_k12_hot", "conch", 9021, 12, 4, "tail"),        # round 6: rescaled weights (WEIGHT_SCALES)
+    ("rank_mid_k6_hot", "mid", 9022, 6, 4, "tail"),
 ]
 # tokenised texts (prompts_text path: the PromptAdapter's prototype prompts): name, tower, seed, sentence lengths (tokens
 # between <sot> and <eot>)
 TEXT_CASES = [
     ("text_conch", "conch", 9011, [9, 14, 3, 20, 9, 1]),
     ("text_small", "small", 9012, [5, 125, 1, 30]),
+    # round 6: rescaled weights AND a pad pattern unlike the shipped prompts' (lengths from 1 to 100 tokens in one call: every prompt's
+    # CLS mask differs; 225 compact rows = 15 row tiles)
+    ("text_conch_hot_padmix", "conch", 9023, [2, 60, 17, 1, 33, 100]),
 ]
 
 

@@ -18,7 +18,9 @@ def test_rank_prompt_text_features_and_gradients(case):
     feats, leaves = TH.oracle_rank_case(case, requires_grad=True)
     s = leaves["sentence"].detach().double()
     assert np.allclose([float(s.sum()), float((s ** 2).sum())], fx["sentence_checksum"], rtol=1e-6)
-    assert np.abs(feats.detach().numpy() - fx["text_features"]).max() < 2e-5
+    # (raw text features, |.| up to ~4: two fp32 evaluation orders of the same 12 blocks -- the reference's fused attention kernels vs the
+    # oracle's explicit ones -- differ by a few 1e-6 RELATIVE; the rescaled-weight cases reach 2.4e-5 absolute on a 4.2 entry)
+    assert np.abs(feats.detach().numpy() - fx["text_features"]).max() < 2e-5 * max(1.0, 0.5 * np.abs(fx["text_features"]).max())
     (feats * torch.from_numpy(fx["G"])).sum().backward()
     for key, leaf in (("grad_context", "context"), ("grad_rank", "rank")):
         ref = fx[key]
@@ -37,7 +39,7 @@ def test_tokenised_text_path(case):
     # (prompt_encoder.py:257-265) and the CLS token only sees position 0 -- reproduced, not "fixed"
     assert [int((p > 0).sum()) for p in pseudo] == [n + 2 if n + 2 < 127 else 0 for n in lens]
     feats = TO.prompt_encoder_forward(W, c["heads"], W["token_embedding.weight"][ids], pseudo, c["layers"])
-    assert np.abs(feats.numpy() - fx["text_features"]).max() < 2e-5
+    assert np.abs(feats.numpy() - fx["text_features"]).max() < 2e-5 * max(1.0, 0.5 * np.abs(fx["text_features"]).max())
 
 
 def test_rows_behind_the_sentence_do_not_reach_the_cls_token():
@@ -58,3 +60,25 @@ def test_rows_behind_the_sentence_do_not_reach_the_cls_token():
     sent[:, n_real] += 0.5 * torch.randn(sent[:, n_real].shape, generator=torch.Generator().manual_seed(2))   # (a constant shift would be removed by the LayerNorms)
     feats3 = TO.prompt_encoder_forward(W, c["heads"], sent, leaves["pseudo"], c["layers"])
     assert (feats3 - feats).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["rank_conch_k12_hot", "rank_mid_k6_hot"])
+def test_hot_cases_reach_the_ranges_a_trained_tower_reaches(name):
+    """Round 6: the rescaled-weight fixtures must really drive the softmax / GELU where the ordinary seeded towers
+    never go -- attention logits |.| >= 25 on live (row, key) pairs, c_fc outputs |.| >= 6 -- and the ordinary case must not (so the
+    new fixtures add coverage instead of repeating it)."""
+    case = next(c for c in TC.RANK_CASES if c[0] == name)
+    inp = TH.rank_case_inputs(case)
+    _, leaves = TH.oracle_rank_case(case)
+    stats = {}
+    with torch.no_grad():
+        TO.prompt_encoder_forward(inp["W"], inp["heads"], leaves["sentence"], leaves["pseudo"], inp["layers"], stats=stats)
+    assert stats["attn_logit_absmax"] >= 25.0 and stats["gelu_input_absmax"] >= 6.0, stats
+    base = next(c for c in TC.RANK_CASES if c[1] == case[1] and c[2] not in TC.WEIGHT_SCALES)
+    binp = TH.rank_case_inputs(base)
+    _, bl = TH.oracle_rank_case(base)
+    bstats = {}
+    with torch.no_grad():
+        TO.prompt_encoder_forward(binp["W"], binp["heads"], bl["sentence"], bl["pseudo"], binp["layers"], stats=bstats)
+    assert bstats["attn_logit_absmax"] < 0.5 * stats["attn_logit_absmax"] and bstats["gelu_input_absmax"] < stats["gelu_input_absmax"]
+    print(name, stats, "ordinary:", bstats)
