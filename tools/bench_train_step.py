@@ -10,7 +10,8 @@ steps = sys.argv[2] if len(sys.argv) > 2 else "40"
 env = dict(os.environ, VLSA_BENCH_ONLY_TRAIN=which)
 out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "8", "--no-cpu-baseline"], env=env,
                      capture_output=True, text=True)
-sys.stderr.write(out.stderr[-3000:])
+sys.stderr.write(out.stderr[-6000:])
+sys.stderr.write(f"\n[bench_train_step] bench.py exit code {out.returncode}\n")
 line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "{}"
 try:
     d = json.loads(line)

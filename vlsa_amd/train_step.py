@@ -27,6 +27,21 @@ import torch
 from . import functional as VF
 
 
+def _dbg(msg):
+    if os.environ.get("VLSA_TRAINSTEP_DEBUG"):
+        import sys
+        sys.stderr.write(f"[TrainStep] {msg}\n")
+        sys.stderr.flush()
+
+
+def _bump_versions(tensors):
+    try:
+        torch._C._increment_version(tensors)            # torch >= 2.4: an iterable of tensors
+    except (RuntimeError, TypeError):
+        for t in tensors:
+            torch._C._increment_version(t)
+
+
 class TrainStep:
     def __init__(self, net, objective, optimizer, dist=None, group=None, world: int = 1, graph: bool = True, max_graphs: int = 8,
                  capture_after: int = 1):
@@ -38,6 +53,7 @@ class TrainStep:
         self._seen = OrderedDict()          # batch key -> eager steps seen
         self._graphs = OrderedDict()        # batch key -> (graph, loss, kept)
         self._pool = None
+        self._cap_stream = None
         self.why_eager: Optional[str] = None if self.graph_enabled else ("graph=False" if not graph else
                                                                         "data parallel" if self.world > 1 else "optimizer is not capturable")
         self.n_eager = self.n_replay = self.n_capture = 0
@@ -55,7 +71,8 @@ class TrainStep:
         if self.world > 1:
             self._allreduce_grads()
         self.opt.step()
-        return loss
+        return loss.detach()          # (detached: a caller that keeps the loss must not keep the step's autograd graph -- and its
+                                      #  AccumulateGrad nodes, bound to the stream they were created on -- alive into a capture)
 
     def _allreduce_grads(self):
         grads = [p.grad for p in self.params if p.grad is not None]
@@ -81,22 +98,41 @@ class TrainStep:
         rows = bags.rows.tobytes() if isinstance(bags, VF.BagSet) else tuple((x.data_ptr(), x.shape[0], x.stride(0)) for x in bags)
         return (rows, t.data_ptr(), None if e is None else e.data_ptr(), t.shape)
 
+    def _side(self, bags, t, e):
+        """one EAGER step on the capture stream (the step before a capture): whatever the step creates lazily -- allocator pools of
+        that stream, autograd's per-parameter AccumulateGrad nodes, library handles -- then exists on the stream the capture runs on"""
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._cap_stream.wait_stream(cur)
+        with torch.cuda.stream(self._cap_stream):
+            loss = self._eager(bags, t, e)
+        cur.wait_stream(self._cap_stream)
+        return loss
+
     def _capture(self, key, bags, t, e):
         bagset = bags if isinstance(bags, VF.BagSet) else VF.BagSet(bags)
         bagset.desc()                                   # the descriptor table goes up outside the capture
-        cur = torch.cuda.current_stream()
         g = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
+        _dbg("capture begins")
         try:
-            with torch.cuda.graph(g, pool=self._pool, capture_error_mode=os.environ.get("VLSA_GRAPH_CAPTURE_MODE", "global")):
+            with torch.cuda.graph(g, pool=self._pool, stream=self._cap_stream,
+                                  capture_error_mode=os.environ.get("VLSA_GRAPH_CAPTURE_MODE", "global")):
                 loss = self._eager(bagset, t, e)
         except Exception as exc:  # noqa: BLE001  (whatever refuses to be captured: this batch -- and the object -- stay eager)
             self.graph_enabled = False
             self.why_eager = f"capture failed: {type(exc).__name__}: {str(exc)[:300]}"
-            torch.cuda.synchronize()
+            _dbg(self.why_eager)
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
             self.net._drop_text_cache()
+            self.opt.zero_grad(set_to_none=True)
             return None
+        _dbg("capture ended")
         if self._pool is None:
             self._pool = g.pool()
         self.n_capture += 1
@@ -104,15 +140,13 @@ class TrainStep:
         self._graphs[key] = (g, loss, (bagset, t, e))
         while len(self._graphs) > self.max_graphs:
             self._graphs.popitem(last=False)
-        del cur
         return self._replay(key)
 
     def _replay(self, key):
         g, loss, _ = self._graphs[key]
         self._graphs.move_to_end(key)
         g.replay()
-        for p in self.params:                           # what optimizer.step() does to the version counters, without a kernel
-            torch._C._increment_version(p)
+        _bump_versions(self.params)                     # what optimizer.step() does to the version counters, without a kernel
         self.net._drop_text_cache()                     # (the capture left the text cache pointing at a graph-owned tensor)
         self.n_replay += 1
         return loss
@@ -127,7 +161,7 @@ class TrainStep:
         if key in self._graphs:
             return self._replay(key)
         n = self._seen.get(key, 0)
-        if n >= self.capture_after:
+        if n > self.capture_after:
             self._seen.pop(key, None)
             loss = self._capture(key, bags, t, e)
             if loss is not None:
@@ -135,6 +169,11 @@ class TrainStep:
             self.n_eager += 1
             return self._eager(bags, t, e)
         self._seen[key] = n + 1
+        if n == self.capture_after:         # the step before the capture: eager, on the capture stream
+            while len(self._seen) > 4096:
+                self._seen.popitem(last=False)
+            self.n_eager += 1
+            return self._side(bags, t, e)
         while len(self._seen) > 4096:
             self._seen.popitem(last=False)
         self.n_eager += 1
