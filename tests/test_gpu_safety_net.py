@@ -206,3 +206,75 @@ def test_in_place_write_before_a_later_lazy_upload_is_still_reported():
         assert "IN PLACE" in str(e)
     with pytest.raises(RuntimeError, match="IN PLACE"):
         rb[0]                                                                  # ... whichever segment item 1 went to
+
+
+def _oracle_logits(net, X):
+    from oracle import vlsa_oracle as O
+    enc = net.mil_encoder
+    with torch.no_grad():
+        ref = O.vlsa_vlfan_forward(X[0].float().cpu(), enc.get_query().detach().float().cpu(), net._text_features().detach().float().cpu(),
+                                   net.logit_scale.detach().cpu(), head_weight=enc.visual_adapter.weight.detach().cpu(),
+                                   head_bias=enc.visual_adapter.bias.detach().cpu())
+    return ref["logits"][0]
+
+
+def test_hot_call_equals_the_full_route_and_follows_every_state_change(monkeypatch):
+    """Round 6: a repeated per-bag inference call under an unchanged model state is ONE pre-built C call (``VLSA._fused_vlfan`` ->
+    ``VlfanInferencePlan.hot_call``).  Same bits as the full route (``VLSA_AMD_NO_HOTCALL``), and nothing stale: an in-place parameter
+    update, a re-assigned parameter, new text features, the logit scale, train / eval, another bag size or dtype -- each followed by a
+    call that is checked against the CPU oracle on the CURRENT values."""
+    from vlsa_amd import vlsa as V
+    net, params = _vlfan_net()
+    net.eval()
+    bags = {(n, dt): cases.make_bag(n, 7700 + n, "clustered").to(dt).cuda()[None] for n in (2798, 700) for dt in (torch.bfloat16, torch.float32)}
+    X = bags[(2798, torch.bfloat16)]
+
+    def call(x):
+        with torch.no_grad():
+            return [t.clone() for t in net(x)]
+    first = call(X)                                        # full route, leaves a hot entry
+    assert len(net._hot) == 1
+    hot = call(X)
+    monkeypatch.setattr(V, "ENV_NO_HOTCALL", True)
+    full = call(X)
+    monkeypatch.setattr(V, "ENV_NO_HOTCALL", False)
+    for a, b, c in zip(first, hot, full):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert (hot[0][0].cpu() - _oracle_logits(net, X)).abs().max().item() < 1e-4
+
+    def check(what, x=X):
+        got = call(x)[0][0].cpu()
+        err = (got - _oracle_logits(net, x)).abs().max().item()
+        assert err < 1e-4, (what, err)
+        again = call(x)[0][0].cpu()                        # ... and the (possibly hot) repeat says the same
+        assert torch.equal(got, again), what
+        return got
+    base = check("unchanged")
+    enc = net.mil_encoder
+    with torch.no_grad():
+        enc.Q.mul_(1.25).add_(0.01)                        # in place: version bump
+    assert not torch.equal(check("query updated in place"), base)
+    enc.Q = torch.nn.Parameter((enc.Q.detach() * 0.5).clone())          # re-assigned: a new object with version 0
+    check("query re-assigned")
+    with torch.no_grad():
+        net.logit_scale.add_(0.3)
+    check("logit scale")
+    with torch.no_grad():
+        enc.visual_adapter.weight.mul_(0.9)
+        enc.visual_adapter.bias.add_(0.05)
+    check("adapter")
+    with torch.no_grad():
+        net.pretrained_text_features.mul_(-1.0)            # the text features the logits are taken against
+    check("text features")
+    net.train()
+    check("train mode")
+    net.eval()
+    for key, x in bags.items():                            # other shapes / dtypes: their own plans and entries
+        check(f"bag {key}", x)
+        check(f"bag {key} again", x)
+    assert 1 <= len(net._hot) <= 4
+    xs = X[:, ::2]                                         # a strided view of the bag: not what the entry was built for
+    assert xs.stride(1) != X.stride(1)
+    check("strided bag", xs)
+    net2 = __import__("copy").deepcopy(net)
+    assert net2._hot == {}                                 # native handles are not state

@@ -121,22 +121,42 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma(const __bf16* __re
     };
 
     VLSA_STAMP(1);
-    if (rg < ntiles) issue_tile(rg, 0);  // first tile goes in flight before anything else touches memory
-    // query B-fragments (scale * log2 e already folded in): lane holds Q[p = i16][128 cw + 32 kk + 8 g .. +8]
+    // Round 6 -- the start of the kernel in the order that keeps HBM busy (profiles/r05_dma_stamps.txt: half of the kernel was ramp):
+    //   1. the query B-fragments (L2 hits, 12 x 16 B per lane) go out FIRST, as inline-asm loads: the vm counter retires loads in
+    //      order, so behind a DMA tile they would wait for the whole first round of HBM traffic (round 5: +7.9 k cycles), and as
+    //      compiler-visible loads hipcc's own `s_waitcnt vmcnt(0)` for them would drain the DMA ring;
+    //   2. BOTH ring slots are requested before anything is waited for (round 5 requested the second tile only after the first
+    //      had landed: HBM idled between the two rounds);
+    //   3. `s_waitcnt vmcnt(<pieces behind the fragments>)` retires the fragments alone.
+    // lane holds Q[p = i16][128 cw + 32 kk + 8 g .. +8] of the three split terms (scale * log2 e already folded in)
     bf16x8 qf[3][4];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            qf[t][kk] = *reinterpret_cast<const bf16x8*>(qsplit + ((size_t)t * 16 + i16) * D + cw * 128 + kk * 32 + g * 8);
+    {
+        const __bf16* q0 = qsplit + (size_t)i16 * D + cw * 128 + g * 8;
+        const __bf16* q1 = q0 + (size_t)16 * D;
+        const __bf16* q2 = q0 + (size_t)32 * D;
+#define VLSA_QLOAD(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
+        VLSA_QLOAD(qf[0][0], q0, 0);   VLSA_QLOAD(qf[0][1], q0, 64);  VLSA_QLOAD(qf[0][2], q0, 128); VLSA_QLOAD(qf[0][3], q0, 192);
+        VLSA_QLOAD(qf[1][0], q1, 0);   VLSA_QLOAD(qf[1][1], q1, 64);  VLSA_QLOAD(qf[1][2], q1, 128); VLSA_QLOAD(qf[1][3], q1, 192);
+        VLSA_QLOAD(qf[2][0], q2, 0);   VLSA_QLOAD(qf[2][1], q2, 64);  VLSA_QLOAD(qf[2][2], q2, 128); VLSA_QLOAD(qf[2][3], q2, 192);
+#undef VLSA_QLOAD
+    }
+    const bool first = rg < ntiles, second = rg + 2 < ntiles;      // wave-uniform
+    if (first) issue_tile(rg, 0);
+    // every wave's FIRST tile is queued before anybody's second (the CU serves its waves' requests in issue order, and the first
+    // exchange needs all four column quarters of tile 0: without this barrier wave 3's tile 0 sat behind three second tiles --
+    // profiles/r06_dma_stamps.txt, first attempt: fragments +6.3 k, wave 0's tile +7.3 k, but the first exchange still at +16 k)
+    __builtin_amdgcn_s_barrier();
+    if (second) issue_tile(rg + 2, 1);
 
     f32x4 acc[8];
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float M = -INFINITY, lsum = 0.f;
 
-    // Retire the query-fragment loads here, in a way hipcc can see (a register use): otherwise its own
-    // s_waitcnt vmcnt(0) for them lands inside the loop and drains our in-flight DMA every iteration.
+    if (second) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the fragments are defined from here on (a register use hipcc can see, behind the wait)
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -147,18 +167,12 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma(const __bf16* __re
         const int tile = 2 * it + rg;
         const int slot = it & 1;
         const bool have = tile < ntiles;           // wave-uniform
-        const bool have_next = tile + 2 < ntiles;  // wave-uniform
-        // every ds_read of the slot we are about to refill was consumed by an MFMA of the previous iteration
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (have_next) {
-            issue_tile(tile + 2, slot ^ 1);
-            if constexpr (WANT_SCORES)  // the score stores share the vm counter: drain everything (slower path)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else  // this tile's 8 pieces have landed; the next 8 stay in flight
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        const bool have_next = tile + 2 < ntiles;  // wave-uniform: the OTHER slot holds (or is receiving) this wave's next tile
+        // This tile's 8 pieces have landed once at most the next tile's 8 are outstanding.  (The score stores of WANT_SCORES share the
+        // counter; loads retire in order among themselves, so "<= 8 outstanding" with 8 younger DMA pieces issued still means that
+        // every piece of THIS tile is in -- whatever the stores do.)
+        if (have_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned char* xs = ring + slot * kSlot;
         const int row0 = tile * kTile;  // relative to rbeg
         if (it == 0) VLSA_STAMP(3);
@@ -300,35 +314,46 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma(const __bf16* __re
                 acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc[ct], 0, 0, 0);
             }
         }
+        // the slot just consumed takes the tile after next: every ds_read of it has returned (they fed the MFMAs above)
+        if (tile + 4 < ntiles) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_tile(tile + 4, slot);
+        }
     }
 
-    // ---- epilogue: merge row group 1 into row group 0 through LDS, then write the workgroup's partial ------
+    // ---- epilogue: the two row groups merge into ONE partial.  Round 6: BOTH halves of the workgroup work -- wave (rg, cw) parks the
+    // four column tiles the OTHER row group will finish in its own (free) ring, takes the partner's four, merges, transposes through
+    // LDS and stores 16-byte row pieces: 4 KB per wave instead of 8 KB by half of the waves (round 5: 4.2 k cycles from "loop done" to
+    // "stores drained" with row group 1 idle behind the first barrier).  The merged value is the same expression as before --
+    // acc(rg 0) * f(rg 0) + acc(rg 1) * f(rg 1) -- whichever wave evaluates it.
     VLSA_STAMP(7);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VLSA_LDS_BARRIER();
     lsum = quad_rows_sum(lsum);
-    unsigned char* mg = smem + (4 + cw) * kWaveRing;  // row group 1's wave (4 + cw) lends its ring: 16 KiB
-    float* ml = reinterpret_cast<float*>(smem + kRingBytes);  // exchange area: [cw][2][16] (M, l) of row group 1
-    if (rg == 1) {
+    unsigned char* park = smem + w * kWaveRing;                          // this wave's ring: [0, 4 KB) the tiles it hands over
+    const unsigned char* theirs = smem + ((rg ^ 1) * 4 + cw) * kWaveRing;   // ... and where the partner (rg ^ 1, cw) parked ours
+    float* ml = reinterpret_cast<float*>(smem + kRingBytes);             // exchange area: [rg][cw][2][16] (M, l)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) *reinterpret_cast<f32x4_ma*>(mg + (ct * 64 + lane) * 16) = acc[ct];
-        if (g == 0) {
-            reinterpret_cast<float_ma*>(ml)[cw * 32 + i16] = M;
-            reinterpret_cast<float_ma*>(ml)[cw * 32 + 16 + i16] = lsum;
-        }
+    for (int k = 0; k < 4; ++k) {   // rg 0 keeps column tiles 0..3 and parks 4..7; rg 1 the other way round (static register indices)
+        const f32x4 v = rg ? acc[k] : acc[4 + k];
+        *reinterpret_cast<f32x4_ma*>(park + (k * 64 + lane) * 16) = v;
+    }
+    if (g == 0) {
+        reinterpret_cast<float_ma*>(ml)[(rg * 4 + cw) * 32 + i16] = M;
+        reinterpret_cast<float_ma*>(ml)[(rg * 4 + cw) * 32 + 16 + i16] = lsum;
     }
     VLSA_LDS_BARRIER();
     VLSA_STAMP(8);
-    if (rg == 0) {
-        const float M1 = reinterpret_cast<const float_ma*>(ml)[cw * 32 + i16];
-        const float l1 = reinterpret_cast<const float_ma*>(ml)[cw * 32 + 16 + i16];
-        const float Mn = fmaxf(M, M1);
-        const float f0 = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);
-        const float f1 = (M1 == -INFINITY) ? 0.f : fast_exp2(M1 - Mn);
-        const float lt = lsum * f0 + l1 * f1;
-        if (cw == 0 && g == 0 && i16 < P) {
+    {
+        const float Mo = reinterpret_cast<const float_ma*>(ml)[((rg ^ 1) * 4 + cw) * 32 + i16];
+        const float lo = reinterpret_cast<const float_ma*>(ml)[((rg ^ 1) * 4 + cw) * 32 + 16 + i16];
+        const float Mn = fmaxf(M, Mo);
+        const float fs = (M == -INFINITY) ? 0.f : fast_exp2(M - Mn);     // this row group's factor
+        const float fo = (Mo == -INFINITY) ? 0.f : fast_exp2(Mo - Mn);   // the partner's
+        const float f0 = rg ? fo : fs, f1 = rg ? fs : fo;                // factor of row group 0 / of row group 1
+        if (rg == 0 && cw == 0 && g == 0 && i16 < P) {
             pm[(size_t)b * kPStride + i16] = Mn;
-            pl[(size_t)b * kPStride + i16] = lt;
+            pl[(size_t)b * kPStride + i16] = lsum * f0 + lo * f1;
         }
         float a0[4], a1[4];
 #pragma unroll
@@ -336,21 +361,23 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma(const __bf16* __re
             a0[r] = __shfl(f0, 4 * g + r);
             a1[r] = __shfl(f1, 4 * g + r);
         }
-        // merged accumulator -> LDS as a [16 p][128 c] fp32 tile (this wave's own ring), then 16-byte row stores
-        unsigned char* tp = smem + cw * kWaveRing;
+        // merged [16 p][64 c] fp32 tile -> LDS (the second slot of this wave's own ring), then 16-byte row stores
+        unsigned char* tp = park + kSlot;
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const f32x4 other = *reinterpret_cast<const f32x4_ma*>(mg + (ct * 64 + lane) * 16);
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 mine = rg ? acc[4 + k] : acc[k];
+            const f32x4 other = *reinterpret_cast<const f32x4_ma*>(theirs + (k * 64 + lane) * 16);
+            const f32x4 x0 = rg ? other : mine, x1 = rg ? mine : other;   // row group 0's / row group 1's accumulators
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                reinterpret_cast<float_ma*>(tp)[(4 * g + r) * 128 + ct * 16 + i16] = acc[ct][r] * a0[r] + other[r] * a1[r];
+                reinterpret_cast<float_ma*>(tp)[(4 * g + r) * 64 + k * 16 + i16] = x0[r] * a0[r] + x1[r] * a1[r];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private round trip: in-order LDS, just drain
-        float* dstp = pacc + (size_t)b * P * D + cw * 128 + (lane & 31) * 4;
+        float* dstp = pacc + (size_t)b * P * D + cw * 128 + rg * 64 + (lane & 15) * 4;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int p = 2 * k + (lane >> 5);
-            const f32x4 v = *reinterpret_cast<const f32x4_ma*>(tp + (p * 128 + (lane & 31) * 4) * 4);
+        for (int k = 0; k < 4; ++k) {
+            const int p = 4 * k + (lane >> 4);
+            const f32x4 v = *reinterpret_cast<const f32x4_ma*>(tp + (p * 64 + (lane & 15) * 4) * 4);
             if (p < P) *reinterpret_cast<f32x4*>(dstp + (size_t)p * D) = v;
         }
     }

@@ -734,6 +734,10 @@ extern "C" int vlsa_vlfan_merge_head(const float* pm, const float* pl, const flo
     }
     hipStream_t s = (hipStream_t)stream;
     float* vpart = reinterpret_cast<float*>(static_cast<unsigned char*>(head_ws) + kHeadTicketBytes);
+    // (Round 6 measured both launches as ONE -- the merge workgroups publishing write-through and arriving on a two-level counter, the
+    // last arriver running the finish on agent-scope loads: 16.6 us against 12.3 us for these two launches, back to back on the same
+    // box; the hand-off costs more than the kernel boundary it removes, as it did for the ticketed k_head of rounds 1-4.  Not kept:
+    // docs/LAB_NOTEBOOK.md.)
     hipLaunchKernelGGL(k_vlfan_merge_wpart, dim3(8, P, 4), dim3(256), 0, s, pm, pl, pacc, G, P, m2, l, out, W, vpart);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     hipLaunchKernelGGL(k_head_finish_parts, dim3(1), dim3(512), 0, s, vpart, out, P, 8, pool_mode, pool_w, b, That, K, logit_scale,

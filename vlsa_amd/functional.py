@@ -573,6 +573,40 @@ class VlfanInferencePlan:
             outs["That"] = self._That_out
         return outs["logits"] if outs and "logits" in outs else self.logits
 
+    def hot_call(self, T, logit_scale, W, b, pool_w, That_out):
+        """The per-bag call with EVERYTHING but the bag frozen: returns ``fn(X [1, N, D]) -> (logits [1, K], vhat [1, D], That)`` that
+        issues ``vlsa_vlfan_forward_bag`` with a pre-built argument list (prepared queries / text features reused: Q = NULL) -- the
+        reference handler's loop calls the model once per slide (runner/vlsa_handler.py:322-330) and that call is bound by its host side
+        (tools/prof_single_slide.py: 28.5 us per call for ANY bag size in round 5, ~15 of it Python around the C call).  The caller
+        (``VLSA._fused_vlfan``) keeps the closure only as long as the model state it was built under holds; the tensors it reads are
+        kept alive here."""
+        lib, k = self.lib, self._c
+        keep = (T, logit_scale, W, b, pool_w, That_out)
+        fn_c = lib.vlsa_vlfan_forward_bag
+        dt_code = {torch.float32: nat.DT_F32, torch.bfloat16: nat.DT_BF16}
+        N, D, K = self.N, self.D, self.K
+        nq = self.P + 1 if self.gated else self.P
+        args = [None, 0, N, 0, D, None, nq, int(self.gated), self.scale, _p(T), K, _p(logit_scale), self.pool, _p(pool_w),
+                None if self.identity_head else _p(W), None if self.identity_head else _p(b), self.kernel, k["qprep"], k["That"],
+                k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G, k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"],
+                k["v"], None, k["vnorm"], None, k["incidence"], None]
+        I_X, I_DT, I_LD, I_VHAT, I_LOGITS, I_STREAM = 0, 1, 3, 32, 34, 36
+        empty, cur = torch.empty, torch.cuda.current_stream
+
+        def fn(X):
+            dev = X.device
+            logits = empty((1, K), dtype=torch.float32, device=dev)
+            vhat = empty((1, D), dtype=torch.float32, device=dev)
+            a = args
+            a[I_X], a[I_DT], a[I_LD] = X.data_ptr(), dt_code[X.dtype], X.stride(1)
+            a[I_VHAT], a[I_LOGITS], a[I_STREAM] = vhat.data_ptr(), logits.data_ptr(), cur(dev).cuda_stream
+            rc = fn_c(*a)
+            if rc != 0:
+                nat.check(rc, "vlsa_vlfan_forward_bag")
+            return logits, vhat, That_out
+        fn.keep = keep
+        return fn
+
     def run_partial_only(self, X: torch.Tensor):
         """Just the streaming kernel (for roofline timing); queries must have been prepared by a run()."""
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
