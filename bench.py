@@ -782,10 +782,14 @@ def main():
                  ("b", net.mil_encoder.visual_adapter.bias), ("ctx", learner.context_embeds), ("rank", learner.rank_embeds),
                  ("logit_scale", net.logit_scale)]
         mode = os.environ.get("VLSA_BENCH_TRAIN_MODE", "auto")         # auto | eager | graph
-        fused = os.environ.get("VLSA_BENCH_ADAM_FUSED", "1") == "1"
-        opt = torch.optim.Adam([{"params": [p_ for _, p_ in named if p_.dim() < 2], "weight_decay": 0.0},
-                                {"params": [p_ for _, p_ in named if p_.dim() >= 2], "weight_decay": 1e-5}], lr=2e-4,
-                               **({"fused": True, "capturable": True} if fused else {}))
+        which = os.environ.get("VLSA_BENCH_ADAM", "vlsa")                # vlsa (one HIP launch) | torch_fused | torch
+        groups = [{"params": [p_ for _, p_ in named if p_.dim() < 2], "weight_decay": 0.0},
+                  {"params": [p_ for _, p_ in named if p_.dim() >= 2], "weight_decay": 1e-5}]          # optim_factory.py:25-37
+        if which == "vlsa":
+            from vlsa_amd.optim import FusedAdam
+            opt = FusedAdam(groups, lr=2e-4)
+        else:
+            opt = torch.optim.Adam(groups, lr=2e-4, **({"fused": True, "capturable": True} if which == "torch_fused" else {}))
         gb = torch.Generator(device=device).manual_seed(seed + rank)
         mine = list(range(NB))[rank::world] if world > 1 else list(range(NB))
         all_sizes = sizes

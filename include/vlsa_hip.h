@@ -502,6 +502,35 @@ int vlsa_pack_rows_bf16(const void* src, int src_dtype, int64_t N, int64_t lds, 
 int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, int B, int K, int from_logits,
                    const float* logit_scale_exp, float alpha, float eps, int p, int raw_distance, float w_ifmle,
                    float w_emd, float* out_ifmle, float* out_emd, float* grad, void* stream);
+/*
+ * The handler's whole objective in ONE launch (runner/vlsa_handler.py:241-258: calc_objective_loss with 'mean'-reduced SurvIFMLE +
+ * SurvEMD, loss/loss_surv.py:163-164, loss/loss_surv_ext.py:104-105): objective[0] = mean_i (w_ifmle * ifmle_i + w_emd * emd_i),
+ * grad [B, K] = d objective / d x (NULL to skip).  logit_scale: device pointer to exp(logit_scale) as the reference's
+ * net.get_logit_scale() hands it over (ls_is_log = 0), or to the raw parameter, exponentiated here (ls_is_log = 1).  B <= 4096.
+ */
+int vlsa_surv_objective(const float* x, const int64_t* t, const float* e, int B, int K, int from_logits, const float* logit_scale,
+                        int ls_is_log, float alpha, float eps, int p, int raw_distance, float w_ifmle, float w_emd,
+                        float* objective, float* grad, void* stream);
+
+/*
+ * The optimizer of the training step in ONE launch: torch.optim.Adam's update (runner/vlsa_handler.py:283-289 builds
+ * optim.Adam(lr, weight_decay) through optim_factory.py:25-60; amsgrad = False, maximize = False, L2 weight decay added to the
+ * gradient) over n_tensors fp32 tensors.  tensors: HOST array (read during the call: by-value kernel arguments); hyper: DEVICE float
+ * table, {lr, weight_decay} per entry, tensors[i].hyper indexes it (a learning-rate schedule writes the table, captured launches read the
+ * new values); state: DEVICE int[2], zeroed by the caller once: state[0] counts the steps taken (bias corrections), state[1] is a
+ * ticket that is zero between launches.  More than VLSA_ADAM_MAX_TENSORS tensors go out as several launches; the last advances the count.
+ */
+#define VLSA_ADAM_MAX_TENSORS 16
+typedef struct vlsa_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    int hyper;
+} vlsa_adam_tensor;
+int vlsa_adam_step(const vlsa_adam_tensor* tensors, int n_tensors, const float* hyper, int* state, double beta1, double beta2, double eps,
+                   void* stream);
 
 /* ---- text side: the frozen CoCa text tower on the prompts' compact rows -------------------------- */
 

@@ -60,6 +60,25 @@ def test_objective_from_raw_logits(B, K, extreme):
     got.backward()
     assert abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
     assert (xd.grad.cpu() - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
+    # round 6: the raw (log) logit scale handed over instead, exponentiated inside the launch; an upstream factor on the scalar; and the
+    # route of batches beyond one block's reach (B > 4096 falls back to the per-sample kernel + torch mean: same numbers)
+    xd2 = logits.cuda().requires_grad_(True)
+    got2 = SurvObjective()(xd2, t.cuda(), e.cuda(), log_logit_scale=torch.tensor(cases.LOGIT_SCALE).cuda())
+    (3.0 * got2).backward()
+    assert abs(got2.item() - got.item()) < 2e-6 * max(1.0, abs(got.item()))
+    assert (xd2.grad - 3.0 * xd.grad).abs().max().item() < 1e-5 * max(1.0, xd.grad.abs().max().item())
+
+
+def test_objective_of_a_large_batch_takes_the_per_sample_route():
+    from vlsa_amd.losses import SurvObjective
+    logits, t, e = _inputs(5000, 6, 2999, False)
+    tail = 1.0 - torch.cumsum(torch.softmax(logits.double(), dim=-1), dim=-1).gather(1, t.view(-1, 1)).view(-1)
+    e = torch.where((e == 0) & (tail < 1e-4), torch.ones_like(e), e)
+    ls = torch.tensor(cases.LOGIT_SCALE).exp()
+    ref = O.vlsa_objective(logits, t, e, ls)
+    got = SurvObjective()(logits.cuda(), t.cuda(), e.cuda(), cur_logit_scale=ls.cuda())
+    got_log = SurvObjective()(logits.cuda(), t.cuda(), e.cuda(), log_logit_scale=torch.tensor(cases.LOGIT_SCALE).cuda())
+    assert abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item())) and abs(got_log.item() - got.item()) < 2e-6 * max(1.0, abs(got.item()))
 
 
 @pytest.mark.parametrize("alpha", [0.0, 0.3])

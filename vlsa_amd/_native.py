@@ -23,6 +23,13 @@ TT_PERSISTENT = 0x100      # vlsa_tt_forward: or-ed into save_for_backward (VLSA
 P_STRIDE = 16
 
 
+ADAM_MAX_TENSORS = 16
+
+
+class AdamTensor(ctypes.Structure):        # vlsa_adam_tensor
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64), ("hyper", c_int)]
+
+
 class VlsaNativeError(RuntimeError):
     pass
 
@@ -95,6 +102,9 @@ _SIGNATURES = {
     "vlsa_pack_rows_bf16": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "vlsa_surv_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_int, c_int,
                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "vlsa_surv_objective": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_float, c_int, c_int,
+                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "vlsa_adam_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "vlsa_gated_prep_bytes": (c_size_t, [c_int]),
     "vlsa_prepare_gated_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_void_p, c_void_p]),

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvlsa_hip.so")
-SOURCES = ["vlfan_partial.hip", "vlfan_partial_dma.hip", "vlfan_batch.hip", "vlfan_batch_f32.hip", "vlfan_backward.hip", "vlfan_backward_batch.hip", "vlfan_backward_batch_f32.hip", "vlfan_tail.hip", "mil_pool.hip", "ingest.hip", "surv_loss.hip", "gated_scores.hip", "gated_scores_tile.hip", "feat_proj.hip", "text_tower.hip", "prompt_sentences.hip", "mlp_backward.hip", "vlfan_dx.hip", "xchg.hip"]
+SOURCES = ["vlfan_partial.hip", "vlfan_partial_dma.hip", "vlfan_batch.hip", "vlfan_batch_f32.hip", "vlfan_backward.hip", "vlfan_backward_batch.hip", "vlfan_backward_batch_f32.hip", "vlfan_tail.hip", "mil_pool.hip", "ingest.hip", "surv_loss.hip", "adam.hip", "gated_scores.hip", "gated_scores_tile.hip", "feat_proj.hip", "text_tower.hip", "prompt_sentences.hip", "mlp_backward.hip", "vlfan_dx.hip", "xchg.hip"]
 HEADERS = ["vlsa_common.h", "vlfan_mfma_common.h", "gated_scores.h", os.path.join("..", "..", "include", "vlsa_hip.h")]
 
 

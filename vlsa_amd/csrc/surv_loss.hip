@@ -20,10 +20,19 @@ __global__ __launch_bounds__(kLossThreads) void k_surv_loss(const float* __restr
                                                    const float* __restrict__ logit_scale_exp, float alpha, float eps, int p,
                                                    int raw_distance, float w_ifmle, float w_emd,
                                                    float* __restrict__ out_ifmle, float* __restrict__ out_emd,
-                                                   float* __restrict__ grad) {
+                                                   float* __restrict__ grad, float* __restrict__ objective, int ls_is_log) {
+    // objective != null (round 6, ONE block launched): the block walks the batch in chunks of 32 samples and also writes the scalar
+    // objective[0] = mean_i (w_ifmle ifmle_i + w_emd emd_i) -- the handler's calc_objective_loss for 'mean'-reduced losses
+    // (runner/vlsa_handler.py:241-258) -- and `grad` comes out scaled by 1 / B (the gradient of that mean): the five elementwise /
+    // reduction launches behind the per-sample values were 25 us of a 1.7 ms optimizer step.  ls_is_log: logit_scale_exp points at the
+    // RAW (log) logit scale parameter and is exponentiated here (saves the step's `logit_scale.exp()` launch).
     __shared__ float sm[5][VLSA_MAX_K][kLossThreads];
-    const int i = blockIdx.x * kLossThreads + threadIdx.x;
-    if (i >= B) return;
+    float obj_acc = 0.f;
+    const int n_chunks = objective != nullptr ? (B + kLossThreads - 1) / kLossThreads : 1;
+    const float gscale = objective != nullptr ? 1.f / (float)B : 1.f;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const int i = (objective != nullptr ? chunk : (int)blockIdx.x) * kLossThreads + threadIdx.x;
+    if (i >= B) continue;
     const LossVec inc{&sm[0][0][threadIdx.x]}, g{&sm[1][0][threadIdx.x]};
     const float* xi = x + (size_t)i * K;
     int t = (int)t_[i];
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(kLossThreads) void k_surv_loss(const float* __restr
     // ---- SurvEMD on y = incidence
     float l_emd = 0.f;
     if (w_emd != 0.f || out_emd != nullptr) {
-        const float ls = logit_scale_exp[0];
+        const float ls = ls_is_log ? expf(logit_scale_exp[0]) : logit_scale_exp[0];
         const int ei = (int)e;  // e.long() of the reference
         const LossVec pd{&sm[2][0][threadIdx.x]}, td{&sm[3][0][threadIdx.x]}, dp{&sm[4][0][threadIdx.x]};
         float mp = -INFINITY, mt = -INFINITY;
@@ -103,15 +112,24 @@ __global__ __launch_bounds__(kLossThreads) void k_surv_loss(const float* __restr
 
     if (out_ifmle != nullptr) out_ifmle[i] = l_ifmle;
     if (out_emd != nullptr) out_emd[i] = l_emd;
+    obj_acc += w_ifmle * l_ifmle + w_emd * l_emd;
     if (grad != nullptr) {
         float* gi = grad + (size_t)i * K;
         if (from_logits) {  // softmax backward to the raw logits
             float dot = 0.f;
             for (int k = 0; k < K; ++k) dot += inc[k] * g[k];
-            for (int k = 0; k < K; ++k) gi[k] = inc[k] * (g[k] - dot);
+            for (int k = 0; k < K; ++k) gi[k] = gscale * (inc[k] * (g[k] - dot));
         } else {
-            for (int k = 0; k < K; ++k) gi[k] = g[k];
+            for (int k = 0; k < K; ++k) gi[k] = gscale * g[k];
         }
+    }
+    }   // chunk
+    if (objective != nullptr) {
+        // fixed-order sum over the 32 lanes (lanes without a sample hold 0): deterministic
+        float s = obj_acc;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+        if (threadIdx.x == 0) objective[0] = s / (float)B;
     }
 }
 
@@ -126,6 +144,20 @@ extern "C" int vlsa_surv_loss(const float* x, const int64_t* t, const float* e, 
     if ((w_emd != 0.f || out_emd) && !logit_scale_exp) return VLSA_EINVAL;
     if (p != 1 && p != 2) return VLSA_EUNSUPPORTED;
     hipLaunchKernelGGL(k_surv_loss, dim3((B + kLossThreads - 1) / kLossThreads), dim3(kLossThreads), 0, (hipStream_t)stream, x, t, e, B, K, from_logits, logit_scale_exp,
-                       alpha, eps, p, raw_distance, w_ifmle, w_emd, out_ifmle, out_emd, grad);
+                       alpha, eps, p, raw_distance, w_ifmle, w_emd, out_ifmle, out_emd, grad, (float*)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
+}
+
+// The handler's whole objective (runner/vlsa_handler.py:241-258 with 'mean'-reduced SurvIFMLE + SurvEMD) from the raw logits in ONE
+// launch: objective[0] = mean_i (w_ifmle ifmle_i + w_emd emd_i), grad [B, K] = d objective / d x.  logit_scale: the EXPONENTIATED scale
+// (ls_is_log == 0, the reference's `net.get_logit_scale()`) or the raw parameter (ls_is_log != 0).  B <= 4096 (one block walks the batch).
+extern "C" int vlsa_surv_objective(const float* x, const int64_t* t, const float* e, int B, int K, int from_logits, const float* logit_scale,
+                                   int ls_is_log, float alpha, float eps, int p, int raw_distance, float w_ifmle, float w_emd,
+                                   float* objective, float* grad, void* stream) {
+    if (!x || !t || !e || !objective || B < 1 || B > 4096 || K < 1 || K > VLSA_MAX_K) return VLSA_EINVAL;
+    if (w_emd != 0.f && !logit_scale) return VLSA_EINVAL;
+    if (p != 1 && p != 2) return VLSA_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_surv_loss, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, x, t, e, B, K, from_logits, logit_scale, alpha, eps, p,
+                       raw_distance, w_ifmle, w_emd, (float*)nullptr, (float*)nullptr, grad, objective, ls_is_log);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
 }

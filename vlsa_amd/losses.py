@@ -52,6 +52,34 @@ class _SurvLossFn(torch.autograd.Function):
         return (dl.reshape(-1, 1) * g,) + (None,) * 10
 
 
+class _SurvObjectiveFn(torch.autograd.Function):
+    """mean_i (w_ifmle ifmle_i + w_emd emd_i) from the raw logits: ONE launch forward (``vlsa_surv_objective``: value, gradient and the
+    mean over the batch; optionally the exp of the raw logit scale), one multiplication backward."""
+
+    @staticmethod
+    def forward(ctx, x, t, e, ls, ls_is_log, alpha, eps, p, raw, w_ifmle, w_emd):
+        _need_gpu(x)
+        lib = nat.load()
+        x = x.detach().float().contiguous()
+        B, K = x.shape
+        t = t.reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
+        e = e.reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+        if t.numel() != B or e.numel() != B:
+            raise ValueError("t and e must hold one entry per sample")
+        ls = ls.detach().to(device=x.device, dtype=torch.float32).reshape(1).contiguous()
+        out = torch.empty(1 + B * K, dtype=torch.float32, device=x.device)      # objective | gradient: one allocation
+        g = out[1:].view(B, K)
+        nat.check(lib.vlsa_surv_objective(_p(x), _p(t), _p(e), B, K, 1, _p(ls), int(ls_is_log), float(alpha), float(eps), int(p), int(raw),
+                                          float(w_ifmle), float(w_emd), _p(out), _p(g), _stream()), "vlsa_surv_objective")
+        ctx.save_for_backward(g)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dl):
+        (g,) = ctx.saved_tensors
+        return (dl * g,) + (None,) * 10
+
+
 def _reduce(loss, reduction):
     if reduction == "mean":
         return loss.mean()
@@ -99,8 +127,15 @@ class SurvObjective(nn.Module):
             raise NotImplementedError("the fused kernel covers p = 1 and p = 2")
         self.w1, self.w2, self.alpha, self.eps, self.p, self.raw = weight_ifmle, weight_emd, alpha, eps, p, raw_distance
 
-    def forward(self, raw_pred, t, e=None, cur_logit_scale=10.0):
+    def forward(self, raw_pred, t, e=None, cur_logit_scale=10.0, log_logit_scale=None):
+        """cur_logit_scale: exp(logit_scale) as the handler passes it (``net.get_logit_scale()``); log_logit_scale: the raw parameter
+        instead (exponentiated inside the launch: one kernel less per step; no gradient flows into it either way -- the reference detaches it)."""
         if e is None:
             t, e = t[:, 0], t[:, 1]
-        loss = _SurvLossFn.apply(raw_pred, t, e, cur_logit_scale, True, self.alpha, self.eps, self.p, self.raw, self.w1, self.w2)
+        ls, is_log = (log_logit_scale, True) if log_logit_scale is not None else (cur_logit_scale, False)
+        if isinstance(ls, torch.Tensor) and raw_pred.is_cuda and raw_pred.dim() == 2 and raw_pred.shape[0] <= 4096:
+            return _SurvObjectiveFn.apply(raw_pred, t, e, ls, is_log, self.alpha, self.eps, self.p, self.raw, self.w1, self.w2)
+        if is_log:
+            ls = ls.detach().exp() if isinstance(ls, torch.Tensor) else float(torch.tensor(ls).exp())
+        loss = _SurvLossFn.apply(raw_pred, t, e, ls, True, self.alpha, self.eps, self.p, self.raw, self.w1, self.w2)
         return loss.mean()

@@ -48,6 +48,8 @@ class TrainStep:
         self.net, self.objective, self.opt = net, objective, optimizer
         self.dist, self.group, self.world = dist, group, int(world)
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        from .losses import SurvObjective
+        self._obj_takes_log = isinstance(objective, SurvObjective)
         self.graph_enabled = bool(graph) and self.world == 1 and self._capturable()
         self.max_graphs, self.capture_after = int(max_graphs), int(capture_after)
         self._seen = OrderedDict()          # batch key -> eager steps seen
@@ -65,7 +67,10 @@ class TrainStep:
     def _eager(self, bags, t, e):
         net = self.net
         logits = net.forward_bags(bags)[0]
-        loss = self.objective(logits, t, e, net.get_logit_scale())
+        if self._obj_takes_log:         # vlsa_amd.losses.SurvObjective: the exp of the logit scale happens inside its one launch
+            loss = self.objective(logits, t, e, log_logit_scale=net.logit_scale)
+        else:
+            loss = self.objective(logits, t, e, net.get_logit_scale())
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         if self.world > 1:
@@ -145,6 +150,9 @@ class TrainStep:
     def _replay(self, key):
         g, loss, _ = self._graphs[key]
         self._graphs.move_to_end(key)
+        sync = getattr(self.opt, "sync_hyper", None)
+        if sync is not None:
+            sync()                                      # vlsa_amd.optim.FusedAdam: a changed learning rate reaches the device table
         g.replay()
         _bump_versions(self.params)                     # what optimizer.step() does to the version counters, without a kernel
         self.net._drop_text_cache()                     # (the capture left the text cache pointing at a graph-owned tensor)
