@@ -163,6 +163,10 @@ int vlsa_vlfan_forward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, i
                            float* pacc, int G, float* m2, float* l, float* out, float* scores, float* A, void* head_ws,
                            float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
 
+/* dQ [nq, D] from dE [P, D] = d loss / d (effective unit queries): the chain rule through q^ = q / max(|q|, 1e-12) and, with a gated
+ * query, e_p = q^_p - q^_gate (model/deepmil.py:187-193), read off a block of vlsa_prepare_queries.  One launch, nq workgroups. */
+int vlsa_query_chain(const float* dE, const void* qprep, int nq, int gated, int D, float* dQ, void* stream);
+
 /* The per-bag backward of the same step -- what autograd runs per bag behind `torch.cat([net(x)[0] for x in bags])` in the
  * reference's training loop (runner/vlsa_handler.py:267-289; model/vlsa.py:181-198, model/deepmil.py:187-204 differentiated) --
  * as ONE host call: vlsa_head_backward_batch (B = 1) -> d rows, dW, db, dT, d logit_scale; vlsa_vlfan_backward + the

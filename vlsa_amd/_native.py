@@ -104,6 +104,7 @@ _SIGNATURES = {
                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_surv_objective": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_float, c_int, c_int,
                                     c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "vlsa_query_chain": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "vlsa_adam_step": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p]),
     "vlsa_gated_prep_bytes": (c_size_t, [c_int]),
     "vlsa_prepare_gated_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

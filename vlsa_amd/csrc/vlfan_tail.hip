@@ -1085,6 +1085,20 @@ __global__ __launch_bounds__(256) void k_query_chain(const float* __restrict__ d
 }
 }  // namespace vlsa
 
+// dQ [nq, D] from dE [P, D] (the gradient w.r.t. the effective unit queries e_p = q^_p - gated q^_gate) and a prepared query block:
+// the chain rule through the normalisation (and the gate row) in one launch -- the batched aggregation's backward ran it as five torch
+// kernels ([P, 512] mul / sum / mul / sub / div: 25 us of the graph-replayed optimizer step).
+extern "C" int vlsa_query_chain(const float* dE, const void* qprep, int nq, int gated, int D, float* dQ, void* stream) {
+    if (!dE || !qprep || !dQ || nq < 1 || nq > VLSA_MAX_P + 1 || D < 1 || D > VLSA_MAX_D) return VLSA_EINVAL;
+    const int P = gated ? nq - 1 : nq;
+    if (P < 1) return VLSA_EINVAL;
+    const vlsa::QPrepLayout L(D);
+    const unsigned char* qp = static_cast<const unsigned char*>(qprep);
+    hipLaunchKernelGGL(vlsa::k_query_chain, dim3(nq), dim3(256), 0, (hipStream_t)stream, dE, reinterpret_cast<const float*>(qp + L.qhat),
+                       reinterpret_cast<const float*>(qp + L.qnorm), P, D, dQ);
+    return launch_status();
+}
+
 extern "C" int vlsa_vlfan_backward_bag(const void* X, int x_dtype, int64_t N, int64_t ldx, int D, const void* qprep, int nq, int gated,
                                        float coattn_scale, const float* dlogits, const float* g_vhat, const float* g_That,
                                        const float* pooled, const float* vhat, const float* vnorm, const float* That,

@@ -907,10 +907,9 @@ class _VlfanBatchAggregateFn(torch.autograd.Function):
             nat.check(lib.vlsa_vlfan_backward_bags(_p(table.desc), B, table.dt, D, _p(qbuf), P, scale, _p(dout), _p(out), _p(m2),
                                                    _p(l), _p(prep), _p(pm), _p(pl), _p(pacc), G, s), "vlsa_vlfan_backward_bags")
             _, _, dE = vlfan_merge(pm, pl, pacc, normalise=False)
-        qp = PreparedQueries(qbuf, nq, P, D, gated)
-        qhat, qnorm = qp.qhat, qp.qnorm
-        dqh = torch.cat([dE, -dE.sum(dim=0, keepdim=True)], dim=0) if gated else dE
-        dQ = (dqh - qhat * (dqh * qhat).sum(dim=-1, keepdim=True)) / qnorm[:, None]
+        # chain rule to the raw queries (normalisation + gate row) in one launch (round 6; was five torch kernels on [P, 512])
+        dQ = torch.empty(nq, D, dtype=torch.float32, device=dev)
+        nat.check(lib.vlsa_query_chain(_p(dE.contiguous()), _p(qbuf), nq, int(gated), D, _p(dQ), s), "vlsa_query_chain")
         dxs = [None] * len(ctx.xshapes)         # (a BagSet's bags are not autograd inputs: none)
         if any(ctx.needs_input_grad[5:]):           # bags that carry a gradient (projected by a trainable Feat_Projecter)
             got = _vlfan_dx(table.bags, qbuf, P, scale, dout, out, m2, l)

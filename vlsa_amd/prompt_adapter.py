@@ -176,7 +176,9 @@ class PromptAdapter(nn.Module):
         if self.method == "Adapter":
             return (1 - self.keep_ratio) * self.adapter(pf) + self.keep_ratio * pf
         if self.method == "TaskRes":
-            out = self.res_ratio * self.residual_features + pf
+            # (one launch each way: pf + ratio * residual -- with the shipped ratio 0.5 the product is exact, so the fused form equals
+            # the reference's `res_ratio * residual + features` bit for bit; otherwise within one ulp)
+            out = torch.add(pf, self.residual_features, alpha=self.res_ratio)
             if has_neg:
                 neg = self.neg_prompt_features.clone()
                 if self.neg_residual_features is not None:
