@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): full GPU test suite, bench lines, rocprofv3 kernel stats of the bench command, separate PMC
-# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/r05/ (copied into profiles/ afterwards).
+# passes for the dominant kernels, and the per-path benches.  Outputs under gpurun_out/${VLSA_ROUND:-r06}/ (copied into profiles/ afterwards).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${VLSA_ROUND:-r06}; mkdir -p $O
 (VLSA_GRAD_ERRORS_OUT=$O/grad_errors.txt timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/pytest_gpu.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2>> $O/bench.err
@@ -96,6 +96,17 @@ cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/train_batch_kernel_st
 python tools/bench_attn.py > $O/bench_attn.txt 2>&1
 python tools/bench_attn.py 50000 fp32 2>&1 | grep want_attn >> $O/bench_attn.txt
 python tools/bench_step.py > $O/bench_step.txt 2>&1
+# round 6: the bench.py train_step leg alone (BASELINE configs[4]): hipGraph replay (default) and eager, and the per-step kernel list
+(VLSA_BENCH_TRAIN_MODE=graph python tools/bench_train_step.py both 30) > $O/bench_train_step_graph.txt 2>&1
+(VLSA_BENCH_TRAIN_MODE=eager python tools/bench_train_step.py both 30) > $O/bench_train_step_eager.txt 2>&1
+VLSA_BENCH_TRAIN_MODE=graph rocprofv3 --kernel-trace --output-format csv -d $O/prof_step -- python tools/bench_train_step.py tcga 60 > /dev/null 2>&1
+python tools/step_kernels.py $O/prof_step > $O/step_kernels.txt 2>&1; rm -rf $O/prof_step
+# round 6: one slide per call -- wall / host per call, the GPU chain from a trace, shader-cycle stamps of the streaming kernel
+python tools/prof_single_slide.py 2>&1 | grep "N=" > $O/single_slide.txt
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_ss -- python tools/prof_single_slide.py 50k > /dev/null 2>&1
+python tools/trace_single_slide.py $O/trace_ss >> $O/single_slide.txt 2>&1; rm -rf $O/trace_ss
+python tools/kbench_tail.py 2>&1 | tail -3 >> $O/single_slide.txt
+[ -f vlsa_amd/_lib/variants/libvlsa_dmatiming.so ] && python tools/dma_stamps.py 2>&1 | grep -v amdgpu > $O/dma_stamps.txt
 python tools/bench_epoch.py 2>&1 | grep -v amdgpu > $O/bench_epoch.txt
 python tools/bench_train.py > $O/bench_train.txt 2>&1
 python tools/kbench_batch_f32.py 2>&1 | grep "N=" > $O/kbench_batch_f32.txt
@@ -104,7 +115,7 @@ python tools/kbench_wide.py 50000 20000 2>&1 | grep "bfloat" > $O/kbench_wide_50
 python tools/kbench_gated.py > $O/kbench_gated.txt 2>&1
 # round 5: the persistent LDS-DMA score kernel next to k_gated_scores on this box, its timing-only ablations and cycle stamps (variant
 # libraries: `python tools/gt_ablate.py build; python tools/gt_stamps.py build` in the CPU container), its counters
-(echo "default (k_scores_tile_p for gated bf16 bags >= 16 384 rows):"; python tools/gt_ablate.py child; echo "VLSA_GS_TILE=0 (k_gated_scores everywhere):"; VLSA_GS_TILE=0 python tools/gt_ablate.py child; echo "VLSA_GS_TILE=1 (k_scores_tile_p for both modules):"; VLSA_GS_TILE=1 python tools/gt_ablate.py child; echo "timing-only ablations of k_scores_tile_p:"; VLSA_GS_TILE=1 python tools/gt_ablate.py) 2>&1 | grep -v amdgpu > $O/gt_ab.txt
+# (the kernel-choice A/B through VLSA_GS_TILE needs a -DVLSA_EXPERIMENT build since round 6: profiles/r05_gt_ab.txt is the record)
 [ -f vlsa_amd/_lib/variants/libvlsa_gtstamp.so ] && python tools/gt_stamps.py 393216 gated 2>&1 | grep -v amdgpu > $O/gt_stamps.txt
 bash tools/pmc_tile.sh 393216 gated > /dev/null 2>&1
 [ -f tools/probes/libmfma_issue.so ] && python tools/probes/mfma_issue.py 2>&1 | grep -v amdgpu > $O/mfma_issue.txt

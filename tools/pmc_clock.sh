@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: shader clock of k_scores_tile and of its timing-only ablations (GRBM_GUI_ACTIVE cycles / kernel duration)
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${VLSA_ROUND:-r06}; mkdir -p $O
 for v in 0 ${GT_ONLY:-6 22}; do
   lib=vlsa_amd/_lib/variants/libvlsa_gt$v.so; [ $v = 0 ] && lib=vlsa_amd/_lib/libvlsa_hip.so
   [ -f $lib ] || continue

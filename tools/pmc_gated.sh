@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): PMC passes of the fragment-order attention-score kernel k_gated_scores alone (gated and ungated
 # module, N patches per bag; VLSA_GS_TILE=0: the persistent LDS-DMA kernel has its own script, tools/pmc_tile.sh):
-# gpurun_out/r05/pmc_scores_<gated|ungated>_<N>.json
+# gpurun_out/${VLSA_ROUND:-r06}/pmc_scores_<gated|ungated>_<N>.json
 export VLSA_GS_TILE=0
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${VLSA_ROUND:-r06}; mkdir -p $O
 N=${1:-393216}     # 12 whole rounds of the gated kernel: one launch per call
 pmc() { tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
   rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2>&1; }

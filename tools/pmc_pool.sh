@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): HBM bytes fetched per 50k-patch bag by scores + pooling, one launch against two (FETCH_SIZE alone in
-# its pass, per kernel, averaged over the launches after the first 12): gpurun_out/r05/pmc_pool_traffic.json
+# its pass, per kernel, averaged over the launches after the first 12): gpurun_out/${VLSA_ROUND:-r06}/pmc_pool_traffic.json
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${VLSA_ROUND:-r06}; mkdir -p $O
 N=${1:-50000}
 for m in one two; do
   timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_pool_$m -- python tools/run_gated_pool.py $N $m > /dev/null 2>&1

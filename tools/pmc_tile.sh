@@ -1,8 +1,8 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): PMC passes of k_scores_tile alone (gated_scores_tile.hip): gpurun_out/r05/pmc_tile_<gated|ungated>_<N>.json
+# Run ON THE GPU BOX (via gpurun): PMC passes of k_scores_tile alone (gated_scores_tile.hip): gpurun_out/${VLSA_ROUND:-r06}/pmc_tile_<gated|ungated>_<N>.json
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${VLSA_ROUND:-r06}; mkdir -p $O
 N=${1:-393216}
 MODS=${2:-gated ungated}
 pmc() { tag=$1; shift; ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
