@@ -5,8 +5,9 @@
   2. the text side: ordinal rank prompts (`RankPromptLearner`) through a (small, random-weight) CoCa-style text tower
      (`CONCHPromptEncoder`, HIP forward + backward) -> the K text features; evaluation: 32 patients per launch through
      `VLSA.forward_bags` (persistent multi-bag HIP kernels)
-  3. a few optimizer steps: text tower once per step, batched HIP forward + backward of the aggregation, IF-MLE + EMD loss in
-     one kernel, Adam on the context / rank embeddings, the text queries' residual and the logit scale
+  3. a few optimizer steps through `TrainStep`: text tower once per step, batched HIP forward + backward of the aggregation, IF-MLE +
+     EMD objective in one kernel, one-launch Adam on the context / rank embeddings, the text queries' residual and the logit scale; a
+     batch that repeats is replayed as one hipGraph
   4. interpretation of one slide (`calc_text_img_similarity`)
 
     python examples/synthetic_demo.py [--patients 64] [--steps 5]
@@ -25,9 +26,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vlsa_amd.inference import calc_text_img_similarity  # noqa: E402
 from vlsa_amd.ingest import ArenaLayout, DeviceBagArena  # noqa: E402
 from vlsa_amd.losses import SurvObjective  # noqa: E402
+from vlsa_amd.optim import FusedAdam  # noqa: E402
 from vlsa_amd.prompt_adapter import PromptAdapter  # noqa: E402
 from vlsa_amd.prompt_encoder import CONCHPromptEncoder  # noqa: E402
 from vlsa_amd.prompt_learner import RankPromptLearner  # noqa: E402
+from vlsa_amd.train_step import TrainStep  # noqa: E402
 from vlsa_amd.vlsa import VLSA  # noqa: E402
 
 
@@ -57,7 +60,7 @@ class ToyTokenizer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--patients", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
@@ -109,16 +112,20 @@ def main():
     t_bin = torch.randint(0, K, (len(pids),), generator=g).to(dev)
     event = (torch.rand(len(pids), generator=g) < 0.5).float().to(dev)
     objective = SurvObjective()
-    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-4)
+    trainable = [p for p in net.parameters() if p.requires_grad]
+    # the handler's optimizer (optim_factory.py:25-37: no weight decay on 1-D parameters) as ONE launch; the step itself owned by TrainStep:
+    # a batch seen for the third time is replayed as one hipGraph (forward_bags, objective, backward, Adam)
+    opt = FusedAdam([{"params": [p for p in trainable if p.dim() < 2], "weight_decay": 0.0},
+                     {"params": [p for p in trainable if p.dim() >= 2], "weight_decay": 1e-5}], lr=2e-4)
+    stepper = TrainStep(net, objective, opt)
     net.train()
+    groups = [torch.randperm(len(pids), generator=g)[:32] for _ in range(2)]          # two fixed 32-patient batches, visited in turn
+    batches = [([arena.bag(pids[int(i)]) for i in idx], t_bin[idx.to(dev)], event[idx.to(dev)]) for idx in groups]
     for step in range(a.steps):
-        idx = torch.randperm(len(pids), generator=g)[:32].tolist()
-        out = net.forward_bags([arena.bag(pids[i]) for i in idx])[0]      # batched HIP forward, saved for the batched backward
-        loss = objective(out, t_bin[idx], event[idx], net.get_logit_scale())
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+        bags, tb, ev = batches[step % 2]
+        loss = stepper.step(bags, tb, ev)
         print(f"[train]  step {step}: loss {loss.item():.4f}")
+    print(f"[train]  {stepper.describe()}")
 
     # 4. interpretation -----------------------------------------------------------------------------------------------
     net.eval()

@@ -503,6 +503,19 @@ def slide_train(X2: torch.Tensor, Q: torch.Tensor, W, b, T: torch.Tensor, logit_
     return _SlideTrainFn.apply(X2, plan.step_params(Q, W, b, T, logit_scale), plan)
 
 
+_PARTIALS = {}
+
+
+def _partials_of(N: int) -> int:
+    """vlsa_num_partials(N), kept per size (one ctypes call per new size instead of one per bag)"""
+    g = _PARTIALS.get(N)
+    if g is None:
+        if len(_PARTIALS) > 1 << 16:
+            _PARTIALS.clear()
+        g = _PARTIALS[N] = int(nat.load().vlsa_num_partials(N))
+    return g
+
+
 class VlfanInferencePlan:
     """Pre-allocated buffers + raw C-ABI calls for the fused inference forward of one bag shape.
 
@@ -519,7 +532,12 @@ class VlfanInferencePlan:
         self.lib, self.N, self.D, self.P, self.K = lib, N, D, P, K
         self.gated, self.pool, self.kernel, self.scale = gated, _POOL_CODES[pool], kernel, float(coattn_scale)
         self.identity_head = identity_head
-        self.G = num_partials(N)
+        # N = None (round 6): a plan for bags of ANY size -- scratch for the largest partial count (256 records of P x 512: 6.3 MB at
+        # P = 12), N and G taken from the bag at every run.  The reference's slides all differ in size (2k - 12k patches at TCGA): a plan
+        # per size made `VLSA`'s plan / hot-call caches thrash in exactly the loop they exist for.  (Not with `want_attn`: [P, N] buffers.)
+        if N is None and want_attn:
+            raise ValueError("an any-size inference plan cannot hold attention weights: give N")
+        self.G = num_partials(N if N is not None else (1 << 40))
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
         self.qprep = torch.empty(lib.vlsa_qprep_bytes(D), dtype=torch.uint8, device=device)
         self.pm, self.pl, self.pacc = f(self.G, nat.P_STRIDE), f(self.G, nat.P_STRIDE), f(self.G, P, D)
@@ -546,6 +564,7 @@ class VlfanInferencePlan:
         lib, s, k = self.lib, _stream(), self._c
         reuse = params_key is not None and params_key == getattr(self, "_params_key", None)
         self._params_key = None          # set again once the call that prepares this key has returned OK
+        N_, G_ = (self.N, self.G) if self.N is not None else (X.shape[0], _partials_of(X.shape[0]))
         if outs:
             k = dict(k)
             for name, t in outs.items():
@@ -555,10 +574,10 @@ class VlfanInferencePlan:
         nq = self.P + 1 if self.gated else self.P
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
         # one Python -> C crossing for the five launches (this path is host-bound: the handler calls it bag by bag)
-        nat.check(lib.vlsa_vlfan_forward_bag(_p(X), dt, self.N, X.stride(0), self.D, None if reuse else _p(Q), nq, int(self.gated), self.scale, _p(T),
+        nat.check(lib.vlsa_vlfan_forward_bag(_p(X), dt, N_, X.stride(0), self.D, None if reuse else _p(Q), nq, int(self.gated), self.scale, _p(T),
                                              self.K, _p(logit_scale), -1 if query_pool_module is not None else self.pool, _p(pool_w),
                                              None if self.identity_head else _p(W), None if self.identity_head else _p(b),
-                                             self.kernel, k["qprep"], k["That"], k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G,
+                                             self.kernel, k["qprep"], k["That"], k["tnorm"], k["pm"], k["pl"], k["pacc"], G_,
                                              k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"], k["v"], k["vhat"],
                                              k["vnorm"], k["logits"], k["incidence"], s), "vlsa_vlfan_forward_bag")
         self._params_key = params_key
@@ -585,19 +604,24 @@ class VlfanInferencePlan:
         fn_c = lib.vlsa_vlfan_forward_bag
         dt_code = {torch.float32: nat.DT_F32, torch.bfloat16: nat.DT_BF16}
         N, D, K = self.N, self.D, self.K
+        any_n = N is None
         nq = self.P + 1 if self.gated else self.P
-        args = [None, 0, N, 0, D, None, nq, int(self.gated), self.scale, _p(T), K, _p(logit_scale), self.pool, _p(pool_w),
+        args = [None, 0, N or 0, 0, D, None, nq, int(self.gated), self.scale, _p(T), K, _p(logit_scale), self.pool, _p(pool_w),
                 None if self.identity_head else _p(W), None if self.identity_head else _p(b), self.kernel, k["qprep"], k["That"],
                 k["tnorm"], k["pm"], k["pl"], k["pacc"], self.G, k["m2"], k["l"], k["out"], k["scores"], k["A"], k["ws"], k["pooled"],
                 k["v"], None, k["vnorm"], None, k["incidence"], None]
-        I_X, I_DT, I_LD, I_VHAT, I_LOGITS, I_STREAM = 0, 1, 3, 32, 34, 36
+        I_X, I_DT, I_N, I_LD, I_G, I_VHAT, I_LOGITS, I_STREAM = 0, 1, 2, 3, 23, 32, 34, 36
         empty, cur = torch.empty, torch.cuda.current_stream
+        partials = _partials_of
 
         def fn(X):
             dev = X.device
             logits = empty((1, K), dtype=torch.float32, device=dev)
             vhat = empty((1, D), dtype=torch.float32, device=dev)
             a = args
+            if any_n:
+                n = X.shape[1]
+                a[I_N], a[I_G] = n, partials(n)
             a[I_X], a[I_DT], a[I_LD] = X.data_ptr(), dt_code[X.dtype], X.stride(1)
             a[I_VHAT], a[I_LOGITS], a[I_STREAM] = vhat.data_ptr(), logits.data_ptr(), cur(dev).cuda_stream
             rc = fn_c(*a)
@@ -610,7 +634,7 @@ class VlfanInferencePlan:
     def run_partial_only(self, X: torch.Tensor):
         """Just the streaming kernel (for roofline timing); queries must have been prepared by a run()."""
         dt = nat.DT_F32 if X.dtype == torch.float32 else nat.DT_BF16
-        nat.check(self.lib.vlsa_vlfan_partial(_p(X), dt, self.N, X.stride(0), self.D, _p(self.qprep), self.P,
+        nat.check(self.lib.vlsa_vlfan_partial(_p(X), dt, self.N if self.N is not None else X.shape[0], X.stride(0), self.D, _p(self.qprep), self.P,
                                               self.kernel, _p(self.pm), _p(self.pl), _p(self.pacc),
                                               _p(self.scores), _stream()), "vlfan_partial")
 

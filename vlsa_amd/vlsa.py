@@ -221,7 +221,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         else:
             self.logit_scale = nn.Parameter(torch.ones([]) * float(logit_scale))  # CoCa init, model/conch/coca_model.py:187
         self._plans = {}
-        self._hot = {}                 # (N, D, dtype, device) -> (eval state, pre-built per-bag call, row stride): see _fused_vlfan
+        self._hot = {}                 # (D, dtype, device) -> (eval state, pre-built per-bag call, row stride): see _fused_vlfan
         self._train_plans = {}
         self._provider_lists = {}                              # provider module -> (module, submodules, tensors, structure epoch)
         self._la = self._la_lists = None                      # look-ahead window + kept module / tensor lists (see _lookahead)
@@ -450,8 +450,9 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         # rewritten by every slow-path call of its plan, so its state is the one the plan's prepared block was computed under.
         hot = self._hot
         if hot and not ENV_NO_HOTCALL and type(X) is torch.Tensor and X.dim() == 3:
-            ent = hot.get((X.shape[1], X.shape[2], X.dtype, X.device))
-            if (ent is not None and X.shape[0] == 1 and X.stride(2) == 1 and X.stride(1) == ent[2]
+            ent = hot.get((X.shape[2], X.dtype, X.device))           # (any bag size: the plan behind it takes N from the bag)
+            if (ent is not None and X.shape[0] == 1 and X.shape[1] > 0 and X.stride(2) == 1 and X.stride(1) == ent[2]
+                    and (X.data_ptr() & 15) == 0
                     and self._same_state(ent[0], self._eval_state(text_features))):
                 return ent[1](X)
         enc = self.mil_encoder
@@ -470,7 +471,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
         K = text_features.shape[0]
         if not (1 <= P <= 16 and 1 <= K <= 64 and D % 8 == 0 and D <= 1024):
             return None
-        key = (N, D, P, K, X2.dtype, X2.device, enc.gated_query, mode, W is None)
+        key = (None, D, P, K, X2.dtype, X2.device, enc.gated_query, mode, W is None)     # one plan for every bag size (round 6)
         plan = self._plans.get(key)
         qmod = pw if mode == "module" else None
         if qmod is not None:
@@ -479,7 +480,7 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             if len(self._plans) > 64:
                 self._plans.clear()
                 self._hot.clear()
-            plan = VF.VlfanInferencePlan(N, D, P, K, X2.device, gated=enc.gated_query, pool="mean" if qmod is not None else mode,
+            plan = VF.VlfanInferencePlan(None, D, P, K, X2.device, gated=enc.gated_query, pool="mean" if qmod is not None else mode,
                                          identity_head=W is None, coattn_scale=float(enc.coattn_logit_scale.exp()))
             self._plans[key] = plan
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=X2.device)  # noqa: E731
@@ -504,10 +505,10 @@ class VLSA(VF.nat.TransientCaches, nn.Module):
             # the next bag of this shape under this state: the pre-built call (the prepared block of `plan` now belongs to this state)
             if len(self._hot) > 64:
                 self._hot.clear()
-            self._hot[(N, D, X2.dtype, X2.device)] = (self._eval_state(text_features),
+            self._hot[(D, X2.dtype, X2.device)] = (self._eval_state(text_features),
                                                      plan.hot_call(Tc, lsc, Wc, bc, pwc, outs["That"]), X2.stride(0))
         else:
-            self._hot.pop((N, D, X2.dtype, X2.device), None)
+            self._hot.pop((D, X2.dtype, X2.device), None)
         return outs["logits"], outs["vhat"], outs["That"]
 
     def _params_key(self, enc, Qsrc, text_features):
