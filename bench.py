@@ -859,7 +859,7 @@ def main():
             dist.all_reduce(lt)
             got = float(lt.item()) / world           # equal shares: the mean of the per-rank means = the batch mean
         ver = None
-        if rank == 0 and world == 1:
+        if True:       # every rank checks ITS share against the oracles (world > 1: the shares' means are averaged, as the losses are)
             from oracle import text_oracle as TO, vlsa_oracle as O
             t_or = time.perf_counter()
             E = Wt["token_embedding.weight"]
@@ -874,8 +874,13 @@ def main():
                 lg = torch.cat([O.vlsa_vlfan_forward(x.float().cpu(), Qo, Tf, lv["logit_scale"], head_weight=lv["W"], head_bias=lv["b"])["logits"]
                                 for x in bags])
                 want = float(O.vlsa_objective(lg, t_.cpu(), e_.cpu(), lv["logit_scale"].exp()))
+            if dist is not None and world > 1:
+                wt = torch.tensor([want], dtype=torch.float64)
+                dist.all_reduce(wt)
+                want = float(wt.item()) / world
             rel = abs(got - want) / max(1.0, abs(want))
-            ver = {"what": "loss of the last timed optimizer step vs oracle.text_oracle + vlsa_oracle.vlsa_objective on the parameters it started from",
+            ver = {"what": "loss of the last timed optimizer step" + (f" (mean over the {world} ranks' shares, each checked by its rank)" if world > 1 else "")
+                           + " vs oracle.text_oracle + vlsa_oracle.vlsa_objective on the parameters it started from",
                    "loss": got, "oracle_loss": want, "rel_diff": rel, "tolerance": 5e-5, "ok": rel < 5e-5,
                    "oracle_seconds": round(time.perf_counter() - t_or, 2)}
         npatch = sum(all_sizes)
@@ -959,10 +964,13 @@ def main():
                         "runs the text tower once per BAG on top (1.44 s per call on its CPU path, BASELINE.md)")
         return legs
 
-    if os.environ.get("VLSA_BENCH_ONLY_TRAIN") and world == 1:
+    if os.environ.get("VLSA_BENCH_ONLY_TRAIN") and (world == 1 or 32 % world == 0):      # (tools/bench_train_step.py: this leg alone)
         legs = train_legs()
-        emit({"train_step": legs})
+        emit({"train_step": legs, "n_gpus": world})
         bad = [k for k, v in legs.items() if isinstance(v, dict) and v.get("verified") and not v["verified"]["ok"]]
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         sys.exit(3 if bad else 0)
     if world == 1 and not force_sharded:
         cfg, scaling = "configs[2]", "strong"

@@ -121,3 +121,54 @@ def test_batches_that_never_repeat_stay_eager():
         ts.step(bags, torch.randint(0, K - 1, (4,), generator=g).cuda(), torch.ones(4).cuda())
     d = ts.describe()
     assert d["captures"] == 0 and d["replays"] == 0 and d["eager_steps"] == 5, d
+
+
+def _dp_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    from vlsa_amd.losses import SurvObjective
+    from vlsa_amd.optim import FusedAdam
+    from vlsa_amd.train_step import TrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        net, named = _model()
+        ts = TrainStep(net, SurvObjective(), FusedAdam(_groups(named), lr=1e-3), dist=dist, world=world)
+        bags, t, e = _batches()[0]
+        mine = list(range(len(bags)))[rank::world]
+        losses = []
+        for _ in range(4):
+            loss = ts.step([bags[i] for i in mine], t[mine], e[mine])
+            lt = loss.detach().cpu().clone()
+            dist.all_reduce(lt)
+            losses.append(float(lt) / world)
+        ret[rank] = (losses, [p.detach().cpu().clone() for p in named])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bag_parallel_steps_reproduce_the_single_process_steps():
+    """TrainStep(dist=...): bags are the data-parallel unit, one flat gradient all-reduce per step (SURVEY.md 8(e) "Training DP").  Two
+    ranks (gloo, both on this GPU) with half of the batch each must follow the single-process trajectory."""
+    import os
+    import torch.multiprocessing as mp
+    from vlsa_amd.losses import SurvObjective
+    from vlsa_amd.optim import FusedAdam
+    from vlsa_amd.train_step import TrainStep
+    net, named = _model()
+    ts = TrainStep(net, SurvObjective(), FusedAdam(_groups(named), lr=1e-3), graph=False)
+    bags, t, e = _batches()[0]
+    ref = [float(ts.step(bags, t, e)) for _ in range(4)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, 29700 + os.getpid() % 90, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for r in range(2):
+        losses, params = ret[r]
+        for a, b in zip(losses, ref):
+            assert abs(a - b) < 1e-4 * max(1.0, abs(b)), (r, losses, ref)
+        for p, q in zip(params, named):
+            assert (p - q.detach().cpu()).abs().max().item() < 1e-4 * max(1.0, q.abs().max().item())
+    for p, q in zip(ret[0][1], ret[1][1]):
+        assert torch.equal(p, q)                          # both ranks hold identical parameters after the all-reduce
