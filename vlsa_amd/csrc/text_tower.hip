@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_tt_embed(float* __restrict__ x, float* 
 // A workgroup owns 16 MT rows x 32 columns; its NW waves split K (each wave streams KW = K / NW columns of both operands:
 // 1 KB per load instruction, each weight read exactly once from HBM per row group) and are reduced through LDS in a fixed
 // order (deterministic, no atomics).  Outputs: row-major Y and / or tiled Yt (the next product's A operand).
-enum { PRO_NONE = 0, PRO_LN = 1 };
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_LNBWD = 2 };
 enum { EPI_BIAS = 1, EPI_RESID = 2, EPI_GELU = 4, EPI_GELU_BWD = 8 };
 constexpr int kSlabMax = 12;   // PRO_LN: (K / NW) / 16 groups of the A slab kept in registers (K <= 768 at NW = 4)
 
@@ -119,6 +119,13 @@ struct GemmArgs {
     float* Ypre;           // row-major pre-activation copy (EPI_GELU, training) or null
     const float* H;        // row-major [M_pad, ldh]: EPI_GELU_BWD multiplies by gelu'(H)
     const float *ln_w, *ln_b;
+    // PRO_LNBWD (round 6): the A operand is the LayerNorm BACKWARD of this row block, evaluated in the prologue --
+    //   dx = R2 + LayerNorm'(X2; ln_w)^T A      (A = d LayerNorm output, X2 = the LayerNorm's input, R2 = the residual path's gradient;
+    // all three tiled [M_pad, K]) -- and the workgroups of column tile 0 also store dx (tiled Yt2, row-major Y2 [M_pad, ld2]): the
+    // k_tt_ln_bwd4 launch in front of the product is gone (23 of the backward pass's 86 launches at 12 blocks)
+    const float *X2, *R2;
+    float *Y2, *Yt2;
+    int ld2;
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
 };
@@ -340,6 +347,159 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             }
         TT_STAMP(6);
         __syncthreads();                    // every wave is done with gamma / beta in the buffer the reduction reuses
+    } else if constexpr (PRO == PRO_LNBWD) {
+        // ---- LayerNorm BACKWARD fused into the operand load: three [16 MT rows] x [KW columns] slabs in registers (d LN output, the
+        // LN's input, the residual gradient), row statistics across the NW waves through LDS (one barrier per pass: each pass has its own
+        // scratch), dx left in the first slab = this wave's A operand.  Same MFMA loop and weight ring as PRO_LN behind it.
+        float* sgam = red + 1024;           // [K] gamma
+        f32x4 gld = {0.f, 0.f, 0.f, 0.f};
+        if (tid * 4 < K) gld = *reinterpret_cast<const f32x4*>(p.ln_w + tid * 4);
+        f32x4 slab[MT][kSlabMax], sx[MT][kSlabMax], sr[MT][kSlabMax];
+        const size_t aoff0 = ((size_t)(m0 >> 4) * KG + (kbeg >> 4)) * 256 + lane * 4;
+#pragma unroll
+        for (int jj = 0; jj < kSlabMax; ++jj)
+            if (jj < G) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const size_t o = aoff0 + (size_t)t * KG * 256 + (size_t)256 * jj;
+                    slab[t][jj] = *reinterpret_cast<const f32x4*>(p.A + o);
+                    sx[t][jj] = *reinterpret_cast<const f32x4*>(p.X2 + o);
+                    sr[t][jj] = *reinterpret_cast<const f32x4*>(p.R2 + o);
+                }
+            }
+        f32x4 rb[PF][NTW];
+#pragma unroll
+        for (int sI = 0; sI < PF; ++sI)
+            if (sI < G) {
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid * 4 < K) *reinterpret_cast<f32x4*>(sgam + tid * 4) = gld;
+        float* st1 = red;                   // [NW][16 MT] per pass
+        float* st2 = red + 128 * MT;
+        float* st3 = red + 256 * MT;
+        float* st4 = red + 384 * MT;
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float sm = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < kSlabMax; ++jj)
+                if (jj < G) sm += (sx[t][jj][0] + sx[t][jj][1]) + (sx[t][jj][2] + sx[t][jj][3]);
+            sm = quad_rows_sum(sm);
+            if (g == 0) st1[w * (16 * MT) + 16 * t + r] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float sm = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sm += st1[ww * (16 * MT) + 16 * t + r];
+            mean[t] = sm / (float)K;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float sm = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < kSlabMax; ++jj)
+                if (jj < G) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float cc = sx[t][jj][i] - mean[t];
+                        sm = fmaf(cc, cc, sm);
+                    }
+                }
+            sm = quad_rows_sum(sm);
+            if (g == 0) st2[w * (16 * MT) + 16 * t + r] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float sm = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) sm += st2[ww * (16 * MT) + 16 * t + r];
+            rstd[t] = 1.f / sqrtf(sm / (float)K + kLnEps);
+        }
+        // x^ in place, g = d LN output * gamma in place; row sums of g and g x^
+        const float* gw = sgam + kbeg + 4 * g;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < kSlabMax; ++jj)
+                if (jj < G) {
+                    const f32x4 gam = *reinterpret_cast<const f32x4*>(gw + 16 * jj);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xh = (sx[t][jj][i] - mean[t]) * rstd[t];
+                        const float gv = slab[t][jj][i] * gam[i];
+                        sx[t][jj][i] = xh;
+                        slab[t][jj][i] = gv;
+                        s1 += gv;
+                        s2 = fmaf(gv, xh, s2);
+                    }
+                }
+            s1 = quad_rows_sum(s1);
+            s2 = quad_rows_sum(s2);
+            if (g == 0) {
+                st3[w * (16 * MT) + 16 * t + r] = s1;
+                st4[w * (16 * MT) + 16 * t + r] = s2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                s1 += st3[ww * (16 * MT) + 16 * t + r];
+                s2 += st4[ww * (16 * MT) + 16 * t + r];
+            }
+            const float sg = s1 / (float)K, sgx = s2 / (float)K;
+#pragma unroll
+            for (int jj = 0; jj < kSlabMax; ++jj)
+                if (jj < G) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        slab[t][jj][i] = sr[t][jj][i] + rstd[t] * (slab[t][jj][i] - sg - sx[t][jj][i] * sgx);
+                }
+        }
+        if (ntile == 0) {                   // one workgroup per row block hands dx on (the residual path of the next LayerNorm backward)
+#pragma unroll
+            for (int jj = 0; jj < kSlabMax; ++jj)
+                if (jj < G) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        if (p.Yt2) *reinterpret_cast<f32x4*>(p.Yt2 + aoff0 + (size_t)t * KG * 256 + (size_t)256 * jj) = slab[t][jj];
+                        if (p.Y2)
+                            *reinterpret_cast<f32x4*>(p.Y2 + (size_t)(m0 + 16 * t + r) * p.ld2 + kbeg + 16 * jj + 4 * g) = slab[t][jj];
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < kSlabMax; ++jj)
+            if (jj < G) {
+                const int sI = jj % PF;
+                f32x4 b[NTW];
+#pragma unroll
+                for (int u = 0; u < NTW; ++u) b[u] = rb[sI][u];
+                if (jj + PF < G) {
+#pragma unroll
+                    for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int u = 0; u < NTW; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(slab[t][jj][i], b[u][i], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();                    // every wave is done with gamma / the statistics in the buffer the reduction reuses
     } else {
         // register ring PF groups deep: the loads of group jj + PF are issued when group jj is consumed (vmcnt returns in order)
         f32x4 ra[PF][MT], rb[PF][NTW];
@@ -1399,10 +1559,13 @@ inline const float* packed_proj(const float* set, const Shape& s) { return set +
 // ---- workspace (floats).  Per-layer region (kept for backward when save != 0, else one region reused):
 //      x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]     (all row-major)
 //      | attn [M_pad, d] tiled: the attention output, kept per block only with save == 2 (its out_proj weight gradient needs it)
-inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 10; }
+//      | x_in tiled [M_pad, d] | x_mid tiled [M_pad, d]   (round 6: the LayerNorm-backward prologues of the input-gradient products read them)
+inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 12; }
+inline float* layer_xin_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 10; }
+inline float* layer_xmid_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 11; }
 struct Scratch {   // behind the layer regions; *_t = tiled
     float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
-    float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *dattn, *dqkv_t;                    // backward
+    float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *da_t, *dattn, *dqkv_t;             // backward
     float* pfx;             // shared prefix: per (block, head) partial dK / dV of the prefix rows [(n_seq + 1)][heads][L][128]
     unsigned int* cnt;      // [heads] tickets (zero between launches: the workspace is zeroed once by the caller)
     float *lnout, *lnstats; // weight gradients: LayerNorm output [M_pad, d] row-major and (mean, rstd) per row of the block at hand
@@ -1412,7 +1575,7 @@ struct Scratch {   // behind the layer regions; *_t = tiled
 constexpr size_t kPCtrWords = (size_t)kPMaxLayers * kPStages * kPMaxRT;
 inline size_t pfx_floats(const Shape& s) { return (size_t)(s.n_seq + 1) * s.heads * (s.L > 0 ? s.L : 0) * 128 + 64; }
 inline size_t scratch_floats(const Shape& s) {
-    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 1 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s)
+    return (size_t)s.M_pad * s.d * (1 + 1 + 1 + 1 + 4 + 2 + 2 + 4 + 2 + 1 + 3) + (size_t)s.ns_pad * (2 * s.d + 2 * s.out_dim) + pfx_floats(s)
            + (size_t)s.M_pad * 3 * s.d + kPCtrWords + 8 + 2 * (size_t)kPMaxLayers * kPStages * 6 + 2 + (size_t)s.M_pad * (s.d + 2);
 }
 inline Scratch scratch_of(float* p, const Shape& s) {
@@ -1429,6 +1592,7 @@ inline Scratch scratch_of(float* p, const Shape& s) {
     c.dxb_t = p; p += md;
     c.dh_t = p; p += 4 * md;
     c.da = p; p += md;
+    c.da_t = p; p += md;
     c.dattn = p; p += md;
     c.dqkv_t = p; p += 3 * md;
     c.pooled_t = p; p += (size_t)s.ns_pad * s.d;
@@ -1461,7 +1625,7 @@ int launch_gemm_g(GemmArgs a, int M_pad, hipStream_t st) {
     const int NT = a.N / (16 * NTW);
     a.xcd_map = NT >= 8 ? 1 : 0;      // XCD-aware block -> tile map (whole rounds of 8 tiles; the rest linear)
     size_t lds = (size_t)NW * MT * NTW * 4 * 64 * sizeof(float);
-    if (PRO == PRO_LN && lds < (size_t)(1024 + 2 * a.K) * sizeof(float)) lds = (size_t)(1024 + 2 * a.K) * sizeof(float);
+    if (PRO != PRO_NONE && lds < (size_t)(1024 + 2 * a.K) * sizeof(float)) lds = (size_t)(1024 + 2 * a.K) * sizeof(float);
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_gemm<MT, NW, PRO, GT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1660,11 +1824,14 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     const float* wset = static_cast<const float*>(packed);
     auto region = [&](int layer) { return ws + (save_for_backward ? (size_t)layer : 0) * LF; };
 
-    hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), c.xin_t, d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
-                       r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
-    TT_LAUNCHED();
     const bool keep_attn = save_for_backward == 2;          // a training tower: the attention output of every block stays
     const bool persist = !keep_attn && persist_supported(s, r, tt_flags);
+    // tiled copies of a block's input / its middle: scratch, or -- kept for the backward pass -- behind the block's region
+    auto xin_t_of = [&](int layer) { return (save_for_backward && !persist) ? layer_xin_t(region(layer), s) : c.xin_t; };
+    auto xmid_t_of = [&](int layer) { return (save_for_backward && !persist) ? layer_xmid_t(region(layer), s) : c.xmid_t; };
+    hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), xin_t_of(0), d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
+                       r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
+    TT_LAUNCHED();
     if (persist) {
         PArgs a{};
         a.ws = ws; a.wset = wset;
@@ -1692,6 +1859,15 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_forward_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_tt_forward_persistent, dim3(grid), dim3(512), lds, st, a);
         TT_LAUNCHED();
+        if (save_for_backward) {            // the backward pass reads tiled copies of every block's x_in / x_mid: made here from the rows the
+            for (int L = 0; L < s.layers; ++L) {            // persistent launch kept (an opt-in, slower path anyway: 24 small launches)
+                float* x_in = region(L);
+                float* x_mid = x_in + (size_t)Mp * 4 * d;
+                hipLaunchKernelGGL(k_tt_tile_rows, dim3(Mp / 16, d / 16), dim3(256), 0, st, x_in, Mp, d, layer_xin_t(x_in, s));
+                hipLaunchKernelGGL(k_tt_tile_rows, dim3(Mp / 16, d / 16), dim3(256), 0, st, x_mid, Mp, d, layer_xmid_t(x_in, s));
+            }
+            TT_LAUNCHED();
+        }
     }
     for (int L = 0; L < (persist ? 0 : s.layers); ++L) {
         const vlsa_tt_layer& w = m->layer[L];
@@ -1704,7 +1880,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         float* attn_t = keep_attn ? h_pre + (size_t)Mp * 4 * d : c.attn_t;
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
         {
-            GemmArgs a = gemm_args(c.xin_t, pw.in_w, 3 * d, d);
+            GemmArgs a = gemm_args(xin_t_of(L), pw.in_w, 3 * d, d);
             a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS | TT_DBG_BITS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
             a.M_real = s.M;
             // 32-row workgroup tiles when they still fit one round of the CUs (K = 12 prompts: 5 x 48 = 240 workgroups of 2/3 the
@@ -1724,11 +1900,11 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         TT_LAUNCHED();
         {
             GemmArgs a = gemm_args(attn_t, pw.out_w, d, d);
-            a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = c.xmid_t; a.epi = EPI_BIAS | EPI_RESID;
+            a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = xmid_t_of(L); a.epi = EPI_BIAS | EPI_RESID;
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
         {
-            GemmArgs a = gemm_args(c.xmid_t, pw.fc_w, 4 * d, d);
+            GemmArgs a = gemm_args(xmid_t_of(L), pw.fc_w, 4 * d, d);
             a.bias = w.fc_b; a.Yt = c.hact_t; a.Ypre = save_for_backward ? h_pre : nullptr; a.ldy = 4 * d; a.epi = EPI_BIAS | EPI_GELU;
             a.ln_w = w.ln2_w; a.ln_b = w.ln2_b;
             a.M_real = s.M;
@@ -1742,7 +1918,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         }
         {
             GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
-            a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
+            a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = (L + 1 < s.layers) ? xin_t_of(L + 1) : c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
     }
@@ -1810,7 +1986,60 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
     static DeviceOnce once;
     const size_t attn_lds = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
     if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds);
-    for (int L = s.layers - 1; L >= 0; --L) {
+    // Round 6: with frozen weights and the CONCH shapes (d = 768: a wave's 192-column slab = 12 groups; few rows: the 16 x 96 / 16 x 32
+    // products) both LayerNorm backward passes of a block run as PROLOGUES of the products that consume their result (PRO_LNBWD):
+    //   ln_2 backward  -> in front of  d attn = dx_mid W_out          (this block)
+    //   ln_1 backward  -> in front of  d h = dx_out W_proj (* gelu')  (the block BELOW, i.e. the next iteration)
+    // 5 launches per block instead of 7; only block 0's ln_1 backward stays a launch (its result feeds the scatter).
+    const bool fuse = !gr && d / 4 / 16 == kSlabMax && (4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && d % 32 == 0
+                      && ((s.M + 15) / 16) * (d / 32) <= 256;
+    for (int L = s.layers - 1; fuse && L >= 0; --L) {
+        const vlsa_tt_layer& w = m->layer[L];
+        const PackedLayer pw = packed_layer(bset, s, L);
+        float* x_in = ws + (size_t)L * LF;
+        float* qkv = x_in + (size_t)Mp * d;
+        float* x_mid = qkv + (size_t)Mp * 3 * d;
+        float* h_pre = x_mid + (size_t)Mp * d;
+        const bool top = L == s.layers - 1;
+        {   // d h_pre = (dx_out @ W_proj) * gelu'(h_pre);  dx_out = the ln_final gradient (top block) or ln_1 backward of block L + 1
+            GemmArgs a = gemm_args(top ? c.dxa_t : c.da_t, pw.proj_w, 4 * d, d);
+            a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
+            a.M_real = s.M;
+            if (top) {
+                TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 6>(a, Mp, st)));
+            } else {
+                a.X2 = layer_xin_t(ws + (size_t)(L + 1) * LF, s); a.R2 = c.dxb_t; a.ln_w = m->layer[L + 1].ln1_w;
+                a.Yt2 = c.dxa_t; a.Y2 = c.dxa; a.ld2 = d;
+                TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 6>(a, Mp, st)));
+            }
+        }
+        {   // d ln_2 out = d h_pre @ W_fc   (tiled: the next product's prologue reads it)
+            GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
+            a.Yt = c.da_t;
+            TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
+        }
+        {   // dx_mid = dx_out + ln_2 backward (prologue);  d attn = dx_mid @ W_out
+            GemmArgs a = gemm_args(c.da_t, pw.out_w, d, d);
+            a.X2 = layer_xmid_t(x_in, s); a.R2 = c.dxa_t; a.ln_w = w.ln2_w; a.Yt2 = c.dxb_t; a.Y2 = c.dxb; a.ld2 = d;
+            a.Y = c.dattn; a.ldy = d;
+            a.M_real = s.M;
+            TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 2>(a, Mp, st)));
+        }
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
+                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
+        TT_LAUNCHED();
+        {   // d ln_1 out = dqkv @ W_in
+            GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
+            a.Yt = c.da_t;
+            if (L == 0) { a.Y = c.da; a.ldy = d; }
+            TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
+        }
+        if (L == 0) {
+            launch_ln_bwd(c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp, st);
+            TT_LAUNCHED();
+        }
+    }
+    for (int L = s.layers - 1; !fuse && L >= 0; --L) {
         const vlsa_tt_layer& w = m->layer[L];
         const PackedLayer pw = packed_layer(bset, s, L);
         float* x_in = ws + (size_t)L * LF;
