@@ -126,6 +126,16 @@ struct GemmArgs {
     const float *X2, *R2;
     float *Y2, *Yt2;
     int ld2;
+    // row statistics (mean, rstd) [M_pad][2] of the LayerNorm a PRO_LN product applies: written by its column tile 0 when stats_out is
+    // set (the forward that saves for the backward pass), read by the PRO_LNBWD product of the same LayerNorm (stats_in) instead of two
+    // passes over the X2 slab and two barrier rounds
+    float* stats_out;
+    const float* stats_in;
+    // the NEXT product's weights (tiled [N' / 16][K' / 16][256]), pulled into the L2 of the XCD whose workgroups will read them while this
+    // product's MFMA loop drains its own ring (see prefetch_next): pf_tile_floats = floats of one of ITS column tiles (16 NTW' x K'),
+    // pf_tiles_xcd = its whole rounds of 8 column tiles (tile t is read by XCD t % 8: the xcd_map of its launch)
+    const float* pfW;
+    int pf_tile_floats, pf_tiles_xcd, pf_magic;     // pf_magic = 65536 / pf_tiles_xcd + 1: n / pf_tiles_xcd = (n * pf_magic) >> 16 for the small n here
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
 };
@@ -150,6 +160,33 @@ __device__ long long tt_stamps[16];
 // NTW = 16-column tiles per workgroup (2 or 3).  The grid should not exceed the 256 CUs by a fraction: 288 or 384 workgroups
 // of equal work run as long as 512 (the CUs that get two share their matrix pipes), so the wide products use 48-column
 // tiles: QKV 4 x 48 = 192 workgroups, c_fc 4 x 64 = 256 (measured: 24 -> 14 us per launch).
+// Weight prefetch for the launch behind this one.  A product's workgroups all start by waiting for their first weight groups from HBM
+// (the tower's 340 MB of weights per pass never stay in the 256 MB Infinity Cache), ~2 us in which nothing else happens; the previous
+// launch has bandwidth to spare, so each of its threads touches up to kPfLoads 128-byte lines of the next product's weights -- one dword
+// per line, into the L2 of the XCD this workgroup runs on (block b -> XCD b % 8), which is the XCD whose workgroups read those column tiles
+// in the next launch.  Issued once the last ring refill is out (no later load of the wave queues behind them: vmcnt retires in order);
+// the values are consumed by an empty asm at the end of the kernel.
+constexpr int kPfLoads = 4;
+__device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, float (&pfv)[kPfLoads]) {
+    // BRANCH-FREE on purpose: behind a conditional load the compiler's s_waitcnt pass no longer knows how many loads are in flight and
+    // parks the rest of the ring behind the prefetch; so every thread always issues kPfLoads loads -- without a target (or out of range)
+    // they re-read one line of this product's own weights
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nj = ((int)gridDim.x - x + 7) >> 3;           // workgroups of this launch on XCD x
+    const int nT = p.pf_tiles_xcd;                          // column tiles of the next launch on XCD x: x, x + 8, ...
+    const bool on = p.pfW != nullptr && nj >= nT;
+    const int jj = (j * p.pf_magic) >> 16, t = j - jj * nT;            // this workgroup's tile (j % nT), its place among the cnt that share it
+    const int cnt = ((nj - t + nT - 1) * p.pf_magic) >> 16;
+    const int LT = on ? p.pf_tile_floats >> 5 : 1;          // 128-byte lines of a tile
+    const float* base = on ? p.pfW + (size_t)(x + 8 * t) * p.pf_tile_floats : p.W;
+#pragma unroll
+    for (int u = 0; u < kPfLoads; ++u) {
+        int o = (jj + u * cnt) * nthreads + (int)threadIdx.x;
+        o = o < LT ? o : 0;
+        pfv[u] = base[(size_t)o * 32];
+    }
+}
+
 template <int MT, int NW, int PRO, int GT, int NTW = 2>
 __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float red[];
@@ -196,6 +233,9 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < NTW; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (compile-time trip counts only; the 8-wave 48-column shape has no four registers to spare: 128 per lane)
+    constexpr bool kPf = GT > 0 && !(NW == 8 && NTW == 3);
+    float pfv[kPfLoads] = {0.f, 0.f, 0.f, 0.f};
 
     // The epilogue's inputs (bias, gelu' argument, residual) of the accumulator registers this wave will finalise (q = w, w + NW, ...)
     // are fetched NOW: read behind the reduction they are dependent loads that cannot be batched (the stores of one register's
@@ -303,6 +343,10 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             rstd[t] = 1.f / sqrtf(s / (float)K + kLnEps);
         }
         TT_STAMP(4);
+        if (p.stats_out && ntile == 0 && w == 0 && g == 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) *reinterpret_cast<float2*>(p.stats_out + 2 * (m0 + 16 * t + r)) = float2{mean[t], rstd[t]};
+        }
         // normalise the slab in place (affine parameters from LDS); the MFMA loop below then runs on registers + the ring
         const float* gw = sgam + kbeg + 4 * g;
         const float* gb = sgam + K + kbeg + 4 * g;
@@ -329,6 +373,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
                     for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + TT_GSTEP * (jj + PF));
                 }
+                if (kPf && jj == (GT > PF ? GT - PF : 0)) prefetch_next(p, NW * 64, pfv);
                 __builtin_amdgcn_sched_barrier(0);
                 if (TT_NOMFMA) {
 #pragma unroll
@@ -356,6 +401,11 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         if (tid * 4 < K) gld = *reinterpret_cast<const f32x4*>(p.ln_w + tid * 4);
         f32x4 slab[MT][kSlabMax], sx[MT][kSlabMax], sr[MT][kSlabMax];
         const size_t aoff0 = ((size_t)(m0 >> 4) * KG + (kbeg >> 4)) * 256 + lane * 4;
+        const bool have_stats = p.stats_in != nullptr;      // (uniform)
+        float2 stin[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            stin[t] = have_stats ? *reinterpret_cast<const float2*>(p.stats_in + 2 * (m0 + 16 * t + r)) : float2{0.f, 1.f};
 #pragma unroll
         for (int jj = 0; jj < kSlabMax; ++jj)
             if (jj < G) {
@@ -381,6 +431,10 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         float* st3 = red + 256 * MT;
         float* st4 = red + 384 * MT;
         float mean[MT], rstd[MT];
+        if (have_stats) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { mean[t] = stin[t].x; rstd[t] = stin[t].y; }
+        } else {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             float sm = 0.f;
@@ -421,6 +475,8 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             for (int ww = 0; ww < NW; ++ww) sm += st2[ww * (16 * MT) + 16 * t + r];
             rstd[t] = 1.f / sqrtf(sm / (float)K + kLnEps);
         }
+        }
+        if (have_stats) __syncthreads();    // gamma is in LDS
         // x^ in place, g = d LN output * gamma in place; row sums of g and g x^
         const float* gw = sgam + kbeg + 4 * g;
 #pragma unroll
@@ -489,6 +545,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
                     for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
                 }
+                if (kPf && jj == (GT > PF ? GT - PF : 0)) prefetch_next(p, NW * 64, pfv);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -526,6 +583,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 #pragma unroll
                 for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
             }
+            if (kPf && jj == (GT > PF ? GT - PF : 0)) prefetch_next(p, NW * 64, pfv);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -578,6 +636,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
         if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
+    if constexpr (kPf) asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));      // the prefetched lines' only consumer
     TT_STAMP(8);
 }
 
@@ -1551,6 +1610,10 @@ struct PackedLayer {
 };
 inline PackedLayer packed_layer(const float* set, const Shape& s, int L) {
     const size_t dd = (size_t)s.d * s.d;
+    // (measurement aid, -DVLSA_EXPERIMENT builds only: every block reads block 0's weights -- the tower with its weights cache-resident;
+    //  results are meaningless)
+    static const bool same_w = VLSA_ENV("VLSA_TT_SAMEW") != nullptr;
+    if (same_w) L = 0;
     const float* b = set + (size_t)L * 12 * dd;
     return PackedLayer{b, b + 3 * dd, b + 4 * dd, b + 8 * dd};
 }
@@ -1560,9 +1623,12 @@ inline const float* packed_proj(const float* set, const Shape& s) { return set +
 //      x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]     (all row-major)
 //      | attn [M_pad, d] tiled: the attention output, kept per block only with save == 2 (its out_proj weight gradient needs it)
 //      | x_in tiled [M_pad, d] | x_mid tiled [M_pad, d]   (round 6: the LayerNorm-backward prologues of the input-gradient products read them)
-inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 12; }
+inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 12 + (size_t)s.M_pad * 4; }
 inline float* layer_xin_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 10; }
 inline float* layer_xmid_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 11; }
+// (mean, rstd) of every row under ln_1 / ln_2 of the block: [M_pad][2] each, kept by the forward for the PRO_LNBWD prologues
+inline float* layer_stats1(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 12; }
+inline float* layer_stats2(float* region, const Shape& s) { return layer_stats1(region, s) + (size_t)s.M_pad * 2; }
 struct Scratch {   // behind the layer regions; *_t = tiled
     float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
     float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *da_t, *dattn, *dqkv_t;             // backward
@@ -1684,6 +1750,20 @@ inline GemmArgs gemm_args(const float* A, const float* W, int N, int K) {
     a.N = N;
     a.K = K;
     return a;
+}
+// this launch also pulls the NEXT product's weights Wn (N' = Nn columns in tiles of 16 ntw, K' = Kn) towards the XCDs that will read them
+// (prefetch_next); on: false switches it off (shapes whose launch does not use the tile sizes assumed here)
+inline void prefetch_for(GemmArgs& a, bool on, const float* Wn, int Nn, int Kn, int ntw) {
+#ifdef VLSA_EXPERIMENT
+    static const bool off = VLSA_ENV("VLSA_TT_NOPF") != nullptr;
+    if (off) return;
+#endif
+    const int per_xcd = ((Nn / (16 * ntw)) & ~7) / 8;
+    if (!on || !Wn || per_xcd < 1) return;
+    a.pfW = Wn;
+    a.pf_tile_floats = 16 * ntw * Kn;
+    a.pf_tiles_xcd = per_xcd;
+    a.pf_magic = 65536 / per_xcd + 1;
 }
 
 
@@ -1829,6 +1909,11 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     // tiled copies of a block's input / its middle: scratch, or -- kept for the backward pass -- behind the block's region
     auto xin_t_of = [&](int layer) { return (save_for_backward && !persist) ? layer_xin_t(region(layer), s) : c.xin_t; };
     auto xmid_t_of = [&](int layer) { return (save_for_backward && !persist) ? layer_xmid_t(region(layer), s) : c.xmid_t; };
+    // the tile shapes of the few-row (K = 12 prompts) launches below: 16 x 64 in_proj, 16 x 32 out_proj / c_proj, 16 x 96 c_fc -- what the
+    // weight prefetch of the launch in front of each assumes
+    const int rt = (s.M + 15) / 16;
+    const bool few = d / 4 / 16 == 12 && (3 * d) % 64 == 0 && rt * (3 * d / 64) <= 256 && (4 * d) % 96 == 0 && rt * (4 * d / 96) <= 256
+                     && d % 32 == 0 && rt * (d / 32) <= 256;
     hipLaunchKernelGGL(k_tt_embed, dim3(Mp), dim3(256), 0, st, region(0), xin_t_of(0), d, emb, emb_seq_stride, emb_tok_stride, r->row_seq,
                        r->row_pos, r->row_src, m->pos_emb, m->cls_emb, s.M);
     TT_LAUNCHED();
@@ -1865,6 +1950,10 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
                 float* x_mid = x_in + (size_t)Mp * 4 * d;
                 hipLaunchKernelGGL(k_tt_tile_rows, dim3(Mp / 16, d / 16), dim3(256), 0, st, x_in, Mp, d, layer_xin_t(x_in, s));
                 hipLaunchKernelGGL(k_tt_tile_rows, dim3(Mp / 16, d / 16), dim3(256), 0, st, x_mid, Mp, d, layer_xmid_t(x_in, s));
+                hipLaunchKernelGGL(k_tt_ln_rows, dim3(Mp / 4), dim3(256), 0, st, x_in, m->layer[L].ln1_w, m->layer[L].ln1_b, (float*)nullptr,
+                                   layer_stats1(x_in, s), d, Mp);
+                hipLaunchKernelGGL(k_tt_ln_rows, dim3(Mp / 4), dim3(256), 0, st, x_mid, m->layer[L].ln2_w, m->layer[L].ln2_b, (float*)nullptr,
+                                   layer_stats2(x_in, s), d, Mp);
             }
             TT_LAUNCHED();
         }
@@ -1883,6 +1972,8 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             GemmArgs a = gemm_args(xin_t_of(L), pw.in_w, 3 * d, d);
             a.bias = w.in_b; a.Y = qkv; a.ldy = 3 * d; a.epi = EPI_BIAS | TT_DBG_BITS; a.ln_w = w.ln1_w; a.ln_b = w.ln1_b;
             a.M_real = s.M;
+            if (save_for_backward) a.stats_out = layer_stats1(x_in, s);
+            prefetch_for(a, few, pw.out_w, d, d, 2);
             // 32-row workgroup tiles when they still fit one round of the CUs (K = 12 prompts: 5 x 48 = 240 workgroups of 2/3 the
             // work instead of 4 x 48 = 192), else 48-row tiles
             const int nt = (3 * d) % 48 == 0 ? (3 * d) / 48 : (3 * d) / 32;
@@ -1901,6 +1992,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(attn_t, pw.out_w, d, d);
             a.bias = w.out_b; a.resid = x_in; a.ldr = d; a.Y = x_mid; a.ldy = d; a.Yt = xmid_t_of(L); a.epi = EPI_BIAS | EPI_RESID;
+            prefetch_for(a, few, pw.fc_w, 4 * d, d, 6);
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
         {
@@ -1908,6 +2000,8 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             a.bias = w.fc_b; a.Yt = c.hact_t; a.Ypre = save_for_backward ? h_pre : nullptr; a.ldy = 4 * d; a.epi = EPI_BIAS | EPI_GELU;
             a.ln_w = w.ln2_w; a.ln_b = w.ln2_b;
             a.M_real = s.M;
+            if (save_for_backward) a.stats_out = layer_stats2(x_in, s);
+            prefetch_for(a, few, pw.proj_w, d, 4 * d, 2);
             // 32 x 64 workgroup tiles when they fit one round (K = 12 prompts: 5 x 48 = 240 workgroups, 160 instead of 192 rows of
             // f32-MFMA work -- this product is matrix-pipe-bound), else 48 x 48
             if ((4 * d) % 96 == 0 && ((s.M + 15) / 16) * (4 * d / 96) <= 256 && d / 4 / 16 == 12)
@@ -1919,6 +2013,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         {
             GemmArgs a = gemm_args(c.hact_t, pw.proj_w, d, 4 * d);
             a.bias = w.proj_b; a.resid = x_mid; a.ldr = d; a.Y = x_next; a.ldy = d; a.Yt = (L + 1 < s.layers) ? xin_t_of(L + 1) : c.xin_t; a.epi = EPI_BIAS | EPI_RESID;
+            if (L + 1 < s.layers) prefetch_for(a, few, packed_layer(wset, s, L + 1).in_w, 3 * d, d, 4);
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
     }
@@ -2005,17 +2100,20 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             GemmArgs a = gemm_args(top ? c.dxa_t : c.da_t, pw.proj_w, 4 * d, d);
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
             a.M_real = s.M;
+            prefetch_for(a, true, pw.fc_w, d, 4 * d, 2);
             if (top) {
                 TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 6>(a, Mp, st)));
             } else {
                 a.X2 = layer_xin_t(ws + (size_t)(L + 1) * LF, s); a.R2 = c.dxb_t; a.ln_w = m->layer[L + 1].ln1_w;
                 a.Yt2 = c.dxa_t; a.Y2 = c.dxa; a.ld2 = d;
+                a.stats_in = layer_stats1(ws + (size_t)(L + 1) * LF, s);
                 TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 6>(a, Mp, st)));
             }
         }
         {   // d ln_2 out = d h_pre @ W_fc   (tiled: the next product's prologue reads it)
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
             a.Yt = c.da_t;
+            prefetch_for(a, true, pw.out_w, d, d, 2);
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
         {   // dx_mid = dx_out + ln_2 backward (prologue);  d attn = dx_mid @ W_out
@@ -2023,6 +2121,8 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             a.X2 = layer_xmid_t(x_in, s); a.R2 = c.dxa_t; a.ln_w = w.ln2_w; a.Yt2 = c.dxb_t; a.Y2 = c.dxb; a.ld2 = d;
             a.Y = c.dattn; a.ldy = d;
             a.M_real = s.M;
+            a.stats_in = layer_stats2(x_in, s);
+            prefetch_for(a, true, pw.in_w, d, 3 * d, 2);
             TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 2>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
@@ -2032,6 +2132,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
             a.Yt = c.da_t;
             if (L == 0) { a.Y = c.da; a.ldy = d; }
+            if (L > 0) prefetch_for(a, true, packed_layer(bset, s, L - 1).proj_w, 4 * d, d, 6);
             TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
         if (L == 0) {
