@@ -32,46 +32,70 @@ struct AdamArgs {
 
 constexpr int kAdamThreads = 256, kAdamPerThread = 4;
 
+// b^n by squaring in double (n >= 1): at most 2 x 31 multiplications, each within half an ulp of double -- the bias corrections are
+// rounded to fp32 afterwards.  (libm's pow is several hundred dependent fp64 instructions: ~1.5 us in front of every update.)
+__device__ __forceinline__ double pow_int(double b, int n) {
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= b;
+        b *= b;
+        n >>= 1;
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(kAdamThreads) void k_adam_step(const AdamArgs a, const float* __restrict__ hyper, int* __restrict__ state) {
     // state[0] = steps taken so far, state[1] = arrival ticket of this launch (zero between launches)
-    __shared__ int s_last;
-    const int step = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __shared__ int s_step;
     int ti = 0;
 #pragma unroll 1
     for (int k = 1; k < a.n_tensors; ++k)
         if ((int)blockIdx.x >= a.t[k].blk0) ti = k;
     const AdamTensor T = a.t[ti];
+    // order of the requests = order of the latencies: the step counter (a device-scope load), then this thread's elements, then the ticket --
+    // the bias corrections are computed while the elements are in flight
+    if (threadIdx.x == 0) s_step = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const float lr = hyper[2 * T.hyper], wd = hyper[2 * T.hyper + 1];
-    const double bc1 = 1.0 - pow(a.b1d, (double)step);
-    const double bc2 = 1.0 - pow(a.b2d, (double)step);
+    const long long base = ((long long)(blockIdx.x - T.blk0) * kAdamThreads + threadIdx.x) * kAdamPerThread;
+    float gv[kAdamPerThread], pv[kAdamPerThread], mv[kAdamPerThread], vv[kAdamPerThread];
+#pragma unroll
+    for (int i = 0; i < kAdamPerThread; ++i) {
+        const long long e = base + i;
+        const bool ok = e < T.n;
+        gv[i] = ok ? T.g[e] : 0.f;
+        pv[i] = ok ? T.p[e] : 0.f;
+        mv[i] = ok ? T.m[e] : 0.f;
+        vv[i] = ok ? T.v[e] : 0.f;
+    }
+    __syncthreads();
+    const int step = s_step;
+    // the step counter moves once every workgroup of the launch has READ it -- a workgroup takes its ticket as soon as its read is back
+    // (not behind its update), the last arriver writes the counter and zeroes the ticket
+    if (a.bump && threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (int)gridDim.x - 1) {
+            __hip_atomic_store(state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const double bc1 = 1.0 - pow_int(a.b1d, step);
+    const double bc2 = 1.0 - pow_int(a.b2d, step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    const long long base = ((long long)(blockIdx.x - T.blk0) * kAdamThreads + threadIdx.x) * kAdamPerThread;
 #pragma unroll
     for (int i = 0; i < kAdamPerThread; ++i) {
         const long long e = base + i;
         if (e < T.n) {
-            float g = T.g[e];
-            const float p = T.p[e];
+            float g = gv[i];
+            const float p = pv[i];
             if (wd != 0.f) g = g + wd * p;
-            float m = T.m[e], v = T.v[e];
+            float m = mv[i], v = vv[i];
             m = m + (g - m) * a.omb1;
             v = v * a.beta2 + a.omb2 * g * g;
             const float denom = sqrtf(v) / bc2_sqrt + a.eps;
             T.m[e] = m;
             T.v[e] = v;
             T.p[e] = p - step_size * (m / denom);
-        }
-    }
-    if (!a.bump) return;
-    // the step counter moves once every workgroup of the launch has read it: the last arriver writes it (and zeroes the ticket)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tk = __hip_atomic_fetch_add(state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = tk == (int)gridDim.x - 1;
-        if (s_last) {
-            __hip_atomic_store(state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(state, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

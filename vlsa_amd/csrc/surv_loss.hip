@@ -133,6 +133,11 @@ __global__ __launch_bounds__(kLossThreads) void k_surv_loss(const float* __restr
     }
 }
 
+
+// (Round 6, tried and removed: the same arithmetic with the per-sample vectors in registers and every bin loop unrolled to 16 -- 14.1 us
+//  against 12.5 us for the LDS loops above inside the training step: one wave running ~20 KB of straight-line code once is bound by
+//  instruction fetch, not by the LDS round trips.  Parking the sample's K inputs in LDS with one batch of loads first: no change either,
+//  12.7 -> 13.5 us on another box -- the time is the ~500 dependent LDS accesses of the bin loops.)
 }  // namespace vlsa
 
 using namespace vlsa;

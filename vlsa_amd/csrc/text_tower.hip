@@ -135,6 +135,8 @@ struct GemmArgs {
     // product's MFMA loop drains its own ring (see prefetch_next): pf_tile_floats = floats of one of ITS column tiles (16 NTW' x K'),
     // pf_tiles_xcd = its whole rounds of 8 column tiles (tile t is read by XCD t % 8: the xcd_map of its launch)
     const float* pfW;
+    const float* pf2;      // a second region the next launches read on EVERY XCD (saved activations of the forward: the LayerNorm-backward
+    int pf2_lines;         // prologues' x, the attention backward's q / k / v): pf2_lines 128-byte lines, pulled into every XCD's L2
     int pf_tile_floats, pf_tiles_xcd, pf_magic;     // pf_magic = 65536 / pf_tiles_xcd + 1: n / pf_tiles_xcd = (n * pf_magic) >> 16 for the small n here
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
@@ -166,8 +168,8 @@ __device__ long long tt_stamps[16];
 // per line, into the L2 of the XCD this workgroup runs on (block b -> XCD b % 8), which is the XCD whose workgroups read those column tiles
 // in the next launch.  Issued once the last ring refill is out (no later load of the wave queues behind them: vmcnt retires in order);
 // the values are consumed by an empty asm at the end of the kernel.
-constexpr int kPfLoads = 4;
-__device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, float (&pfv)[kPfLoads]) {
+constexpr int kPfLoads = 4, kPf2Loads = 2, kPfRegs = kPfLoads + kPf2Loads;
+__device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, float (&pfv)[kPfRegs]) {
     // BRANCH-FREE on purpose: behind a conditional load the compiler's s_waitcnt pass no longer knows how many loads are in flight and
     // parks the rest of the ring behind the prefetch; so every thread always issues kPfLoads loads -- without a target (or out of range)
     // they re-read one line of this product's own weights
@@ -184,6 +186,14 @@ __device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, f
         int o = (jj + u * cnt) * nthreads + (int)threadIdx.x;
         o = o < LT ? o : 0;
         pfv[u] = base[(size_t)o * 32];
+    }
+    const float* b2 = p.pf2 != nullptr ? p.pf2 : p.W;
+    const int n2 = p.pf2 != nullptr ? p.pf2_lines : 1;
+#pragma unroll
+    for (int u = 0; u < kPf2Loads; ++u) {
+        int o = (j + u * nj) * nthreads + (int)threadIdx.x;
+        o = o < n2 ? o : 0;
+        pfv[kPfLoads + u] = b2[(size_t)o * 32];
     }
 }
 
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         for (int u = 0; u < NTW; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     // (compile-time trip counts only; the 8-wave 48-column shape has no four registers to spare: 128 per lane)
     constexpr bool kPf = GT > 0 && !(NW == 8 && NTW == 3);
-    float pfv[kPfLoads] = {0.f, 0.f, 0.f, 0.f};
+    float pfv[kPfRegs] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // The epilogue's inputs (bias, gelu' argument, residual) of the accumulator registers this wave will finalise (q = w, w + NW, ...)
     // are fetched NOW: read behind the reduction they are dependent loads that cannot be batched (the stores of one register's
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
         if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
-    if constexpr (kPf) asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));      // the prefetched lines' only consumer
+    if constexpr (kPf) asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]));      // the prefetched lines' only consumer
     TT_STAMP(8);
 }
 
@@ -1765,6 +1775,14 @@ inline void prefetch_for(GemmArgs& a, bool on, const float* Wn, int Nn, int Kn, 
     a.pf_tiles_xcd = per_xcd;
     a.pf_magic = 65536 / per_xcd + 1;
 }
+inline void prefetch_region(GemmArgs& a, const float* ptr, size_t floats) {
+#ifdef VLSA_EXPERIMENT
+    static const bool off = VLSA_ENV("VLSA_TT_NOPF2") != nullptr || VLSA_ENV("VLSA_TT_NOPF") != nullptr;
+    if (off) return;
+#endif
+    a.pf2 = ptr;
+    a.pf2_lines = (int)(floats / 32);
+}
 
 
 void launch_ln_bwd(const float* da, const float* x, const float* gamma, const float* dres, float* dx, float* dxt, int d, int rows,
@@ -2023,7 +2041,11 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
     {   // text features = pooled @ text_projection
         GemmArgs a = gemm_args(c.pooled_t, packed_proj(wset, s), s.out_dim, d);
         a.Y = c.feat; a.ldy = s.out_dim;
-        TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, s.ns_pad, st)));
+        // 16-row x 16-column tiles over the row groups that hold prompts (K = 12 prompts: 32 workgroups of 49 KB of weights each; the
+        // 48 x 32 tiles of the general shape were 16 workgroups of 98 KB and three times the MFMA work: 10.0 -> us per launch)
+        a.M_real = s.n_seq;
+        if (s.out_dim % 16 == 0 && d / 4 / 16 == 12) TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 1>(a, s.ns_pad, st)));
+        else TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, s.ns_pad, st)));
     }
     if (hipMemcpyAsync(out, c.feat, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
     return VLSA_OK;
@@ -2062,7 +2084,9 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
     {   // d pooled = dout @ text_projection^T
         GemmArgs a = gemm_args(c.dout_t, packed_proj(bset, s), d, s.out_dim);
         a.Y = c.dpool; a.ldy = d;
-        TT_TRY((launch_gemm<3, 4, PRO_NONE, 8>(a, s.ns_pad, st)));
+        a.M_real = s.n_seq;
+        if (d % 16 == 0 && s.out_dim / 4 / 16 == 8) TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 8, 1>(a, s.ns_pad, st)));
+        else TT_TRY((launch_gemm<3, 4, PRO_NONE, 8>(a, s.ns_pad, st)));
     }
     hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.dpool, c.x_final, r->row_seq, r->row_src, m->lnf_w, c.dxa,
                        c.dxa_t, d, s.M, Mp);
@@ -2101,6 +2125,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             a.Yt = c.dh_t; a.H = h_pre; a.ldh = 4 * d; a.epi = EPI_GELU_BWD;
             a.M_real = s.M;
             prefetch_for(a, true, pw.fc_w, d, 4 * d, 2);
+            prefetch_region(a, layer_xmid_t(x_in, s), (size_t)Mp * d);      // ln_2 backward's x, two launches ahead
             if (top) {
                 TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 6>(a, Mp, st)));
             } else {
@@ -2114,6 +2139,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             GemmArgs a = gemm_args(c.dh_t, pw.fc_w, d, 4 * d);
             a.Yt = c.da_t;
             prefetch_for(a, true, pw.out_w, d, d, 2);
+            prefetch_region(a, qkv, (size_t)Mp * 3 * d);                     // the attention backward's q / k / v
             TT_TRY((launch_gemm_rows16<8, 24>(a, s.M, Mp, st)));
         }
         {   // dx_mid = dx_out + ln_2 backward (prologue);  d attn = dx_mid @ W_out
@@ -2133,6 +2159,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             a.Yt = c.da_t;
             if (L == 0) { a.Y = c.da; a.ldy = d; }
             if (L > 0) prefetch_for(a, true, packed_layer(bset, s, L - 1).proj_w, 4 * d, d, 6);
+            if (L > 0) prefetch_region(a, layer_xin_t(x_in, s), (size_t)Mp * d);    // ln_1 backward's x (the next launch's prologue)
             TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
         if (L == 0) {

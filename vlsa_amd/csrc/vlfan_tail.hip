@@ -387,6 +387,19 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v
     v += (size_t)bag * D;
     vhat += (size_t)bag * D;
     logits += (size_t)bag * K;
+    // the text rows this wave will need (k = wv, wv + 4, ...: up to 4 rows of D <= 512 here, else read in place) and the logit scale are
+    // requested together with v: they do not depend on the norm, and behind it they were one more round of dependent loads per k
+    constexpr int kTR = 4, kTC = 8;
+    const bool pre = D <= 64 * kTC && K <= 4 * kTR;
+    float tr[kTR][kTC];
+#pragma unroll
+    for (int i = 0; i < kTR; ++i)
+#pragma unroll
+        for (int q = 0; q < kTC; ++q) {
+            const int k = wv + 4 * i, c = lane + 64 * q;
+            tr[i][q] = (pre && k < K && c < D) ? That[(size_t)k * D + c] : 0.f;
+        }
+    const float ls_raw = logit_scale[0];
     float ss = 0.f;
     for (int c = tid; c < D; c += 256) {
         const float x = v[c];
@@ -402,11 +415,22 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ v
     }
     if (tid == 0) vnorm[bag] = nrm;
     __syncthreads();
-    const float ls = expf(logit_scale[0]);
+    const float ls = expf(ls_raw);
     for (int k = wv; k < K; k += 4) {
         const float* tk = That + (size_t)k * D;
         float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += sp[c] * tk[c];
+        if (pre) {
+            const int i = (k - wv) >> 2;
+#pragma unroll
+            for (int ii = 0; ii < kTR; ++ii)
+                if (ii == i) {
+#pragma unroll
+                    for (int q = 0; q < kTC; ++q)
+                        if (lane + 64 * q < D) s += sp[lane + 64 * q] * tr[ii][q];
+                }
+        } else {
+            for (int c = lane; c < D; c += 64) s += sp[c] * tk[c];
+        }
         s = wave_sum(s);
         if (lane == 0) {
             const float lg = ls * s;
@@ -929,9 +953,19 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
             __syncthreads();
             if (tid < 64) sb[tid] = b0 + tid < B ? dv[(size_t)(b0 + tid) * D + j] : 0.f;
             __syncthreads();
+            // 16 loads of `pooled` in flight per round (a load per fma, one after the other, was a chain of 32 L2 round trips: 18 us for
+            // 32 bags -- the longest of the small launches of the training step); same order of additions as before
+            const int nb = min(64, B - b0);
             for (int c = tid; c < D; c += 256) {
                 float s = b0 == 0 ? 0.f : dW[(size_t)j * D + c];
-                for (int b = 0; b < 64 && b0 + b < B; ++b) s = fmaf(sb[b], pooled[(size_t)(b0 + b) * D + c], s);
+                for (int b1 = 0; b1 < nb; b1 += 16) {
+                    float pv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) pv[u] = b1 + u < nb ? pooled[(size_t)(b0 + b1 + u) * D + c] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (b1 + u < nb) s = fmaf(sb[b1 + u], pv[u], s);
+                }
                 dW[(size_t)j * D + c] = s;
             }
             if (tid == 0) {
@@ -965,12 +999,12 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
         for (int b = 0; b < 8; ++b) acc[b] = 0.f;
         if (W != nullptr) {
             const int jbeg = js * jq, jend = min(D, jbeg + jq);
-            for (int j0 = jbeg; j0 < jend; j0 += 16) {
-                float wv[16];
+            for (int j0 = jbeg; j0 < jend; j0 += 32) {       // (32 loads in flight per round: two rounds at D = 512)
+                float wv[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) wv[u] = (j0 + u < jend && c < D) ? W[(size_t)(j0 + u) * D + c] : 0.f;
+                for (int u = 0; u < 32; ++u) wv[u] = (j0 + u < jend && c < D) ? W[(size_t)(j0 + u) * D + c] : 0.f;
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 32; ++u)
                     if (j0 + u < jend) {
 #pragma unroll
                         for (int b = 0; b < 8; ++b) acc[b] = fmaf(sdv[b][j0 + u], wv[u], acc[b]);
@@ -1006,7 +1040,17 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
             const int c = tid + 256 * i;
             float s = 0.f;
             if (c < D) {
-                for (int b = 0; b < B; ++b) s = fmaf(dlogits[(size_t)b * K + k], vhat[(size_t)b * D + c], s);
+                for (int b1 = 0; b1 < B; b1 += 16) {           // (16 loads in flight per round, as above)
+                    float dl[16], vh[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        dl[u] = b1 + u < B ? dlogits[(size_t)(b1 + u) * K + k] : 0.f;
+                        vh[u] = b1 + u < B ? vhat[(size_t)(b1 + u) * D + c] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (b1 + u < B) s = fmaf(dl[u], vh[u], s);
+                }
                 s *= ls;
                 if (g_That != nullptr) s += g_That[(size_t)k * D + c];
                 dot = fmaf(s, That[(size_t)k * D + c], dot);
@@ -1024,7 +1068,14 @@ __global__ __launch_bounds__(256) void k_head_bwd_params(const float* __restrict
     }
     if (tid == 0) {                                   // d logit_scale
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dls_part[b];
+        for (int b1 = 0; b1 < B; b1 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = b1 + u < B ? dls_part[b1 + u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (b1 + u < B) s += v[u];
+        }
         dls[0] = s;
     }
 }
