@@ -312,6 +312,15 @@ int vlsa_head_forward_batch(const float* rows, int B, int P, int D, int pool_mod
                             void* stream);
 
 /*
+ * vlsa_normalize_rows(T) + vlsa_head_forward_batch (ticket-free route, B >= 1, pool_mode MEAN / MAX / WEIGHT) with the text normalisation
+ * inside the pooling launch: the training step's head (model/vlsa.py:186-192 on the step's own text features, runner/vlsa_handler.py:267-281)
+ * in three launches.  T [K, D] raw text features; writes That [K, D], tnorm [K] and the outputs of vlsa_head_forward_batch.
+ */
+int vlsa_head_forward_batch_text(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                 const float* b, const float* T, int K, const float* logit_scale, float* That, float* tnorm,
+                                 float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence, void* stream);
+
+/*
  * Backward of vlsa_head_forward_batch with pool_mode MEAN (the training step's tail: model/deepmil.py:203-204, model/vlsa.py:188-192
  * under autograd) in two launches: dlogits [B, K] (+ optional gradients g_vhat [B, D], g_That [K, D] flowing into the returned unit
  * features) -> drows [B, P, D], dW [D, D], db [D] (W NULL: identity adapter, no dW / db), dT [K, D] (w.r.t. the RAW text features:

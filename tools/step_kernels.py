@@ -28,3 +28,11 @@ for s, e, k in seg:
     c[1] += (e - s) / 1e3
 for k, (c, tt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{k:72s} x{c / n:5.1f}  {tt / n:8.1f} us/step  avg {tt / c:6.2f}")
+if "--order" in sys.argv:       # the launches of ONE step in order (tower blocks folded: only the first and the last block are listed)
+    one = rows[idx[-3]:idx[-2]]
+    print("\none step, in launch order (start offset us, duration us, gap to the previous end us):")
+    t0, prev = one[0][0], None
+    for s, e, k in one:
+        k = k.split("(")[0][-60:]
+        print(f"  {(s - t0) / 1e3:8.1f} {(e - s) / 1e3:6.2f} {0.0 if prev is None else (s - prev) / 1e3:6.2f}  {k}")
+        prev = e

@@ -122,6 +122,8 @@ _SIGNATURES = {
                                         c_int64, c_void_p]),
     "vlsa_scored_pool_partial_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
+    "vlsa_head_forward_batch_text": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vlsa_head_backward_batch": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int] + [c_void_p] * 7),
     "vlsa_prompt_sentences": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_void_p, c_void_p]),

@@ -140,6 +140,7 @@ struct GemmArgs {
     int pf_tile_floats, pf_tiles_xcd, pf_magic;     // pf_magic = 65536 / pf_tiles_xcd + 1: n / pf_tiles_xcd = (n * pf_magic) >> 16 for the small n here
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
+    int M_store;           // > 0: Y has only this many rows (a caller's buffer without padding): rows behind them are not stored
 };
 
 // Tile choice (measured, K = 12 prompts -> 192 padded rows): the operands reach the MFMAs through the CU's L1 at ~46 B/clk, and an
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         }
         if (epi & EPI_GELU_BWD) val *= gelu_grad(e_h[i]);
         if (epi & EPI_RESID) val += e_res[i];
-        if (p.Y) p.Y[(size_t)row * p.ldy + col] = val;
+        if (p.Y && (p.M_store == 0 || row < p.M_store)) p.Y[(size_t)row * p.ldy + col] = val;
         if (p.Yt) p.Yt[tiled_index(row, col, N)] = val;
     }
     if constexpr (kPf) asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]));      // the prefetched lines' only consumer
@@ -851,12 +852,38 @@ __device__ __forceinline__ void ln_stats(const float (&v)[kLnSlots], int nslot, 
 // consecutive columns 4 lane + 256 k (contiguous in the row-major arrays AND in a 16 x 16 tile of the tiled copy): 3 loads per array
 // and 2 x 3 stores per lane at d = 768 instead of 12 and 24 four-byte ones; d % 256 == 0 (else the 4-byte path below).
 constexpr int kLnSlots4 = 4;
+// With a scatter target (block 0's ln_1 backward of the frozen tower: the pass's LAST LayerNorm backward) the same launch also produces
+// d prompts_embedding, so the memset and k_tt_scatter launches behind it are gone: row r < sc.M with a source token writes its dx to
+// demb[row_seq[r], row_src[r], :], and the workgroups behind the LayerNorm rows zero every [seq, token] row of demb (contiguous
+// [n, ctx_len, d]) that no compact row writes to (a wave per row: the <= 128 compact rows are searched, 64 per step).
+struct ScatterArgs {
+    float* demb;            // null: no scatter
+    const int* row_seq;
+    const int* row_src;
+    int64_t s_seq;
+    int M, ctx_len, demb_rows, ln_blocks;
+};
 __global__ __launch_bounds__(256) void k_tt_ln_bwd4(const float* __restrict__ da, const float* __restrict__ x,
                                                    const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                   float* __restrict__ dx, float* __restrict__ dxt, int d, int rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+                                                   float* __restrict__ dx, float* __restrict__ dxt, int d, int rows, const ScatterArgs sc) {
+    const int lane = threadIdx.x & 63;
     const int nslot = d >> 8;
+    if (sc.demb != nullptr && (int)blockIdx.x >= sc.ln_blocks) {
+        const int R = ((int)blockIdx.x - sc.ln_blocks) * 4 + (threadIdx.x >> 6);
+        if (R >= sc.demb_rows) return;
+        const int seq = R / sc.ctx_len, tok = R - seq * sc.ctx_len;
+        bool hit = false;
+        for (int m0 = 0; m0 < sc.M; m0 += 64) {
+            const int m = m0 + lane;
+            hit = hit || (m < sc.M && sc.row_seq[m] == seq && sc.row_src[m] == tok);
+        }
+        if (__ballot(hit) != 0ull) return;
+        float* o = sc.demb + (size_t)seq * sc.s_seq + (size_t)tok * d;
+        for (int k = 0; k < nslot; ++k) *reinterpret_cast<f32x4*>(o + 4 * lane + 256 * k) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
     f32x4 xv[kLnSlots4], gv[kLnSlots4], rv[kLnSlots4];
 #pragma unroll
     for (int k = 0; k < kLnSlots4; ++k)
@@ -902,6 +929,10 @@ __global__ __launch_bounds__(256) void k_tt_ln_bwd4(const float* __restrict__ da
             for (int i = 0; i < 4; ++i) o[i] = rv[k][i] + rstd * (gv[k][i] - sg - xv[k][i] * sgx);
             *reinterpret_cast<f32x4*>(dx + (size_t)row * d + c) = o;
             *reinterpret_cast<f32x4*>(dxt + tiled_index(row, c, d)) = o;      // columns c .. c + 3: one k-slot of the tile, contiguous
+            if (sc.demb != nullptr && row < sc.M) {
+                const int src = sc.row_src[row];
+                if (src >= 0) *reinterpret_cast<f32x4*>(sc.demb + (size_t)sc.row_seq[row] * sc.s_seq + (size_t)src * d + c) = o;
+            }
         }
 }
 
@@ -1788,7 +1819,7 @@ inline void prefetch_region(GemmArgs& a, const float* ptr, size_t floats) {
 void launch_ln_bwd(const float* da, const float* x, const float* gamma, const float* dres, float* dx, float* dxt, int d, int rows,
                    hipStream_t st) {
     if (d % 256 == 0 && d <= 256 * kLnSlots4)
-        hipLaunchKernelGGL(k_tt_ln_bwd4, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows);
+        hipLaunchKernelGGL(k_tt_ln_bwd4, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows, ScatterArgs{});
     else
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows);
 }
@@ -2042,10 +2073,14 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         GemmArgs a = gemm_args(c.pooled_t, packed_proj(wset, s), s.out_dim, d);
         a.Y = c.feat; a.ldy = s.out_dim;
         // 16-row x 16-column tiles over the row groups that hold prompts (K = 12 prompts: 32 workgroups of 49 KB of weights each; the
-        // 48 x 32 tiles of the general shape were 16 workgroups of 98 KB and three times the MFMA work: 10.0 -> us per launch)
+        // 48 x 32 tiles of the general shape were 16 workgroups of 98 KB and three times the MFMA work: 10.0 -> 5.2 us per launch)
         a.M_real = s.n_seq;
-        if (s.out_dim % 16 == 0 && d / 4 / 16 == 12) TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 1>(a, s.ns_pad, st)));
-        else TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, s.ns_pad, st)));
+        if (s.out_dim % 16 == 0 && d / 4 / 16 == 12) {
+            a.Y = out; a.M_store = s.n_seq;         // straight into the caller's [n_seq, out_dim] (no copy launch behind the product)
+            TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 12, 1>(a, s.ns_pad, st)));
+            return VLSA_OK;
+        }
+        TT_TRY((launch_gemm<3, 4, PRO_NONE, 12>(a, s.ns_pad, st)));
     }
     if (hipMemcpyAsync(out, c.feat, (size_t)s.n_seq * s.out_dim * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return VLSA_ELAUNCH;
     return VLSA_OK;
@@ -2103,6 +2138,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
         TT_LAUNCHED();
     }
     static DeviceOnce once;
+    bool scattered = false;
     const size_t attn_lds = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
     if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds);
     // Round 6: with frozen weights and the CONCH shapes (d = 768: a wave's 192-column slab = 12 groups; few rows: the 16 x 96 / 16 x 32
@@ -2163,7 +2199,17 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             TT_TRY((launch_gemm_rows16<8, 18>(a, s.M, Mp, st)));
         }
         if (L == 0) {
-            launch_ln_bwd(c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp, st);
+            // the pass's last LayerNorm backward also writes d prompts_embedding when that is a contiguous [n, ctx_len, d] block
+            // (what autograd hands over): no memset, no scatter launch behind it
+            scattered = d % 256 == 0 && d <= 256 * kLnSlots4 && emb_tok_stride == d && emb_seq_stride > 0 && emb_seq_stride % d == 0
+                        && demb_floats % emb_seq_stride == 0 && (reinterpret_cast<uintptr_t>(demb) & 15) == 0;
+            if (scattered) {
+                ScatterArgs sc{demb, r->row_seq, r->row_src, emb_seq_stride, s.M, (int)(emb_seq_stride / d), (int)(demb_floats / d), (Mp + 3) / 4};
+                hipLaunchKernelGGL(k_tt_ln_bwd4, dim3(sc.ln_blocks + (sc.demb_rows + 3) / 4), dim3(256), 0, st, c.da, x_in, w.ln1_w, c.dxb, c.dxa,
+                                   c.dxa_t, d, Mp, sc);
+            } else {
+                launch_ln_bwd(c.da, x_in, w.ln1_w, c.dxb, c.dxa, c.dxa_t, d, Mp, st);
+            }
             TT_LAUNCHED();
         }
     }
@@ -2241,6 +2287,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
                            (float*)gr->pos_emb, (float*)gr->cls_emb);
         TT_LAUNCHED();
     }
+    if (scattered) return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;
     if (hipMemsetAsync(demb, 0, (size_t)demb_floats * sizeof(float), st) != hipSuccess) return VLSA_ELAUNCH;
     hipLaunchKernelGGL(k_tt_scatter, dim3(s.M), dim3(256), 0, st, c.dxa, d, demb, emb_seq_stride, emb_tok_stride, r->row_seq, r->row_src, s.M);
     return hipGetLastError() == hipSuccess ? VLSA_OK : VLSA_ELAUNCH;

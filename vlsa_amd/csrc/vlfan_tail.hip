@@ -822,10 +822,23 @@ int vlsa_launch_head_pooled_batch(const float* pooled, int B, int D, const float
 // 33.8 us for 32 bags (every workgroup re-pools its bag's rows and runs the drain + ticket chain; profiles/r04_step_kernel_stats.csv).
 namespace vlsa {
 __global__ __launch_bounds__(256) void k_pool_rows(const float* __restrict__ rows, int P, int D, int pool_mode,
-                                                    const float* __restrict__ pool_w, float* __restrict__ pooled) {
+                                                    const float* __restrict__ pool_w, float* __restrict__ pooled, int B,
+                                                    const float* __restrict__ T, float* __restrict__ That, float* __restrict__ tnorm) {
     __shared__ float spw[VLSA_MAX_P];
+    __shared__ float red[4];
     __builtin_amdgcn_s_setprio(VLSA_TAIL_PRIO);
     const int tid = threadIdx.x, bag = blockIdx.x;
+    if (bag >= B) {      // workgroups behind the bags (vlsa_head_forward_batch_text): T^[r] = T[r] / max(|T[r]|, eps), k_normalize_rows' arithmetic
+        const int r = bag - B;
+        const float* x = T + (size_t)r * D;
+        float ss = 0.f;
+        for (int d = tid; d < D; d += 256) ss += x[d] * x[d];
+        ss = block_sum_256(ss, red);
+        const float nrm = fmaxf(sqrtf(ss), kNormEps);
+        for (int d = tid; d < D; d += 256) That[(size_t)r * D + d] = x[d] / nrm;
+        if (tnorm != nullptr && tid == 0) tnorm[r] = nrm;
+        return;
+    }
     if (pool_mode == VLSA_POOL_WEIGHT) {
         if (tid == 0) {
             float mx = -INFINITY, s = 0.f;
@@ -843,7 +856,24 @@ int vlsa_launch_head_rows_batch(const float* rows, int B, int P, int D, int pool
                                 float* vhat, float* vnorm, float* logits, float* incidence, hipStream_t s) {
     if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT) return VLSA_EINVAL;
     if (pool_mode == VLSA_POOL_WEIGHT && !pool_w) return VLSA_EINVAL;
-    hipLaunchKernelGGL(vlsa::k_pool_rows, dim3(B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, pooled);
+    hipLaunchKernelGGL(vlsa::k_pool_rows, dim3(B), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, pooled, B, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr);
+    if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
+    return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
+}
+
+// The training step's head from the RAW text features: vlsa_normalize_rows(T) + vlsa_head_forward_batch in three launches instead of
+// four -- the K rows of T are normalised by K extra workgroups of the pooling launch (they are independent of the bags' rows, and inside
+// the graph-replayed step a launch of its own costs them ~4.8 us).  Writes That [K, D] and tnorm [K] as vlsa_normalize_rows does.
+extern "C" int vlsa_head_forward_batch_text(const float* rows, int B, int P, int D, int pool_mode, const float* pool_w, const float* W,
+                                            const float* b, const float* T, int K, const float* logit_scale, float* That, float* tnorm,
+                                            float* pooled, float* v, float* vhat, float* vnorm, float* logits, float* incidence,
+                                            void* stream) {
+    if (!rows || !T || !That || !tnorm || !logit_scale || !pooled || !v || !vhat || !vnorm || !logits) return VLSA_EINVAL;
+    if (B < 1 || P < 1 || P > VLSA_MAX_P || K < 1 || K > VLSA_MAX_K || D <= 0 || D > VLSA_MAX_D || (D % 4) != 0) return VLSA_EINVAL;
+    if (pool_mode < VLSA_POOL_MEAN || pool_mode > VLSA_POOL_WEIGHT || (pool_mode == VLSA_POOL_WEIGHT && !pool_w) || pooled == rows) return VLSA_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(vlsa::k_pool_rows, dim3(B + K), dim3(256), 0, s, rows, P, D, pool_mode, pool_w, pooled, B, T, That, tnorm);
     if (hipGetLastError() != hipSuccess) return VLSA_ELAUNCH;
     return vlsa_launch_head_pooled_batch(pooled, B, D, W, b, That, K, logit_scale, v, vhat, vnorm, logits, incidence, s);
 }

@@ -244,8 +244,8 @@ class HeadTickets:
 
 class _HeadTrainFn(torch.autograd.Function):
     """(logits [B, K], v^ [B, D], T^ [K, D]) from the aggregated rows [B, P, D]: mean query pooling, Linear / identity adapter,
-    normalisation and cosine logits (model/deepmil.py:203-204, model/vlsa.py:188-192) -- two launches forward
-    (vlsa_normalize_rows, vlsa_head_forward_batch), two backward (vlsa_head_backward_batch), in place of ~40 autograd kernels:
+    normalisation and cosine logits (model/deepmil.py:203-204, model/vlsa.py:188-192) -- ONE host call and three launches forward
+    (vlsa_head_forward_batch_text; one bag: vlsa_normalize_rows + vlsa_head_forward_batch), two backward (vlsa_head_backward_batch), in place of ~40 autograd kernels:
     the optimizer step is bound by its number of dependent launches."""
 
     @staticmethod
@@ -257,16 +257,22 @@ class _HeadTrainFn(torch.autograd.Function):
         dev = rows.device
         Tc = _f32c(T)
         K = Tc.shape[0]
-        That, tnorm = normalize_rows(Tc)
         Wc = None if W is None else _f32c(W)
         bc = None if b is None else _f32c(b)
         ls = _f32c(logit_scale).reshape(1)
-        # the kernel hands the tickets back zeroed; without an owner: a fresh zeroed buffer (one memset launch more)
-        tk = torch.zeros(B, dtype=torch.int32, device=dev) if tickets is None else tickets.get(dev, B, s.value or 0)
         f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
         pooled, v, vhat, vnorm, logits = f(B, D), f(B, D), f(B, D), f(B), f(B, K)
-        nat.check(lib.vlsa_head_forward_batch(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(That), K, _p(ls), _p(tk),
-                                              _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), None, s), "vlsa_head_forward_batch")
+        if B > 1:
+            # (the text normalisation rides in the pooling launch: three launches for the head, no tickets)
+            That, tnorm = f(K, D), f(K)
+            nat.check(lib.vlsa_head_forward_batch_text(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(Tc), K, _p(ls), _p(That), _p(tnorm),
+                                                       _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), None, s), "vlsa_head_forward_batch_text")
+        else:
+            That, tnorm = normalize_rows(Tc)
+            # the kernel hands the tickets back zeroed; without an owner: a fresh zeroed buffer (one memset launch more)
+            tk = torch.zeros(B, dtype=torch.int32, device=dev) if tickets is None else tickets.get(dev, B, s.value or 0)
+            nat.check(lib.vlsa_head_forward_batch(_p(rows), B, P, D, nat.POOL_MEAN, None, _p(Wc), _p(bc), _p(That), K, _p(ls), _p(tk),
+                                                  _p(pooled), _p(v), _p(vhat), _p(vnorm), _p(logits), None, s), "vlsa_head_forward_batch")
         ctx.save_for_backward(pooled, vhat, vnorm, That, tnorm, logits, ls, *([Wc] if Wc is not None else []))
         ctx.meta = (B, P, D, K, Wc is not None, b is not None, tuple(logit_scale.shape))
         return logits, vhat, That

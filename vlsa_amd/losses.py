@@ -139,3 +139,25 @@ class SurvObjective(nn.Module):
             ls = ls.detach().exp() if isinstance(ls, torch.Tensor) else float(torch.tensor(ls).exp())
         loss = _SurvLossFn.apply(raw_pred, t, e, ls, True, self.alpha, self.eps, self.p, self.raw, self.w1, self.w2)
         return loss.mean()
+
+    def value_and_grad(self, raw_pred, t, e=None, log_logit_scale=None):
+        """(objective, d objective / d raw_pred) from the one launch, outside autograd -- for a caller that owns the step and starts the
+        backward pass itself with ``raw_pred.backward(grad)`` (``vlsa_amd.train_step.TrainStep``): ``loss.backward()`` costs two more
+        launches (the ones_like seed and its product with the saved gradient), ~10 us of a graph-replayed step.  [B <= 4096, K] logits
+        on the GPU, the raw (log) logit scale as a tensor."""
+        if e is None:
+            t, e = t[:, 0], t[:, 1]
+        lib = nat.load()
+        x = raw_pred.detach().float().contiguous()
+        _need_gpu(x)
+        B, K = x.shape
+        t = t.reshape(-1).to(device=x.device, dtype=torch.int64).contiguous()
+        e = e.reshape(-1).to(device=x.device, dtype=torch.float32).contiguous()
+        if t.numel() != B or e.numel() != B:
+            raise ValueError("t and e must hold one entry per sample")
+        ls = log_logit_scale.detach().to(device=x.device, dtype=torch.float32).reshape(1).contiguous()
+        out = torch.empty(1 + B * K, dtype=torch.float32, device=x.device)
+        g = out[1:].view(B, K)
+        nat.check(lib.vlsa_surv_objective(_p(x), _p(t), _p(e), B, K, 1, _p(ls), 1, float(self.alpha), float(self.eps), int(self.p),
+                                          int(self.raw), float(self.w1), float(self.w2), _p(out), _p(g), _stream()), "vlsa_surv_objective")
+        return out[0], g

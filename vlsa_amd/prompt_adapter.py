@@ -171,7 +171,7 @@ class PromptAdapter(nn.Module):
         return raw
 
     def forward(self):
-        pf = self._feature("prompt_features").clone()
+        pf = self._feature("prompt_features")       # (read only below: every method is out of place; only the pass-through hands out a copy)
         has_neg = self._has_neg()
         if self.method == "Adapter":
             return (1 - self.keep_ratio) * self.adapter(pf) + self.keep_ratio * pf
@@ -188,4 +188,4 @@ class PromptAdapter(nn.Module):
         if self.method == "FC":
             src = torch.cat([pf, self.neg_prompt_features.clone()], dim=0) if has_neg else pf
             return self.fc(src)
-        return pf
+        return pf.clone()

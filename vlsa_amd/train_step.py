@@ -67,12 +67,15 @@ class TrainStep:
     def _eager(self, bags, t, e):
         net = self.net
         logits = net.forward_bags(bags)[0]
-        if self._obj_takes_log:         # vlsa_amd.losses.SurvObjective: the exp of the logit scale happens inside its one launch
-            loss = self.objective(logits, t, e, log_logit_scale=net.logit_scale)
+        self.opt.zero_grad(set_to_none=True)
+        if self._obj_takes_log and logits.dim() == 2 and logits.shape[0] <= 4096:
+            # vlsa_amd.losses.SurvObjective: value AND gradient come out of its one launch (with the exp of the logit scale), so the
+            # backward pass starts at the logits -- no ones_like seed, no product with the saved gradient (two launches of ~5 us)
+            loss, g = self.objective.value_and_grad(logits, t, e, log_logit_scale=net.logit_scale)
+            logits.backward(g)
         else:
             loss = self.objective(logits, t, e, net.get_logit_scale())
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+            loss.backward()
         if self.world > 1:
             self._allreduce_grads()
         self.opt.step()
