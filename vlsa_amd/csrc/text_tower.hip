@@ -141,6 +141,8 @@ struct GemmArgs {
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
     int M_store;           // > 0: Y has only this many rows (a caller's buffer without padding): rows behind them are not stored
+    int lda, a_rows;       // NTW == 1 kernels only: lda > 0 = A is ROW-MAJOR [a_rows, lda] (a caller's buffer: the first product of the backward
+                           // pass reads the incoming gradient as it lies); rows behind a_rows - 1 repeat the last one (their results are padding)
 };
 
 // Tile choice (measured, K = 12 prompts -> 192 padded rows): the operands reach the MFMAs through the CU's L1 at ~46 B/clk, and an
@@ -235,6 +237,17 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
     const float* Ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) Ap[t] = p.A + ((size_t)((m0 >> 4) + t) * KG + (kbeg >> 4)) * 256 + lane * 4;
+    int astep = 256;       // floats from one 16-column group of the A operand to the next
+    if constexpr (NTW == 1) {
+        if (p.lda > 0) {   // row-major A: lane (r, g) of a fragment holds A[row r][16 jj + 4 g .. + 3]
+            astep = 16;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int row = m0 + 16 * t + r;
+                Ap[t] = p.A + (size_t)(row < p.a_rows ? row : p.a_rows - 1) * p.lda + kbeg + 4 * g;
+            }
+        }
+    }
     const float* Wp[NTW];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) Wp[u] = p.W + ((size_t)((n0 >> 4) + u) * KG + (kbeg >> 4)) * 256 + lane * 4;
@@ -575,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
         for (int sI = 0; sI < PF; ++sI)
             if (sI < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * sI);
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + (NTW == 1 ? astep : 256) * sI);
 #pragma unroll
                 for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * sI);
             }
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
             for (int u = 0; u < NTW; ++u) b[u] = rb[sI][u];
             if (jj + PF < G) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + 256 * (jj + PF));
+                for (int t = 0; t < MT; ++t) ra[sI][t] = *reinterpret_cast<const f32x4*>(Ap[t] + (NTW == 1 ? astep : 256) * (jj + PF));
 #pragma unroll
                 for (int u = 0; u < NTW; ++u) rb[sI][u] = *reinterpret_cast<const f32x4*>(Wp[u] + 256 * (jj + PF));
             }
@@ -758,7 +771,23 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         }
         const bool is_cls = !pfx_block && i == S - 1;
         float dot = 0.f, dp = 0.f;
-        if (j < S) {
+        if (S <= 16) {
+            // short prompts (the rank prompts: 13 keys): lane = (quarter of the 64 features, key) -- 16 x 4 LDS reads per lane instead of
+            // 64 x 4 with three quarters of the lanes idle; the quarters' partial dots meet through two lane exchanges, every quarter then
+            // holds the whole dot and quarter 0 alone feeds the row sums below (the LDS port is what this phase waits for: 8 waves of a
+            // workgroup share it)
+            const int jj = lane & 15, cq = (lane >> 4) * 16, jc = jj < S ? jj : S - 1;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                dot = fmaf(Qs[i * LD + cq + c], Ks[jc * LD + cq + c], dot);
+                dp = fmaf(Os[i * LD + cq + c], Vs[jc * LD + cq + c], dp);
+            }
+            dot += __shfl_xor(dot, 16);
+            dp += __shfl_xor(dp, 16);
+            dot += __shfl_xor(dot, 32);
+            dp += __shfl_xor(dp, 32);
+            // lanes 16 .. 63 hold copies: they take no part in the sums (j >= S: not ok) -- the copies of lanes 0 .. 15 are what is stored
+        } else if (j < S) {
 #pragma unroll
             for (int c = 0; c < kHeadDim; ++c) {
                 dot = fmaf(Qs[i * LD + c], Ks[j * LD + c], dot);
@@ -2114,14 +2143,18 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
     const Scratch c = scratch_of(ws + (size_t)s.layers * LF, s);
     const float* bset = static_cast<const float*>(packed) + set_floats(s);
 
-    hipLaunchKernelGGL(k_tt_tile_rows, dim3(s.ns_pad / 16, s.out_dim / 16), dim3(256), 0, st, dout, s.n_seq, s.out_dim, c.dout_t);
-    TT_LAUNCHED();
     {   // d pooled = dout @ text_projection^T
         GemmArgs a = gemm_args(c.dout_t, packed_proj(bset, s), d, s.out_dim);
         a.Y = c.dpool; a.ldy = d;
         a.M_real = s.n_seq;
-        if (d % 16 == 0 && s.out_dim / 4 / 16 == 8) TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 8, 1>(a, s.ns_pad, st)));
-        else TT_TRY((launch_gemm<3, 4, PRO_NONE, 8>(a, s.ns_pad, st)));
+        if (d % 16 == 0 && s.out_dim / 4 / 16 == 8 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) {
+            a.A = dout; a.lda = s.out_dim; a.a_rows = s.n_seq;       // the incoming gradient as it lies (no tiling launch in front)
+            TT_TRY((launch_gemm_g<1, 4, PRO_NONE, 8, 1>(a, s.ns_pad, st)));
+        } else {
+            hipLaunchKernelGGL(k_tt_tile_rows, dim3(s.ns_pad / 16, s.out_dim / 16), dim3(256), 0, st, dout, s.n_seq, s.out_dim, c.dout_t);
+            TT_LAUNCHED();
+            TT_TRY((launch_gemm<3, 4, PRO_NONE, 8>(a, s.ns_pad, st)));
+        }
     }
     hipLaunchKernelGGL(k_tt_lnf_bwd, dim3((Mp + 3) / 4), dim3(256), 0, st, c.dpool, c.x_final, r->row_seq, r->row_src, m->lnf_w, c.dxa,
                        c.dxa_t, d, s.M, Mp);
