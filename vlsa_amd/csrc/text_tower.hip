@@ -738,6 +738,12 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
                                                     float* __restrict__ pfx, unsigned int* __restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ bool s_last;
+#ifdef VLSA_EXPERIMENT
+    const int abl = ldo >> 16;      // timing-only ablations (tools/attn_bwd_ablate.sh): 1 = no prefix fold, 2 = no phase 2, 4 = no phase 1, 8 = loads only
+    ldo &= 0xffff;
+#else
+    constexpr int abl = 0;
+#endif
     constexpr int LD = kHeadDim + 1;
     float* Qs = sm;
     float* Ks = Qs + kAttnBwdMaxS * LD;
@@ -762,7 +768,8 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         Os[j * LD + c] = dout[(size_t)grow(j) * ldo + h * kHeadDim + c];
     }
     __syncthreads();
-    for (int i = w; i < S; i += nwave) {   // lane j: score, weight and their gradients for key j of query row i
+    if (abl & 8) return;
+    for (int i = (abl & 4) ? S : w; i < S; i += nwave) {   // lane j: score, weight and their gradients for key j of query row i
         const int j = lane;
         if (i < qbeg) {                // prefix rows are queries of the prefix block only
             Pm[i * LD + j] = 0.f;
@@ -771,23 +778,7 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         }
         const bool is_cls = !pfx_block && i == S - 1;
         float dot = 0.f, dp = 0.f;
-        if (S <= 16) {
-            // short prompts (the rank prompts: 13 keys): lane = (quarter of the 64 features, key) -- 16 x 4 LDS reads per lane instead of
-            // 64 x 4 with three quarters of the lanes idle; the quarters' partial dots meet through two lane exchanges, every quarter then
-            // holds the whole dot and quarter 0 alone feeds the row sums below (the LDS port is what this phase waits for: 8 waves of a
-            // workgroup share it)
-            const int jj = lane & 15, cq = (lane >> 4) * 16, jc = jj < S ? jj : S - 1;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                dot = fmaf(Qs[i * LD + cq + c], Ks[jc * LD + cq + c], dot);
-                dp = fmaf(Os[i * LD + cq + c], Vs[jc * LD + cq + c], dp);
-            }
-            dot += __shfl_xor(dot, 16);
-            dp += __shfl_xor(dp, 16);
-            dot += __shfl_xor(dot, 32);
-            dp += __shfl_xor(dp, 32);
-            // lanes 16 .. 63 hold copies: they take no part in the sums (j >= S: not ok) -- the copies of lanes 0 .. 15 are what is stored
-        } else if (j < S) {
+        if (j < S) {
 #pragma unroll
             for (int c = 0; c < kHeadDim; ++c) {
                 dot = fmaf(Qs[i * LD + c], Ks[j * LD + c], dot);
@@ -804,8 +795,8 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         Dm[i * LD + j] = p * (dp - delta) * 0.125f;
     }
     __syncthreads();
-    const bool shared_keys = L > 0;
-    for (int rr = w; rr < S; rr += nwave) {   // lane = feature c of row rr: dQ, dK, dV
+    const bool shared_keys = L > 0 && !(abl & 1);
+    for (int rr = (abl & 2) ? S : w; rr < S; rr += nwave) {   // lane = feature c of row rr: dQ, dK, dV
         float dq = 0.f, dk = 0.f, dv = 0.f;
         for (int j = 0; j < S; ++j) {
             dq = fmaf(Dm[rr * LD + j], Ks[j * LD + lane], dq);
@@ -825,6 +816,11 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         }
     }
     if (!shared_keys) return;
+    // (Round 6, timing-only ablations, profiles/r06_attn_bwd_ablate.txt: of this launch's 10.8 us the fold below is 3.3 -- three dependent
+    //  trips through the memory fabric: drain of the write-through stores, the ticket, the shares' loads --, phase 2 above 2.1, phase 1
+    //  0.7, the loads 4.5 with the launch itself.  Tried and not kept: the shares first and the ticket taken before the rest of phase 2
+    //  (the drain then stalls the whole workgroup in the middle: 3.1), phase 2's LDS reads batched (2.1 -> 2.1), phase 1 on
+    //  (feature quarter, key) lanes (no change: it is 0.7 us).)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
@@ -1853,6 +1849,15 @@ void launch_ln_bwd(const float* da, const float* x, const float* gamma, const fl
         hipLaunchKernelGGL(k_tt_ln_bwd, dim3((rows + 3) / 4), dim3(256), 0, st, da, x, gamma, dres, dx, dxt, d, rows);
 }
 
+// (measurement aid: the attention backward's timing-only ablation bits ride in the high half of its `ldo` argument, -DVLSA_EXPERIMENT only)
+inline int attn_bwd_ldo(int d) {
+#ifdef VLSA_EXPERIMENT
+    static const int abl = VLSA_ENV("VLSA_TT_ATTN_ABL") ? atoi(VLSA_ENV("VLSA_TT_ATTN_ABL")) : 0;
+    return d | (abl << 16);
+#else
+    return d;
+#endif
+}
 // threads of an attention workgroup: a wave per row of the prompt (up to 16 waves); VLSA_TT_ATTN_THREADS overrides (A/B hook)
 int attn_threads(int max_len) {
     if (const char* e = VLSA_ENV("VLSA_TT_ATTN_THREADS")) {
@@ -2220,7 +2225,7 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             prefetch_for(a, true, pw.in_w, d, 3 * d, 2);
             TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 2>(a, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, attn_bwd_ldo(d),
                            c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
         TT_LAUNCHED();
         {   // d ln_1 out = dqkv @ W_in
