@@ -67,6 +67,9 @@ def test_objective_from_raw_logits(B, K, extreme):
     (3.0 * got2).backward()
     assert abs(got2.item() - got.item()) < 2e-6 * max(1.0, abs(got.item()))
     assert (xd2.grad - 3.0 * xd.grad).abs().max().item() < 1e-5 * max(1.0, xd.grad.abs().max().item())
+    # value_and_grad (what TrainStep starts its backward pass from): the same launch outside autograd -- bit-equal to the route above
+    v3, g3 = SurvObjective().value_and_grad(logits.cuda(), t.cuda(), e.cuda(), log_logit_scale=torch.tensor(cases.LOGIT_SCALE).cuda())
+    assert torch.equal(v3, got2.detach()) and torch.equal(3.0 * g3, xd2.grad)
 
 
 def test_objective_of_a_large_batch_takes_the_per_sample_route():

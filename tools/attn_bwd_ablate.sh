@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r06
 O=gpurun_out/r06/attn_bwd_ablate.txt
 E=$PWD/vlsa_amd/_lib/libvlsa_hip_exp.so
 : > $O
-for abl in 0 1 3 7 8; do
+for abl in ${ABLS:-0 1 3 7 8}; do
   rm -rf gpurun_out/r06/abl
   VLSA_HIP_LIB=$E VLSA_TT_ATTN_ABL=$abl rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06/abl -- python tools/bench_text.py > /dev/null 2>&1
   echo "== VLSA_TT_ATTN_ABL=$abl" >> $O

@@ -675,7 +675,9 @@ __global__ __launch_bounds__(NW * 64) void k_tt_gemm(const GemmArgs p) {
 constexpr int kAttnMaxS = 128;
 __global__ __launch_bounds__(1024) void k_tt_attn_fwd(const float* __restrict__ qkv, int ld, float* __restrict__ out_t,
                                                     const int* __restrict__ seq_row0, const unsigned char* __restrict__ cls_keep,
-                                                    int heads, int d, int n_seq, int L) {
+                                                    int heads, int d, int n_seq, int L, float* __restrict__ stats) {
+    // stats (nullable; the forward that saves for the backward pass): [row][head][2] = (max of the row's scaled scores, 1 / sum of the
+    // exponentials) -- with them and the kept output the backward can form the prefix keys' dK / dV without a sum across workgroups
     __shared__ float Ks[kAttnMaxS][kHeadDim + 1];
     __shared__ float Vs[kAttnMaxS][kHeadDim + 1];
     __shared__ float Qs[kAttnMaxS][kHeadDim];
@@ -717,6 +719,7 @@ __global__ __launch_bounds__(1024) void k_tt_attn_fwd(const float* __restrict__ 
         const float inv = 1.f / wave_sum(p[0] + p[1]);
         p[0] *= inv;
         p[1] *= inv;
+        if (stats != nullptr && lane == 0) *reinterpret_cast<float2*>(stats + ((size_t)grow(i) * heads + h) * 2) = float2{m, inv};
         float o = 0.f;
         const int S0 = S < 64 ? S : 64;
         for (int j = 0; j < S0; ++j)
@@ -735,16 +738,124 @@ constexpr int kAttnBwdMaxS = 64;
 __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ qkv, int ld, const float* __restrict__ dout, int ldo,
                                                     float* __restrict__ dqkv, const int* __restrict__ seq_row0,
                                                     const unsigned char* __restrict__ cls_keep, int heads, int d, int n_seq, int L,
-                                                    float* __restrict__ pfx, unsigned int* __restrict__ cnt) {
+                                                    float* __restrict__ pfx, unsigned int* __restrict__ cnt,
+                                                    const float* __restrict__ O_t, const float* __restrict__ stats,
+                                                    const int* __restrict__ row_seq, int M, int use_stats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ bool s_last;
 #ifdef VLSA_EXPERIMENT
-    const int abl = ldo >> 16;      // timing-only ablations (tools/attn_bwd_ablate.sh): 1 = no prefix fold, 2 = no phase 2, 4 = no phase 1, 8 = loads only
+    const int abl = ldo >> 16;      // timing-only ablations (tools/attn_bwd_ablate.sh): 1 = no prefix fold, 2 = no phase 2, 4 = no phase 1, 8 = loads only, 16 / 32 = key workgroups: nothing / loads only
     ldo &= 0xffff;
 #else
     constexpr int abl = 0;
 #endif
     constexpr int LD = kHeadDim + 1;
+    if (use_stats && (int)blockIdx.x >= (n_seq + 1) * heads) {
+        // ---- round 6: a workgroup per (prefix key jk, head): dK / dV of the key over ALL M query rows, from the forward's row statistics
+        // (m, 1 / l) and its kept output O (delta_i = dO_i . O_i) -- no shares, no ticket, no fold.  M <= 128 rows (host).
+        //   A   lane = query row (two halves of 64), wave = (half, slice of the 64 features): partial q.k, dO.v, dO.O      -> LDS
+        //   A2  two waves, lane = row: the slices summed in order, weight p = exp(s - m) / l under the row's mask, d score    -> LDS
+        //   B   lane = feature, the rows dealt over the waves: dK += d score * q, dV += p * dO                               -> LDS
+        //   C   two waves add the waves' sums in wave order and store.
+        // (First version: lane = feature throughout, three lane sums per row -- 80 VALU instructions per row on every wave, 3.3 us of
+        //  issue time with 3-4 waves per SIMD; profiles/r06_attn_bwd_ablate2.txt.)
+        // use_stats = keys per workgroup (1 .. 4: the host keeps the grid within one round of the CUs; the q / dO / O rows are loaded once)
+        const int idx = (int)blockIdx.x - (n_seq + 1) * heads, hh = idx % heads, jk0 = (idx / heads) * use_stats;
+        const int nk = L - jk0 < use_stats ? L - jk0 : use_stats;
+        if (abl & 16) return;
+        const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+        constexpr int MR = 128;
+        float* Qa = sm;                       // [MR][LD] q, dO, O of the head
+        float* Da = Qa + MR * LD;
+        float* Oa = Da + MR * LD;
+        float* part = Oa + MR * LD;           // A: [8 slices][3][MR];  B / C: the waves' sums [16][128]
+        float* st = part + 8 * 3 * MR;        // [MR][2] m, 1 / l
+        float* vis = st + 2 * MR;             // [4][MR] the row sees the key
+        float* Pd = vis + 4 * MR;             // [MR] p, [MR] d score
+        float* kv = Pd + 2 * MR;              // [4][128] k_jk | v_jk
+        for (int e = tid; e < M * kHeadDim; e += nthr) {
+            const int r = e >> 6, c = e & 63;
+            Qa[r * LD + c] = qkv[(size_t)r * ld + hh * kHeadDim + c];
+            Da[r * LD + c] = dout[(size_t)r * ldo + hh * kHeadDim + c];
+            Oa[r * LD + c] = O_t[tiled_index(r, hh * kHeadDim + c, d)];
+        }
+        for (int r = tid; r < M; r += nthr) {
+            const float2 ml = *reinterpret_cast<const float2*>(stats + ((size_t)r * heads + hh) * 2);
+            st[2 * r] = ml.x;
+            st[2 * r + 1] = ml.y;
+            const bool cls_row = r >= L && r == seq_row0[row_seq[r] + 1] - 1;
+            for (int kk = 0; kk < nk; ++kk) {
+                const int jk = jk0 + kk;
+                // the prefix rows among themselves: causal; a prompt's CLS row sees the flagged rows; its tokens see every prefix key
+                const bool ok = r < L ? jk <= r : (cls_row ? cls_keep[jk] != 0 : true);
+                vis[kk * MR + r] = ok ? 1.f : 0.f;
+            }
+        }
+        for (int e = tid; e < nk * 128; e += nthr) {
+            const int kk = e >> 7, t = e & 127;
+            kv[e] = qkv[(size_t)(jk0 + kk) * ld + (t < 64 ? d : 2 * d) + hh * kHeadDim + (t & 63)];
+        }
+        __syncthreads();
+        if (abl & 32) return;
+        const int ncs = nwave >> 1 < 8 ? nwave >> 1 : 8;      // feature slices (13 waves: 6)
+        for (int kk = 0; kk < nk; ++kk) {
+        const int jk = jk0 + kk;
+        const float* kvk = kv + kk * 128;
+        const float* visk = vis + kk * MR;
+        if (kk) __syncthreads();              // (the previous key's phase C has read `part`)
+        {   // A
+            const int rh = w & 1, cs = w >> 1, r = 64 * rh + lane;
+            if (cs < ncs) {
+                const int c0 = cs * kHeadDim / ncs, c1 = (cs + 1) * kHeadDim / ncs;
+                float sa = 0.f, pa = 0.f, ea = 0.f;
+                if (r < M) {
+                    for (int c = c0; c < c1; ++c) {
+                        const float q = Qa[r * LD + c], g = Da[r * LD + c], o = Oa[r * LD + c];
+                        sa = fmaf(q, kvk[c], sa);
+                        pa = fmaf(g, kvk[64 + c], pa);
+                        ea = fmaf(g, o, ea);
+                    }
+                }
+                part[(cs * 3 + 0) * MR + r] = sa;
+                part[(cs * 3 + 1) * MR + r] = pa;
+                part[(cs * 3 + 2) * MR + r] = ea;
+            }
+        }
+        __syncthreads();
+        if (w < 2) {   // A2
+            const int r = 64 * w + lane;
+            float sa = 0.f, pa = 0.f, ea = 0.f;
+            for (int cs = 0; cs < ncs; ++cs) {
+                sa += part[(cs * 3 + 0) * MR + r];
+                pa += part[(cs * 3 + 1) * MR + r];
+                ea += part[(cs * 3 + 2) * MR + r];
+            }
+            const bool ok = r < M && visk[r] != 0.f;
+            const float pw = ok ? __expf(sa * 0.125f - st[2 * r]) * st[2 * r + 1] : 0.f;
+            Pd[r] = pw;
+            Pd[MR + r] = pw * (pa - ea) * 0.125f;
+        }
+        __syncthreads();
+        float dk = 0.f, dv = 0.f;
+        for (int r = w; r < M; r += nwave) {   // B
+            dk = fmaf(Pd[MR + r], Qa[r * LD + lane], dk);
+            dv = fmaf(Pd[r], Da[r * LD + lane], dv);
+        }
+        part[w * 128 + lane] = dk;
+        part[w * 128 + 64 + lane] = dv;
+        __syncthreads();
+        if (w < 2) {   // C
+            float t[16];
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) t[ww] = ww < nwave ? part[ww * 128 + 64 * w + lane] : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) acc += t[ww];
+            dqkv[tiled_index(jk, hh * kHeadDim + lane + (w ? 2 * d : d), 3 * d)] = acc;
+        }
+        }   // kk
+        return;
+    }
     float* Qs = sm;
     float* Ks = Qs + kAttnBwdMaxS * LD;
     float* Vs = Ks + kAttnBwdMaxS * LD;
@@ -797,6 +908,7 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
     __syncthreads();
     const bool shared_keys = L > 0 && !(abl & 1);
     for (int rr = (abl & 2) ? S : w; rr < S; rr += nwave) {   // lane = feature c of row rr: dQ, dK, dV
+        if (use_stats && rr < L && !pfx_block) continue;    // (nothing of a prefix row is this block's to write: its dQ is the prefix block's, its dK / dV the key blocks')
         float dq = 0.f, dk = 0.f, dv = 0.f;
         for (int j = 0; j < S; ++j) {
             dq = fmaf(Dm[rr * LD + j], Ks[j * LD + lane], dq);
@@ -809,13 +921,13 @@ __global__ __launch_bounds__(1024) void k_tt_attn_bwd(const float* __restrict__ 
         if (!pfx_row) {
             dqkv[tiled_index(grow(rr), col + d, 3 * d)] = dk;
             dqkv[tiled_index(grow(rr), col + 2 * d, 3 * d)] = dv;
-        } else {                                   // this block's share of a prefix row's dK / dV: published write-through
+        } else if (!use_stats) {                   // this block's share of a prefix row's dK / dV: published write-through
             float* pp = pfx + (((size_t)seq * heads + h) * L + rr) * 128;
             __hip_atomic_store(pp + lane, dk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(pp + 64 + lane, dv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (!shared_keys) return;
+    if (!shared_keys || use_stats) return;
     // (Round 6, timing-only ablations, profiles/r06_attn_bwd_ablate.txt: of this launch's 10.8 us the fold below is 3.3 -- three dependent
     //  trips through the memory fabric: drain of the write-through stores, the ticket, the shares' loads --, phase 2 above 2.1, phase 1
     //  0.7, the loads 4.5 with the launch itself.  Tried and not kept: the shares first and the ticket taken before the rest of phase 2
@@ -1687,14 +1799,19 @@ inline const float* packed_proj(const float* set, const Shape& s) { return set +
 
 // ---- workspace (floats).  Per-layer region (kept for backward when save != 0, else one region reused):
 //      x_in [M_pad, d] | qkv [M_pad, 3d] | x_mid [M_pad, d] | h_pre [M_pad, 4d]     (all row-major)
-//      | attn [M_pad, d] tiled: the attention output, kept per block only with save == 2 (its out_proj weight gradient needs it)
+//      | attn [M_pad, d] tiled: the attention output, kept per block by every saving forward (round 6: the attention backward's prefix-key
+//        workgroups need it; with save == 2 also the out_proj weight gradient)
 //      | x_in tiled [M_pad, d] | x_mid tiled [M_pad, d]   (round 6: the LayerNorm-backward prologues of the input-gradient products read them)
-inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 12 + (size_t)s.M_pad * 4; }
+inline size_t layer_floats(const Shape& s) { return (size_t)s.M_pad * s.d * 12 + (size_t)s.M_pad * 4 + (size_t)s.M_pad * 32; }
 inline float* layer_xin_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 10; }
 inline float* layer_xmid_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 11; }
 // (mean, rstd) of every row under ln_1 / ln_2 of the block: [M_pad][2] each, kept by the forward for the PRO_LNBWD prologues
 inline float* layer_stats1(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 12; }
 inline float* layer_stats2(float* region, const Shape& s) { return layer_stats1(region, s) + (size_t)s.M_pad * 2; }
+// the attention's row statistics (max, 1 / sum) [M_pad][heads <= 16][2] and -- in the `attn` slot of the region -- its output, kept by every
+// saving forward for the attention backward's prefix-key workgroups
+inline float* layer_astats(float* region, const Shape& s) { return layer_stats2(region, s) + (size_t)s.M_pad * 2; }
+inline float* layer_attn_t(float* region, const Shape& s) { return region + (size_t)s.M_pad * s.d * 9; }
 struct Scratch {   // behind the layer regions; *_t = tiled
     float *x_final, *xin_t, *xmid_t, *attn_t, *hact_t, *pooled_t, *feat;                              // forward
     float *dout_t, *dpool, *dxa, *dxa_t, *dxb, *dxb_t, *dh_t, *da, *da_t, *dattn, *dqkv_t;             // backward
@@ -2037,6 +2154,10 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
                                    layer_stats1(x_in, s), d, Mp);
                 hipLaunchKernelGGL(k_tt_ln_rows, dim3(Mp / 4), dim3(256), 0, st, x_mid, m->layer[L].ln2_w, m->layer[L].ln2_b, (float*)nullptr,
                                    layer_stats2(x_in, s), d, Mp);
+                // ... and the attention's output + row statistics (the attention once more, from the block's kept q / k / v)
+                hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), 0, st,
+                                   x_in + (size_t)Mp * d, 3 * d, layer_attn_t(x_in, s), r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L,
+                                   layer_astats(x_in, s));
             }
             TT_LAUNCHED();
         }
@@ -2049,7 +2170,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
         float* x_mid = qkv + (size_t)Mp * 3 * d;
         float* h_pre = x_mid + (size_t)Mp * d;
         float* x_next = (L + 1 < s.layers) ? (save_for_backward ? region(L + 1) : x_in) : c.x_final;
-        float* attn_t = keep_attn ? h_pre + (size_t)Mp * 4 * d : c.attn_t;
+        float* attn_t = save_for_backward ? layer_attn_t(x_in, s) : c.attn_t;
         // x_mid = x_in + out_proj(attention(ln_1(x_in)));  x_next = x_mid + c_proj(gelu(c_fc(ln_2(x_mid))))
         {
             GemmArgs a = gemm_args(xin_t_of(L), pw.in_w, 3 * d, d);
@@ -2070,7 +2191,7 @@ extern "C" int vlsa_tt_forward(const vlsa_tt_model* m, const vlsa_tt_rows* r, co
             else TT_TRY((launch_gemm_wide<3, 4, PRO_LN, 12>(a, Mp, st)));
         }
         hipLaunchKernelGGL(k_tt_attn_fwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), 0, st, qkv, 3 * d, attn_t, r->seq_row0,
-                           r->cls_keep, s.heads, d, s.n_seq, s.L);
+                           r->cls_keep, s.heads, d, s.n_seq, s.L, save_for_backward ? layer_astats(x_in, s) : (float*)nullptr);
         TT_LAUNCHED();
         {
             GemmArgs a = gemm_args(attn_t, pw.out_w, d, d);
@@ -2177,8 +2298,29 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
     }
     static DeviceOnce once;
     bool scattered = false;
-    const size_t attn_lds = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
-    if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds);
+    // Round 6: shared prefix, <= 128 compact rows (M; M_pad may be larger), and the extra L x heads workgroups still fit one round of the CUs: the prefix keys'
+    // dK / dV come from a workgroup per (key, head) over all query rows (the forward's attention statistics + output) instead of the
+    // ticketed fold of per-prompt shares (3.3 of the launch's 10.8 us: profiles/r06_attn_bwd_ablate.txt)
+    // keys per key workgroup: the fewest (<= 4) that keep the grid within 256 workgroups
+    int use_stats = 0;
+    if (s.L > 0 && s.M <= 128 && s.heads <= 16)
+        for (int kpb = 1; kpb <= 4 && !use_stats; ++kpb)
+            if ((s.n_seq + 1 + (s.L + kpb - 1) / kpb) * s.heads <= 256) use_stats = kpb;
+#ifdef VLSA_EXPERIMENT
+    if (VLSA_ENV("VLSA_TT_NOSTATS")) use_stats = 0;
+    if (VLSA_ENV("VLSA_TT_DEBUG_STATS")) fprintf(stderr, "[tt_backward] use_stats=%d L=%d Mp=%d heads=%d n_seq=%d\n", (int)use_stats, s.L, Mp, s.heads, s.n_seq);
+#endif
+    const size_t lds_ticket = (size_t)6 * kAttnBwdMaxS * (kHeadDim + 1) * sizeof(float);
+    const size_t lds_stats = ((size_t)3 * 128 * (kHeadDim + 1) + 8 * 3 * 128 + 12 * 128) * sizeof(float);
+    const size_t attn_lds = use_stats && lds_stats > lds_ticket ? lds_stats : lds_ticket;
+    size_t attn_lds_x = attn_lds;
+    int attn_grid_x = (s.n_seq + (s.L > 0 ? 1 : 0) + (use_stats ? (s.L + use_stats - 1) / use_stats : 0)) * s.heads;
+#ifdef VLSA_EXPERIMENT
+    if (const char* e = VLSA_ENV("VLSA_TT_ATTN_LDS")) attn_lds_x = (size_t)atoi(e);      // (timing only)
+    if (const char* e = VLSA_ENV("VLSA_TT_ATTN_GRID")) attn_grid_x = atoi(e);
+#endif
+    const int attn_grid = attn_grid_x;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)k_tt_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_stats > lds_ticket ? lds_stats : lds_ticket));
     // Round 6: with frozen weights and the CONCH shapes (d = 768: a wave's 192-column slab = 12 groups; few rows: the 16 x 96 / 16 x 32
     // products) both LayerNorm backward passes of a block run as PROLOGUES of the products that consume their result (PRO_LNBWD):
     //   ln_2 backward  -> in front of  d attn = dx_mid W_out          (this block)
@@ -2225,8 +2367,9 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             prefetch_for(a, true, pw.in_w, d, 3 * d, 2);
             TT_TRY((launch_gemm_g<1, 4, PRO_LNBWD, 12, 2>(a, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, attn_bwd_ldo(d),
-                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3(attn_grid), dim3(attn_threads(r->max_len)), attn_lds_x, st, qkv, 3 * d, c.dattn, attn_bwd_ldo(d),
+                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt, layer_attn_t(x_in, s), layer_astats(x_in, s),
+                           r->row_seq, s.M, use_stats);
         TT_LAUNCHED();
         {   // d ln_1 out = dqkv @ W_in
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
@@ -2301,8 +2444,9 @@ int tt_backward(const vlsa_tt_model* m, const vlsa_tt_rows* r, const void* packe
             a.Y = c.dattn; a.ldy = d;
             TT_TRY((launch_gemm_rows16<4, 12>(a, s.M, Mp, st)));
         }
-        hipLaunchKernelGGL(k_tt_attn_bwd, dim3((s.n_seq + (s.L > 0 ? 1 : 0)) * s.heads), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
-                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt);
+        hipLaunchKernelGGL(k_tt_attn_bwd, dim3(attn_grid), dim3(attn_threads(r->max_len)), attn_lds, st, qkv, 3 * d, c.dattn, d,
+                           c.dqkv_t, r->seq_row0, r->cls_keep, s.heads, d, s.n_seq, s.L, c.pfx, c.cnt, layer_attn_t(x_in, s), layer_astats(x_in, s),
+                           r->row_seq, s.M, use_stats);
         TT_LAUNCHED();
         {   // d ln_1 out = dqkv @ W_in   (rows M .. M_pad-1 of dqkv_t are never written: they only reach discarded padding rows)
             GemmArgs a = gemm_args(c.dqkv_t, pw.in_w, d, 3 * d);
