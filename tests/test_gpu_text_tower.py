@@ -70,6 +70,30 @@ def test_rank_prompts_through_the_tower_forward_and_backward(case):
     assert np.abs(pl.rank_embeds.grad.cpu().numpy() - fx["grad_rank"]).max() < TOL * max(1.0, np.abs(fx["grad_rank"]).max())
 
 
+def test_shared_prefix_of_many_prompts_takes_the_ticketed_fold():
+    """More than 128 compact rows with a shared prefix: the attention backward cannot hold all query rows in one workgroup's LDS and folds
+    the prompts' shares of the prefix keys' dK / dV through the per-head ticket (the route every shared-prefix case took before round 6).
+    30 rank prompts on the CONCH-size tower: features and gradients with the prefix evaluated once = the row-per-position route."""
+    base_case = next(c for c in TC.RANK_CASES if c[0] == "rank_conch_k4")
+    case = (base_case[0], base_case[1], base_case[2], 30, base_case[4], base_case[5])
+    inp = TH.rank_case_inputs(base_case)
+    enc = build_encoder(case[1], case[2])
+    pl = build_learner(case, inp).cuda()
+    L = pl.shared_prefix_len
+    tok = pl.pseudo_sentence_tokens
+    assert L > 0 and enc._plan(tok, torch.device("cuda", 0), L).M > 128
+    G = torch.randn(30, enc.output_dim, generator=torch.Generator().manual_seed(77)).cuda()
+    out = {}
+    for name, pref in (("rows", 0), ("prefix", L)):
+        pl.zero_grad(set_to_none=True)
+        f = enc(prompts_embedding=pl(), prompts_pseudo_tokens=tok, shared_prefix_len=pref)
+        (f * G).sum().backward()
+        out[name] = (f.detach().clone(), pl.context_embeds.grad.clone(), pl.rank_embeds.grad.clone())
+    for a, b, what in zip(out["rows"], out["prefix"], ("features", "d context", "d rank")):
+        err, scale = (a - b).abs().max().item(), max(1.0, a.abs().max().item())
+        assert err < TOL * scale, (what, err, scale)
+
+
 @pytest.mark.parametrize("case", TC.TEXT_CASES, ids=[c[0] for c in TC.TEXT_CASES])
 def test_tokenised_text_path(case):
     (name, tower, seed, lens) = case
