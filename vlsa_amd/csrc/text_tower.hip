@@ -26,9 +26,15 @@
 //                         reduced through LDS (deterministic, no atomics).  pro = LayerNorm fused into the A-operand load
 //                         (the wave's whole A slab sits in registers; row statistics by a two-pass reduction across the
 //                         waves), or identity.  The one product kernel serves forward, backward and the text projection.
+//                         Round 6: pro = LayerNorm BACKWARD as well (both LayerNorm backward passes of a block ride in front of the
+//                         products that consume them), and every product touches the NEXT product's weights -- one dword per
+//                         128-byte line, into the L2 of the XCD that will read them (prefetch_next) -- once its own ring is issued.
 //   k_tt_attn_fwd/bwd     per (prompt, head) attention over the compact rows: causal for token rows, explicit key list for
-//                         the CLS row; <= 128 rows forward, <= 64 rows backward.
-//   k_tt_ln_bwd, k_tt_lnf_fwd/bwd, k_tt_scatter   LayerNorm backward (+ residual), ln_final on the CLS rows, d prompts_embedding.
+//                         the CLS row; <= 128 rows forward, <= 64 rows backward.  Shared prefix: its keys' dK / dV come from one more
+//                         workgroup per (1-2 keys, head) over all query rows, from the row statistics and the output the forward
+//                         keeps (<= 128 compact rows), else from a ticketed fixed-order fold of the prompts' shares.
+//   k_tt_ln_bwd, k_tt_lnf_fwd/bwd, k_tt_scatter   LayerNorm backward (+ residual; the pass's last one also writes d prompts_embedding),
+//                         ln_final on the CLS rows, d prompts_embedding (the general route).
 // Backward is w.r.t. the prompt embeddings only: the tower is frozen in every shipped configuration
 // (vlsa_txt_encoder_frozen: True, cfg_vlsa_conch.yaml:69; runner/vlsa_handler.py:131).
 #include "vlsa_common.h"
