@@ -113,3 +113,40 @@ def test_merge_head_entry_point_equals_merge_plus_head():
         for name, a_, b_ in zip(("m2", "l", "out", "pooled", "v", "vhat", "vnorm", "logits", "incidence"), *outs):
             tol = 1e-5 * max(1.0, float(b_.abs().max()))
             assert float((a_ - b_).abs().max()) <= tol, (G, P, K, mode, name, float((a_ - b_).abs().max()))
+
+
+@pytest.mark.parametrize("B,P,K,mode", [(32, 12, 12, 0), (5, 7, 4, 1), (70, 16, 64, 2), (2, 1, 1, 0)])
+def test_head_forward_with_the_text_rows_normalised_in_the_pooling_launch(B, P, K, mode):
+    """vlsa_head_forward_batch_text (round 6: the training step's head in three launches) = vlsa_normalize_rows + vlsa_head_forward_batch,
+    bit for bit, for every pooling mode."""
+    import ctypes
+    from vlsa_amd import _native as nat
+    lib = nat.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4100 + B)
+    D = 512
+    rows = torch.randn(B, P, D, generator=g).to(dev)
+    T = (torch.randn(K, D, generator=g) * 3).to(dev)
+    W = (torch.randn(D, D, generator=g) * D ** -0.5).to(dev)
+    b = (torch.randn(D, generator=g) * 0.1).to(dev)
+    pw = torch.randn(P, generator=g).to(dev)
+    ls = torch.tensor([3.1], device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)  # noqa: E731
+    outs = []
+    for fused in (False, True):
+        That, tnorm, pooled, v, vhat, vnorm, logits = f(K, D), f(K), f(B, D), f(B, D), f(B, D), f(B), f(B, K)
+        if fused:
+            nat.check(lib.vlsa_head_forward_batch_text(p(rows), B, P, D, mode, p(pw), p(W), p(b), p(T), K, p(ls), p(That), p(tnorm), p(pooled),
+                                                       p(v), p(vhat), p(vnorm), p(logits), None, s), "text")
+        else:
+            tk = torch.zeros(B, dtype=torch.int32, device=dev)
+            nat.check(lib.vlsa_normalize_rows(p(T), K, D, p(That), p(tnorm), s), "norm")
+            nat.check(lib.vlsa_head_forward_batch(p(rows), B, P, D, mode, p(pw), p(W), p(b), p(That), K, p(ls), p(tk), p(pooled), p(v), p(vhat),
+                                                  p(vnorm), p(logits), None, s), "head")
+        outs.append((That, tnorm, pooled, v, vhat, vnorm, logits))
+    for a, c, name in zip(outs[0], outs[1], ("That", "tnorm", "pooled", "v", "vhat", "vnorm", "logits")):
+        if B == 1 and name in ("pooled",):
+            continue
+        assert torch.equal(a, c), name
