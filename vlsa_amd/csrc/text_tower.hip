@@ -28,7 +28,7 @@
 //                         waves), or identity.  The one product kernel serves forward, backward and the text projection.
 //                         Round 6: pro = LayerNorm BACKWARD as well (both LayerNorm backward passes of a block ride in front of the
 //                         products that consume them), and every product touches the NEXT product's weights -- one dword per
-//                         128-byte line, into the L2 of the XCD that will read them (prefetch_next) -- once its own ring is issued.
+//                         128-byte line, into the memory-side Infinity Cache as it turned out (prefetch_next) -- once its own ring is issued.
 //   k_tt_attn_fwd/bwd     per (prompt, head) attention over the compact rows: causal for token rows, explicit key list for
 //                         the CLS row; <= 128 rows forward, <= 64 rows backward.  Shared prefix: its keys' dK / dV come from one more
 //                         workgroup per (1-2 keys, head) over all query rows, from the row statistics and the output the forward
@@ -137,12 +137,12 @@ struct GemmArgs {
     // passes over the X2 slab and two barrier rounds
     float* stats_out;
     const float* stats_in;
-    // the NEXT product's weights (tiled [N' / 16][K' / 16][256]), pulled into the L2 of the XCD whose workgroups will read them while this
-    // product's MFMA loop drains its own ring (see prefetch_next): pf_tile_floats = floats of one of ITS column tiles (16 NTW' x K'),
+    // the NEXT product's weights (tiled [N' / 16][K' / 16][256]), pulled towards this product's workgroups' successors (into the
+    // Infinity Cache, as measured) while this product's MFMA loop drains its own ring (see prefetch_next): pf_tile_floats = floats of one of ITS column tiles (16 NTW' x K'),
     // pf_tiles_xcd = its whole rounds of 8 column tiles (tile t is read by XCD t % 8: the xcd_map of its launch)
     const float* pfW;
-    const float* pf2;      // a second region the next launches read on EVERY XCD (saved activations of the forward: the LayerNorm-backward
-    int pf2_lines;         // prologues' x, the attention backward's q / k / v): pf2_lines 128-byte lines, pulled into every XCD's L2
+    const float* pf2;      // a second region the next launches open with (saved activations of the forward: the LayerNorm-backward
+    int pf2_lines;         // prologues' x, the attention backward's q / k / v): pf2_lines 128-byte lines, touched once by the grid
     int pf_tile_floats, pf_tiles_xcd, pf_magic;     // pf_magic = 65536 / pf_tiles_xcd + 1: n / pf_tiles_xcd = (n * pf_magic) >> 16 for the small n here
     int ldr, ldy, ldh, N, K, MG, xcd_map, epi;
     int M_real;            // host only: rows that carry data (0: all M_pad rows); row groups behind them are not launched
@@ -174,8 +174,11 @@ __device__ long long tt_stamps[16];
 // Weight prefetch for the launch behind this one.  A product's workgroups all start by waiting for their first weight groups from HBM
 // (the tower's 340 MB of weights per pass never stay in the 256 MB Infinity Cache), ~2 us in which nothing else happens; the previous
 // launch has bandwidth to spare, so each of its threads touches up to kPfLoads 128-byte lines of the next product's weights -- one dword
-// per line, into the L2 of the XCD this workgroup runs on (block b -> XCD b % 8), which is the XCD whose workgroups read those column tiles
-// in the next launch.  Issued once the last ring refill is out (no later load of the wave queues behind them: vmcnt retires in order);
+// per line.  The lines are dealt so that block b (XCD b % 8) touches the column tiles XCD b % 8 will read in the next launch, but what the
+// counters show is that the L2s do NOT keep them across the kernel boundary: FETCH_SIZE per forward pass went from 660 to 985 MB
+// (profiles/r06_pmc_text_tower_prefetch.json against r06_pmc_text_tower.json: every product still fetches its own 2.4-9.4 MB and now
+// also the next one's) -- the second fetch is served by the memory-side Infinity Cache instead of HBM, and that is the gain
+// (forward 583 -> 540 us, 527 with every block on block 0's weights).  Issued once the last ring refill is out (no later load of the wave queues behind them: vmcnt retires in order);
 // the values are consumed by an empty asm at the end of the kernel.
 constexpr int kPfLoads = 4, kPf2Loads = 2, kPfRegs = kPfLoads + kPf2Loads;
 __device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, float (&pfv)[kPfRegs]) {
@@ -200,8 +203,8 @@ __device__ __forceinline__ void prefetch_next(const GemmArgs& p, int nthreads, f
     const int n2 = p.pf2 != nullptr ? p.pf2_lines : 1;
 #pragma unroll
     for (int u = 0; u < kPf2Loads; ++u) {
-        int o = (j + u * nj) * nthreads + (int)threadIdx.x;
-        o = o < n2 ? o : 0;
+        int o = ((int)blockIdx.x + u * (int)gridDim.x) * nthreads + (int)threadIdx.x;      // every line once, by the whole grid (see above: what
+        o = o < n2 ? o : 0;                                                                // is warmed is the memory-side cache, not an L2)
         pfv[kPfLoads + u] = b2[(size_t)o * 32];
     }
 }
