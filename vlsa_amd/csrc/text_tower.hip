@@ -1129,6 +1129,14 @@ __global__ __launch_bounds__(256) void k_tt_lnf_fwd(const float* __restrict__ x,
         for (int k = 0; k < nslot; ++k) pooled[tiled_index(s, lane + 64 * k, d)] = 0.f;
         return;
     }
+    // (the affine parameters are requested together with the row index: behind the statistics they were a third dependent round trip)
+    float gv[kLnSlots], bv[kLnSlots];
+#pragma unroll
+    for (int k = 0; k < kLnSlots; ++k)
+        if (k < nslot) {
+            gv[k] = gamma[lane + 64 * k];
+            bv[k] = beta[lane + 64 * k];
+        }
     const int row = seq_row0[s + 1] - 1;
     float xv[kLnSlots];
 #pragma unroll
@@ -1138,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_tt_lnf_fwd(const float* __restrict__ x,
     ln_stats(xv, nslot, d, mean, rstd);
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) pooled[tiled_index(s, lane + 64 * k, d)] = fmaf((xv[k] - mean) * rstd, gamma[lane + 64 * k], beta[lane + 64 * k]);
+        if (k < nslot) pooled[tiled_index(s, lane + 64 * k, d)] = fmaf((xv[k] - mean) * rstd, gv[k], bv[k]);
 }
 
 // dx[row] = ln_final backward of dpooled[s] on the CLS row of prompt s, zero on every other row.
@@ -1149,21 +1157,26 @@ __global__ __launch_bounds__(256) void k_tt_lnf_bwd(const float* __restrict__ dp
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M_pad) return;
     const int nslot = d >> 6;
-    if (row >= M || row_src[row] >= 0) {
+    // (one round of requests for everything that does not hang on another load: the row's source flag and prompt, its x, gamma; only
+    //  the prompt's d pooled row follows in a second round -- it was flag -> prompt -> rows, three dependent trips)
+    const int rsrc = row < M ? row_src[row] : 0, s = row < M ? row_seq[row] : 0;
+    float xv[kLnSlots], gv[kLnSlots];
+#pragma unroll
+    for (int k = 0; k < kLnSlots; ++k)
+        if (k < nslot) {
+            xv[k] = x[(size_t)row * d + lane + 64 * k];
+            gv[k] = gamma[lane + 64 * k];
+        }
+    if (row >= M || rsrc >= 0) {
         for (int k = 0; k < nslot; ++k) {
             dx[(size_t)row * d + lane + 64 * k] = 0.f;
             dxt[tiled_index(row, lane + 64 * k, d)] = 0.f;
         }
         return;
     }
-    const int s = row_seq[row];
-    float xv[kLnSlots], gv[kLnSlots];
 #pragma unroll
     for (int k = 0; k < kLnSlots; ++k)
-        if (k < nslot) {
-            xv[k] = x[(size_t)row * d + lane + 64 * k];
-            gv[k] = dpooled[(size_t)s * d + lane + 64 * k] * gamma[lane + 64 * k];
-        }
+        if (k < nslot) gv[k] *= dpooled[(size_t)s * d + lane + 64 * k];
     float mean, rstd;
     ln_stats(xv, nslot, d, mean, rstd);
     float sg = 0.f, sgx = 0.f;
