@@ -13,6 +13,9 @@
 // [2 h][4 g][12 p] layout so that a workgroup stays inside 80 KiB of LDS, hence P <= 12 here (the reference's datasets use
 // 7..12 prototypes); larger P goes through the per-bag kernel.
 #include "vlsa_common.h"
+#ifndef VLSA_DMA_NT
+#define VLSA_DMA_NT "nt"      // streaming rows: non-temporal (measurement builds may pass -DVLSA_DMA_NT=\"\")
+#endif
 
 namespace vlsa {
 
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_vlfan_backward_dma_batch(const BagDe
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %1\n\t"
                 "s_nop 0\n\t"
-                "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen " VLSA_DMA_NT " lds\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
                 : "s"(dst + i * 1024), "v"((i & 1) ? voff_o : voff_e), "s"(rsrc), "s"(sbase + i * 4 * ldb)

@@ -10,6 +10,9 @@
 //
 // Per-tile arithmetic, LDS image, exchange and epilogue are those of k_vlfan_partial_dma (vlfan_partial_dma.hip).
 #include "vlsa_common.h"
+#ifndef VLSA_DMA_NT
+#define VLSA_DMA_NT "nt"      // streaming rows: non-temporal (measurement builds may pass -DVLSA_DMA_NT=\"\")
+#endif
 
 namespace vlsa {
 
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void k_vlfan_partial_dma_batch(const BagDes
                 "s_mov_b32 %0, m0\n\t"
                 "s_mov_b32 m0, %1\n\t"
                 "s_nop 0\n\t"
-                "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen " VLSA_DMA_NT " lds\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
                 : "s"(dst + i * 1024), "v"((i & 1) ? voff_o : voff_e), "s"(rsrc), "s"(sbase + i * 4 * ldb)
